@@ -1,0 +1,72 @@
+"""Loader for the golden fixtures written by oracle/gen_golden.py (plain named arrays)."""
+import glob
+import os
+
+import numpy as np
+import torch
+
+from oracle import rnb_oracle as O
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def case_names():
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+
+
+class Golden:
+    def __init__(self, name):
+        self.name = name
+        z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False)
+        self.z = z
+        s = z["conf.sdf"]
+        sf = z["conf.sdf_f"]
+        c = z["conf.color"]
+        r = z["conf.render"]
+        rf = z["conf.render_f"]
+        self.mc = O.ModelConf(
+            sdf=O.SDFConf(d_in=int(s[0]), d_out=int(s[1]), d_hidden=int(s[2]), n_layers=int(s[3]),
+                          skip_in=(int(s[4]),) if s[4] >= 0 else (), multires=int(s[5]),
+                          bias=float(sf[0]), scale=float(sf[1])),
+            color=O.ColorConf(d_feature=int(c[0]), d_in=int(c[1]), d_out=int(c[2]), d_hidden=int(c[3]),
+                              n_layers=int(c[4]), multires_view=int(c[5])),
+            render=O.RenderConf(n_samples=int(r[0]), n_importance=int(r[1]), n_outside=int(r[2]),
+                                up_sample_steps=int(r[3]), perturb=float(rf[0])),
+            init_val=float(rf[1]))
+        self.api = str(z["meta.api"])
+        self.cos_anneal_ratio = float(z["meta.cos_anneal_ratio"])
+        self.no_albedo = bool(int(z["meta.no_albedo"]))
+        self.perturb_overwrite = float(z["meta.perturb_overwrite"])
+        self.grad_stride = int(z["meta.grad_stride"])
+        self.batch = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("in.")}
+        self.out = {k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("out.")}
+        self.grads = {k[5:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("grad.")}
+        self.gradnorm = {k[9:]: float(z[k]) for k in z.files if k.startswith("gradnorm.")}
+        self.n_steps = int(z["trace.n_steps"])
+        self.steps = []
+        for i in range(self.n_steps):
+            pre = f"trace.{i}."
+            self.steps.append({k[len(pre):]: torch.from_numpy(np.asarray(z[k])) for k in z.files
+                               if k.startswith(pre)})
+        self.has_weights = any(k.startswith("w.") for k in z.files)
+        self.wsum = {k[5:]: z[k] for k in z.files if k.startswith("wsum.")}
+
+    def params(self, requires_grad=False):
+        """Named parameters: stored arrays, or (full_*_geo) regenerated from seed 0 and verified
+        against the stored checksums."""
+        if self.has_weights:
+            p = {k[2:]: torch.from_numpy(self.z[k]).clone() for k in self.z.files if k.startswith("w.")}
+        else:
+            torch.manual_seed(0)
+            p = O.init_params(self.mc)
+            for k, chk in self.wsum.items():
+                d = p[k].double().reshape(-1)
+                got = np.array([float(d.sum()), float((d * d).sum()), float(d[0]), float(d[-1])])
+                np.testing.assert_allclose(got, chk, rtol=1e-12, atol=1e-12, err_msg=k)
+        if requires_grad:
+            for v in p.values():
+                v.requires_grad_(True)
+        return p
+
+    def background_rgb(self):
+        return self.batch.get("background_rgb")

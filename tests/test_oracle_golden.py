@@ -1,0 +1,83 @@
+"""Pins oracle/rnb_oracle.py (the CPU restatement) to golden vectors produced by the reference
+itself (oracle/gen_golden.py).  CPU only; runs in seconds."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import rnb_oracle as O
+from tests.golden_util import Golden, case_names
+
+CASES = case_names()
+
+
+def run_oracle(g: Golden, p):
+    b = g.batch
+    if g.api == "render":
+        return O.render(p, g.mc, b["rays_o"], b["rays_d"], b["near"], b["far"], t_rand=b["t_rand"],
+                        perturb_overwrite=g.perturb_overwrite, background_rgb=g.background_rgb(),
+                        cos_anneal_ratio=g.cos_anneal_ratio, trace={})
+    return O.render_rnb(p, g.mc, b["rays_o"], b["rays_d"], b["near"], b["far"], b["lights_dir"],
+                        t_rand=b["t_rand"], perturb_overwrite=g.perturb_overwrite,
+                        cos_anneal_ratio=g.cos_anneal_ratio, no_albedo=g.no_albedo,
+                        warmup=(g.api == "render_rnb_warmup"))
+
+
+def test_fixtures_present():
+    assert len(CASES) >= 8
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_sampling_indices_bit_exact(name):
+    g = Golden(name)
+    p = g.params()
+    b = g.batch
+    trace = {}
+    perturb = g.mc.render.perturb if g.perturb_overwrite < 0 else g.perturb_overwrite
+    z = O.sample_rays(p, g.mc, b["rays_o"], b["rays_d"], b["near"], b["far"], b["t_rand"], perturb, trace)
+    assert len(trace["steps"]) == g.n_steps
+    for i, (mine, ref) in enumerate(zip(trace["steps"], g.steps)):
+        assert torch.equal(mine["inds"], ref["inds"]), f"step {i} searchsorted indices"
+        assert torch.equal(mine["sort_index"], ref["sort_index"]), f"step {i} sort index"
+        assert torch.equal(mine["new_z"], ref["new_z"]), f"step {i} new z"
+        assert torch.equal(mine["z_out"], ref["z_out"]), f"step {i} merged z"
+    assert torch.equal(z, g.steps[-1]["z_out"])
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_render_outputs_and_grads(name):
+    g = Golden(name)
+    p = g.params(requires_grad=True)
+    out = run_oracle(g, p)
+    for k, ref in g.out.items():
+        if k == "loss":
+            continue
+        torch.testing.assert_close(out[k].detach(), ref, rtol=1e-5, atol=1e-6, msg=lambda m: f"{k}: {m}")
+    b = g.batch
+    if g.api == "render":
+        loss = (out["color_fine"] - b["true_rgb"][0]).abs().mean() + 0.1 * out["gradient_error"] \
+            + 0.1 * torch.nn.functional.binary_cross_entropy(
+                out["weight_sum"].clip(1e-3, 1 - 1e-3), (b["mask"] > 0.5).float())
+    else:
+        loss, _ = O.rnb_loss(out, b["true_rgb"], b["mask"])
+    torch.testing.assert_close(loss.detach(), g.out["loss"], rtol=1e-5, atol=1e-6)
+    loss.backward()
+    names_with_grad = {k for k, v in p.items() if v.grad is not None}
+    assert names_with_grad == set(g.grads.keys())
+    for k, ref in g.grads.items():
+        mine = p[k].grad.reshape(-1)[:: g.grad_stride]
+        denom = max(g.gradnorm[k], 1e-12)
+        rel = float((mine - ref).double().norm()) / (denom / np.sqrt(g.grad_stride))
+        assert rel < 1e-4, f"{k}: rel-L2 {rel:.3e}"
+
+
+def test_param_order_matches_reference_leaf_order():
+    g = Golden("tiny_warmup_geo")
+    # reference order = named_parameters order recorded when the fixture was written
+    ref_order = [k[2:] for k in g.z.files if k.startswith("w.")]
+    assert O.param_order(g.mc) == ref_order
+
+
+def test_geometric_init_reproduces_reference_state():
+    g = Golden("full_warmup_geo")
+    assert not g.has_weights
+    g.params()  # asserts the checksums of every tensor
