@@ -1,0 +1,219 @@
+/*
+ * rnbneus.h — C ABI of librnbneus_hip.so, the MI355X (gfx950) implementation of the RNb-NeuS
+ * volumetric SDF renderer hot path.
+ *
+ * The reference (rti-team-imvia/RNb-NeuS-fork) has no FFI layer: its boundary is the Python object
+ * protocol between exp_runner.py and models/{embedder,fields,renderer}.py.  Each entry point below
+ * names the reference interface it replaces (file:line relative to the reference root).  The Python
+ * drop-in classes in rnb-neus-fork_amd/ bind these symbols with ctypes (INTEGRATION.md shows the
+ * stub); nothing in the signatures depends on PyTorch: plain device pointers, sizes, a hipStream_t.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative RNB_E_* code; it never throws, never calls
+ *     exit and never synchronises the device.  rnb_last_error_string() describes the last failure on
+ *     the calling thread.
+ *   - all pointers are DEVICE pointers to fp32 (or int32 where stated) unless marked host.
+ *   - the caller owns every buffer (inputs, outputs, workspaces); the library allocates nothing that
+ *     outlives a call and keeps no mutable global state.  Work is enqueued on the given stream only.
+ *   - tensors are dense row-major with the shapes given in brackets.
+ */
+#ifndef RNBNEUS_H
+#define RNBNEUS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RNB_ABI_VERSION 1
+#define RNB_MAX_LIN 16 /* linear layers per MLP */
+
+enum {
+  RNB_OK = 0,
+  RNB_E_INVALID = -1,     /* bad argument / unsupported configuration */
+  RNB_E_WORKSPACE = -2,   /* workspace too small */
+  RNB_E_HIP = -3,         /* a HIP runtime call or launch failed */
+  RNB_E_NULL = -4         /* required pointer is NULL */
+};
+
+typedef void* rnb_stream_t; /* hipStream_t */
+
+/* Constructor arguments of the three networks and the renderer, i.e. the `model { ... }` block of
+ * confs/wmask_rnb.conf:53-90 as splatted into SDFNetwork(**conf) (models/fields.py:9-20),
+ * RenderingNetwork(**conf) (models/fields.py:132-141) and NeuSRenderer(**conf)
+ * (models/renderer.py:73-82). */
+typedef struct rnb_model_desc {
+  /* SDFNetwork */
+  int32_t sdf_d_in;       /* must be 3 */
+  int32_t sdf_d_out;      /* 1 + feature width (257) */
+  int32_t sdf_d_hidden;   /* 256 */
+  int32_t sdf_n_layers;   /* 8 hidden layers => 9 linear layers */
+  int32_t sdf_skip_in;    /* single skip layer index (4) or -1 */
+  int32_t sdf_multires;   /* 6 */
+  float   sdf_scale;      /* 1.0 */
+  int32_t sdf_weight_norm;
+  /* RenderingNetwork, mode "no_view_dir" only */
+  int32_t col_d_feature;  /* 256 */
+  int32_t col_d_in;       /* 6 (points + normals; view dirs are ignored in this mode) */
+  int32_t col_d_out;      /* 3 */
+  int32_t col_d_hidden;   /* 256 */
+  int32_t col_n_layers;   /* 2 hidden layers => 3 linear layers */
+  int32_t col_multires_view; /* 4 */
+  int32_t col_squeeze_out;   /* 1: sigmoid on the output */
+  int32_t col_weight_norm;
+  /* NeuSRenderer */
+  int32_t n_samples;      /* 64 */
+  int32_t n_importance;   /* 64 */
+  int32_t up_sample_steps;/* 4 */
+  int32_t reserved;
+} rnb_model_desc;
+
+/* Trainable leaves of one MLP in the reference's state_dict naming (linN.weight_g [out,1],
+ * linN.weight_v [out,in], linN.bias [out]).  With weight_norm == 0, v holds linN.weight and g is
+ * ignored. */
+typedef struct rnb_mlp_params {
+  int32_t n_lin;
+  int32_t pad_;
+  const float* g[RNB_MAX_LIN];
+  const float* v[RNB_MAX_LIN];
+  const float* b[RNB_MAX_LIN];
+} rnb_mlp_params;
+
+typedef struct rnb_mlp_grads { /* same shapes as rnb_mlp_params, written (not accumulated) */
+  int32_t n_lin;
+  int32_t pad_;
+  float* g[RNB_MAX_LIN];
+  float* v[RNB_MAX_LIN];
+  float* b[RNB_MAX_LIN];
+} rnb_mlp_grads;
+
+int rnb_abi_version(void);
+const char* rnb_last_error_string(void);
+
+/* ---- weight norm ------------------------------------------------------------------------------
+ * Replaces torch.nn.utils.weight_norm's forward/backward as applied at models/fields.py:72-74 and
+ * :168-170.  The forward materialises W = g * v / ||v||_row for every layer of both MLPs into one
+ * "packed" buffer (tile-padded, skip-layer 1/sqrt(2) folded in, layout private to the library) that
+ * all compute entry points consume; the backward maps a gradient buffer of the same layout back to
+ * the leaves. `color`/`color_grads` may be NULL (no_albedo training, exp_runner.py:111-112); `sdf` may be
+ * NULL when only the albedo network is evaluated (rnb_color_forward). */
+int rnb_packed_floats(const rnb_model_desc* desc, int64_t* n_floats);
+int rnb_weightnorm_fwd(const rnb_model_desc* desc, const rnb_mlp_params* sdf, const rnb_mlp_params* color,
+                       float* packed, rnb_stream_t stream);
+int rnb_weightnorm_bwd(const rnb_model_desc* desc, const rnb_mlp_params* sdf, const rnb_mlp_params* color,
+                       const float* packed_grad, const rnb_mlp_grads* sdf_grads,
+                       const rnb_mlp_grads* color_grads, rnb_stream_t stream);
+
+/* ---- point-wise network evaluation (no autograd) ---------------------------------------------
+ * rnb_sdf_forward   : SDFNetwork.forward / .sdf      (models/fields.py:82-108)
+ *                     sdf_out [n]; feat_out [n, d_out-1] or NULL
+ * rnb_sdf_gradient  : SDFNetwork.gradient            (models/fields.py:114-127), grad_out [n,3];
+ *                     sdf_out optional
+ * rnb_color_forward : RenderingNetwork.forward       (models/fields.py:177-215), out [n, d_out]
+ * Used by NeuSRenderer.extract_geometry's query_func (models/renderer.py:1219-1224), by the
+ * up-sampling loop and by tests. */
+int rnb_points_workspace_bytes(const rnb_model_desc* desc, int64_t n_points, int64_t* bytes);
+int rnb_sdf_forward(const rnb_model_desc* desc, const float* packed, const float* pts, int64_t n,
+                    float* sdf_out, float* feat_out, void* ws, size_t ws_bytes, rnb_stream_t stream);
+int rnb_sdf_gradient(const rnb_model_desc* desc, const float* packed, const float* pts, int64_t n,
+                     float* grad_out, float* sdf_out, void* ws, size_t ws_bytes, rnb_stream_t stream);
+int rnb_color_forward(const rnb_model_desc* desc, const float* packed, const float* pts,
+                      const float* normals, const float* feats, int64_t n, float* out, void* ws,
+                      size_t ws_bytes, rnb_stream_t stream);
+
+/* ---- hierarchical sampling ---------------------------------------------------------------------
+ * rnb_up_sample_step: one iteration of the loop at models/renderer.py:970-982 WITHOUT the network
+ *   call: NeuSRenderer.up_sample (:132-176) + sample_pdf(det=True) (:39-69) + the concat/sort half of
+ *   cat_z_vals (:178-183).  z_in [B,n] sorted, sdf_in [B,n];
+ *   outputs new_z [B,n_new], inds int32 [B,n_new] (= torch.searchsorted(cdf,u,right=True)),
+ *   z_out [B,n+n_new] sorted, sort_index int32 [B,n+n_new] (= index of torch.sort over cat[z,new_z]).
+ * rnb_gather_sdf: sdf_out[b,k] = cat[sdf_old, sdf_new][b, sort_index[b,k]]   (renderer.py:185-190)
+ * rnb_sample_rays: the whole no-grad prologue shared by render / render_rnb / render_rnb_warmup
+ *   (models/renderer.py:557-608 == :829-880 == :933-984): z = near + (far-near)*linspace(0,1,n_samples)
+ *   (+ (t_rand-0.5)*2/n_samples when t_rand != NULL), coarse SDF, up_sample_steps x (up_sample,
+ *   cat_z_vals incl. SDF evaluation of the new points).  z_vals_out [B, n_samples+n_importance].
+ *   `t_rand` [B] is the torch.rand([B,1]) draw of renderer.py:572, made by the caller. */
+int rnb_up_sample_step(const float* rays_o, const float* rays_d, const float* z_in, const float* sdf_in,
+                       int64_t B, int32_t n, int32_t n_new, float inv_s, float* new_z, int32_t* inds,
+                       float* z_out, int32_t* sort_index, rnb_stream_t stream);
+int rnb_gather_sdf(const float* sdf_old, const float* sdf_new, const int32_t* sort_index, int64_t B,
+                   int32_t n, int32_t n_new, float* sdf_out, rnb_stream_t stream);
+int rnb_sample_workspace_bytes(const rnb_model_desc* desc, int64_t B, int64_t* bytes);
+int rnb_sample_rays(const rnb_model_desc* desc, const float* packed, const float* rays_o,
+                    const float* rays_d, const float* near, const float* far, const float* t_rand,
+                    int64_t B, float* z_vals_out, void* ws, size_t ws_bytes, rnb_stream_t stream);
+
+/* ---- fine pass: render cores + wrappers ---------------------------------------------------------
+ * rnb_render_fwd evaluates NeuSRenderer.render_core (models/renderer.py:194-285; mode RNB_MODE_CORE,
+ * the composite of NeuSRenderer.render :632-648) or render_core_mvps (:466-554) followed by the
+ * multi-light shading composite of render_rnb (:1009-1033; RNB_MODE_MVPS) / render_rnb_warmup
+ * (:905-930; RNB_MODE_MVPS | RNB_FLAG_RELU_SHADING) on given sorted z_vals, and keeps what the
+ * backward needs in `ws`.  rnb_render_bwd is loss.backward() through that graph
+ * (exp_runner.py:261): it consumes gradients w.r.t. the returned tensors and writes gradients w.r.t.
+ * the packed weights and the variance scalar. */
+enum {
+  RNB_MODE_CORE = 0,            /* render(): colour = sum_s c*w (+ background_rgb) */
+  RNB_MODE_MVPS = 1,            /* render_rnb*: colour[l] = sum_s albedo*w*(n.l)    */
+  RNB_FLAG_RELU_SHADING = 2,    /* warm-up: relu on n.l (renderer.py:913)           */
+  RNB_FLAG_NO_ALBEDO = 4,       /* albedo := 1 (renderer.py:905-906, :1009-1010)    */
+  RNB_FLAG_LIGHT_PER_RAY = 8,   /* lights_dir is [L,B,3] instead of [L,3]           */
+  RNB_FLAG_FORWARD_ONLY = 16    /* no backward will follow                          */
+};
+
+typedef struct rnb_render_args {
+  int64_t B;              /* rays */
+  int32_t S;              /* samples per ray (n_samples + n_importance) */
+  int32_t n_lights;       /* L (MVPS) ; ignored for CORE */
+  int32_t flags;          /* RNB_MODE_* | RNB_FLAG_* */
+  float   cos_anneal_ratio;
+  const float* rays_o;    /* [B,3] */
+  const float* rays_d;    /* [B,3] */
+  const float* z_vals;    /* [B,S] sorted */
+  const float* lights_dir;/* [L,3] or [L,B,3] */
+  const float* background_rgb; /* [3] or NULL (CORE only, renderer.py:266-267) */
+  const float* variance;  /* [1] SingleVarianceNetwork.variance (models/fields.py:317-325) */
+  /* outputs (keys of the dict returned at renderer.py:638-648 / :1023-1033) */
+  float* color_fine;      /* MVPS: [L,B,C]  CORE: [B,3] ; C = col_d_out */
+  float* weights;         /* [B,S] */
+  float* cdf_fine;        /* [B,S] */
+  float* gradients;       /* [B,S,3] */
+  float* inside_sphere;   /* [B,S] */
+  float* weight_sum;      /* [B] */
+  float* weight_max;      /* [B] */
+  float* s_val;           /* [B] */
+  float* gradient_error;  /* [1] */
+  /* optional extra outputs of the cores (may be NULL) */
+  float* sdf;             /* [B*S] */
+  float* sampled_albedo;  /* [B*S,C] (network output, before the no_albedo override) */
+} rnb_render_args;
+
+typedef struct rnb_render_grads { /* d loss / d <output>; NULL = zero */
+  const float* color_fine;
+  const float* weights;
+  const float* cdf_fine;
+  const float* gradients;
+  const float* weight_sum;
+  const float* weight_max;
+  const float* s_val;
+  const float* gradient_error;
+} rnb_render_grads;
+
+int rnb_render_workspace_bytes(const rnb_model_desc* desc, int64_t B, int32_t S, int32_t flags,
+                               int64_t* bytes);
+int rnb_render_fwd(const rnb_model_desc* desc, const float* packed, const rnb_render_args* args,
+                   void* ws, size_t ws_bytes, rnb_stream_t stream);
+int rnb_render_bwd(const rnb_model_desc* desc, const float* packed, const rnb_render_args* args,
+                   const rnb_render_grads* gout, float* packed_grad, float* variance_grad, void* ws,
+                   size_t ws_bytes, rnb_stream_t stream);
+
+/* Name/duration of the heaviest kernel family, for bench.py's roofline line: fills `flops` with the
+ * algorithmic MLP FLOPs of one rnb_render_fwd+bwd (+ sampling) at the given shape. */
+int rnb_algorithmic_flops(const rnb_model_desc* desc, int64_t B, int32_t flags, double* train_flops,
+                          double* forward_flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RNBNEUS_H */

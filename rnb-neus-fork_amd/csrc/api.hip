@@ -1,0 +1,423 @@
+// C-ABI entry points of librnbneus_hip.so (declared in include/rnbneus.h).
+#include "rnb_internal.h"
+
+using namespace rnb;
+
+#define RNB_API extern "C" __attribute__((visibility("default")))
+
+#define RNB_REQUIRE(p, name) \
+  if (!(p)) RNB_FAIL(RNB_E_NULL, name " is NULL")
+
+RNB_API int rnb_abi_version(void) { return RNB_ABI_VERSION; }
+RNB_API const char* rnb_last_error_string(void) { return rnb::last_error(); }
+
+RNB_API int rnb_packed_floats(const rnb_model_desc* desc, int64_t* n_floats) {
+  RNB_REQUIRE(n_floats, "n_floats");
+  Layout L;
+  RNB_TRY(make_layout(desc, &L));
+  *n_floats = L.total;
+  return RNB_OK;
+}
+
+RNB_API int rnb_weightnorm_fwd(const rnb_model_desc* desc, const rnb_mlp_params* sdf, const rnb_mlp_params* color,
+                               float* packed, rnb_stream_t stream) {
+  RNB_REQUIRE(packed, "packed");
+  Layout L;
+  RNB_TRY(make_layout(desc, &L));
+  return weightnorm_fwd(desc, L, sdf, color, packed, (hipStream_t)stream);
+}
+
+RNB_API int rnb_weightnorm_bwd(const rnb_model_desc* desc, const rnb_mlp_params* sdf, const rnb_mlp_params* color,
+                               const float* packed_grad, const rnb_mlp_grads* sdf_grads,
+                               const rnb_mlp_grads* color_grads, rnb_stream_t stream) {
+  RNB_REQUIRE(packed_grad, "packed_grad");
+  Layout L;
+  RNB_TRY(make_layout(desc, &L));
+  return weightnorm_bwd(desc, L, sdf, color, packed_grad, sdf_grads, color_grads, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// point-wise evaluation
+// ---------------------------------------------------------------------------------------------------
+static const int kPointsMode = PM_WITH_NORMAL | PM_WITH_COLOR;
+
+RNB_API int rnb_points_workspace_bytes(const rnb_model_desc* desc, int64_t n_points, int64_t* bytes) {
+  RNB_REQUIRE(bytes, "bytes");
+  if (n_points < 0) RNB_FAIL(RNB_E_INVALID, "n_points < 0");
+  Layout L;
+  RNB_TRY(make_layout(desc, &L));
+  Carver c(nullptr, 0);
+  PointBufs pb;
+  carve_points(L, c, n_points, kPointsMode, &pb);
+  *bytes = (int64_t)c.off;
+  return RNB_OK;
+}
+
+static int points_setup(const rnb_model_desc* desc, int64_t n, void* ws, size_t ws_bytes, Layout* L, PointBufs* pb) {
+  RNB_TRY(make_layout(desc, L));
+  RNB_REQUIRE(ws, "workspace");
+  Carver c(ws, ws_bytes);
+  carve_points(*L, c, n, kPointsMode, pb);
+  if (!c.ok) RNB_FAIL(RNB_E_WORKSPACE, "workspace too small: need %zu bytes, have %zu", c.off, ws_bytes);
+  return RNB_OK;
+}
+
+RNB_API int rnb_sdf_forward(const rnb_model_desc* desc, const float* packed, const float* pts, int64_t n,
+                            float* sdf_out, float* feat_out, void* ws, size_t ws_bytes, rnb_stream_t stream) {
+  RNB_REQUIRE(packed, "packed");
+  RNB_REQUIRE(pts, "pts");
+  RNB_REQUIRE(sdf_out, "sdf_out");
+  if (n <= 0) return n == 0 ? RNB_OK : (set_error("n < 0"), RNB_E_INVALID);
+  hipStream_t s = (hipStream_t)stream;
+  Layout L;
+  PointBufs pb;
+  RNB_TRY(points_setup(desc, n, ws, ws_bytes, &L, &pb));
+  RNB_TRY(launch_pe_points(L, pts, n, pb, s));
+  RNB_TRY(sweep_forward(L, packed, pb, feat_out != nullptr, false, feat_out, s));
+  RNB_CHECK_HIP(hipMemcpyAsync(sdf_out, pb.sdf, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, s));
+  return RNB_OK;
+}
+
+RNB_API int rnb_sdf_gradient(const rnb_model_desc* desc, const float* packed, const float* pts, int64_t n,
+                             float* grad_out, float* sdf_out, void* ws, size_t ws_bytes, rnb_stream_t stream) {
+  RNB_REQUIRE(packed, "packed");
+  RNB_REQUIRE(pts, "pts");
+  RNB_REQUIRE(grad_out, "grad_out");
+  if (n <= 0) return n == 0 ? RNB_OK : (set_error("n < 0"), RNB_E_INVALID);
+  hipStream_t s = (hipStream_t)stream;
+  Layout L;
+  PointBufs pb;
+  RNB_TRY(points_setup(desc, n, ws, ws_bytes, &L, &pb));
+  RNB_TRY(launch_pe_points(L, pts, n, pb, s));
+  RNB_TRY(sweep_forward(L, packed, pb, false, true, nullptr, s));
+  RNB_TRY(sweep_reverse(L, packed, pb, s));
+  RNB_TRY(launch_copy_cols(pb.nrm, 4, 3, n, grad_out, s));
+  if (sdf_out) RNB_CHECK_HIP(hipMemcpyAsync(sdf_out, pb.sdf, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, s));
+  return RNB_OK;
+}
+
+RNB_API int rnb_color_forward(const rnb_model_desc* desc, const float* packed, const float* pts, const float* normals,
+                              const float* feats, int64_t n, float* out, void* ws, size_t ws_bytes,
+                              rnb_stream_t stream) {
+  RNB_REQUIRE(packed, "packed");
+  RNB_REQUIRE(pts, "pts");
+  RNB_REQUIRE(normals, "normals");
+  RNB_REQUIRE(feats, "feats");
+  RNB_REQUIRE(out, "out");
+  if (n <= 0) return n == 0 ? RNB_OK : (set_error("n < 0"), RNB_E_INVALID);
+  hipStream_t s = (hipStream_t)stream;
+  Layout L;
+  PointBufs pb;
+  RNB_TRY(points_setup(desc, n, ws, ws_bytes, &L, &pb));
+  if (L.F <= 0) RNB_FAIL(RNB_E_INVALID, "model has no feature head");
+  RNB_TRY(launch_fill_cols(feats, L.F, n, pb.Mp, L.Cinp, pb.cin, s));
+  RNB_TRY(sweep_color(L, packed, pb, pts, normals, 3, s));
+  RNB_TRY(launch_copy_cols(pb.alb, 4, L.Co, n, out, s));
+  return RNB_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// hierarchical sampling
+// ---------------------------------------------------------------------------------------------------
+RNB_API int rnb_up_sample_step(const float* rays_o, const float* rays_d, const float* z_in, const float* sdf_in,
+                               int64_t B, int32_t n, int32_t n_new, float inv_s, float* new_z, int32_t* inds,
+                               float* z_out, int32_t* sort_index, rnb_stream_t stream) {
+  RNB_REQUIRE(rays_o, "rays_o");
+  RNB_REQUIRE(rays_d, "rays_d");
+  RNB_REQUIRE(z_in, "z_in");
+  RNB_REQUIRE(sdf_in, "sdf_in");
+  RNB_REQUIRE(z_out, "z_out");
+  if (B <= 0) return B == 0 ? RNB_OK : (set_error("B < 0"), RNB_E_INVALID);
+  return launch_up_sample_step(rays_o, rays_d, z_in, sdf_in, nullptr, nullptr, n, B, n, n_new, inv_s, new_z, inds,
+                               z_out, sort_index, nullptr, nullptr, (hipStream_t)stream);
+}
+
+RNB_API int rnb_gather_sdf(const float* sdf_old, const float* sdf_new, const int32_t* sort_index, int64_t B,
+                           int32_t n, int32_t n_new, float* sdf_out, rnb_stream_t stream) {
+  RNB_REQUIRE(sdf_old, "sdf_old");
+  RNB_REQUIRE(sdf_new, "sdf_new");
+  RNB_REQUIRE(sort_index, "sort_index");
+  RNB_REQUIRE(sdf_out, "sdf_out");
+  if (B <= 0) return B == 0 ? RNB_OK : (set_error("B < 0"), RNB_E_INVALID);
+  return launch_gather_sdf(sdf_old, sdf_new, sort_index, B, n, n_new, sdf_out, (hipStream_t)stream);
+}
+
+struct SampleBufs {
+  float* z[2];
+  float* sdf[2];
+  int32_t* index;
+  float* pts;      // [B*n_samples,3] coarse points, later [B*n_new,3]
+  PointBufs pb;    // sized for B*n_samples points
+  size_t pb_off;   // carve offset of the point buffers
+};
+
+static void carve_sample(const Layout& L, const rnb_model_desc* d, Carver& c, int64_t B, SampleBufs* sb) {
+  const int S = d->n_samples + d->n_importance;
+  for (int i = 0; i < 2; ++i) sb->z[i] = c.take<float>(B * S);
+  for (int i = 0; i < 2; ++i) sb->sdf[i] = c.take<float>(B * S);
+  sb->index = c.take<int32_t>(B * S);
+  sb->pts = c.take<float>(B * d->n_samples * 3);
+  sb->pb_off = c.off;
+  carve_points(L, c, B * d->n_samples, PM_SDF_ONLY, &sb->pb);
+}
+
+static int check_sampling_desc(const rnb_model_desc* d) {
+  if (d->n_samples < 2) RNB_FAIL(RNB_E_INVALID, "n_samples must be >= 2");
+  if (d->n_importance < 0) RNB_FAIL(RNB_E_INVALID, "n_importance < 0");
+  if (d->n_importance > 0) {
+    if (d->up_sample_steps < 1 || d->n_importance % d->up_sample_steps != 0)
+      RNB_FAIL(RNB_E_INVALID, "n_importance (%d) must be a positive multiple of up_sample_steps (%d)",
+               d->n_importance, d->up_sample_steps);
+    if (d->n_importance / d->up_sample_steps > d->n_samples)
+      RNB_FAIL(RNB_E_INVALID, "n_importance/up_sample_steps must not exceed n_samples");
+  }
+  return RNB_OK;
+}
+
+RNB_API int rnb_sample_workspace_bytes(const rnb_model_desc* desc, int64_t B, int64_t* bytes) {
+  RNB_REQUIRE(bytes, "bytes");
+  Layout L;
+  RNB_TRY(make_layout(desc, &L));
+  RNB_TRY(check_sampling_desc(desc));
+  if (B < 0) RNB_FAIL(RNB_E_INVALID, "B < 0");
+  Carver c(nullptr, 0);
+  SampleBufs sb;
+  carve_sample(L, desc, c, B, &sb);
+  *bytes = (int64_t)c.off;
+  return RNB_OK;
+}
+
+RNB_API int rnb_sample_rays(const rnb_model_desc* desc, const float* packed, const float* rays_o, const float* rays_d,
+                            const float* near, const float* far, const float* t_rand, int64_t B, float* z_vals_out,
+                            void* ws, size_t ws_bytes, rnb_stream_t stream) {
+  RNB_REQUIRE(packed, "packed");
+  RNB_REQUIRE(rays_o, "rays_o");
+  RNB_REQUIRE(rays_d, "rays_d");
+  RNB_REQUIRE(near, "near");
+  RNB_REQUIRE(far, "far");
+  RNB_REQUIRE(z_vals_out, "z_vals_out");
+  if (B <= 0) return B == 0 ? RNB_OK : (set_error("B < 0"), RNB_E_INVALID);
+  hipStream_t s = (hipStream_t)stream;
+  Layout L;
+  RNB_TRY(make_layout(desc, &L));
+  RNB_TRY(check_sampling_desc(desc));
+  const int n0 = desc->n_samples;
+  if (desc->n_importance == 0) return launch_z_init(rays_o, rays_d, near, far, t_rand, B, n0, z_vals_out, nullptr, s);
+  RNB_REQUIRE(ws, "workspace");
+  Carver c(ws, ws_bytes);
+  SampleBufs sb;
+  carve_sample(L, desc, c, B, &sb);
+  if (!c.ok) RNB_FAIL(RNB_E_WORKSPACE, "workspace too small: need %zu bytes, have %zu", c.off, ws_bytes);
+  const int steps = desc->up_sample_steps;
+  const int n_new = desc->n_importance / steps;
+
+  RNB_TRY(launch_z_init(rays_o, rays_d, near, far, t_rand, B, n0, sb.z[0], sb.pts, s));
+  RNB_TRY(launch_pe_points(L, sb.pts, B * n0, sb.pb, s));
+  RNB_TRY(sweep_forward(L, packed, sb.pb, false, false, nullptr, s));
+  RNB_CHECK_HIP(hipMemcpyAsync(sb.sdf[0], sb.pb.sdf, (size_t)B * n0 * sizeof(float), hipMemcpyDeviceToDevice, s));
+  int cur = 0;
+  int n = n0;
+  for (int i = 0; i < steps; ++i) {
+    const bool last = (i + 1 == steps);
+    float* z_next = last ? z_vals_out : sb.z[cur ^ 1];
+    RNB_TRY(launch_up_sample_step(rays_o, rays_d, sb.z[cur], sb.sdf[cur], nullptr, nullptr, n, B, n, n_new,
+                                  (float)(64 << i), nullptr, nullptr, z_next, last ? nullptr : sb.index,
+                                  last ? nullptr : sb.pts, nullptr, s));
+    if (!last) {
+      // SDF of the new points (renderer.py:185), then carry the SDF row through the sort (:186-190)
+      Carver c2((char*)ws + sb.pb_off, ws_bytes - sb.pb_off);
+      PointBufs pbn;
+      carve_points(L, c2, B * n_new, PM_SDF_ONLY, &pbn);
+      RNB_TRY(launch_pe_points(L, sb.pts, B * n_new, pbn, s));
+      RNB_TRY(sweep_forward(L, packed, pbn, false, false, nullptr, s));
+      RNB_TRY(launch_gather_sdf(sb.sdf[cur], pbn.sdf, sb.index, B, n, n_new, sb.sdf[cur ^ 1], s));
+    }
+    cur ^= 1;
+    n += n_new;
+  }
+  return RNB_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// fine pass
+// ---------------------------------------------------------------------------------------------------
+struct RenderBufs {
+  float* pts;
+  float* dists;
+  float* gerr_part;
+  float* gerr_den;
+  float* invs_part;
+  PointBufs pb;
+};
+
+static int render_mode_of(int flags, const Layout& L) {
+  int mode = PM_WITH_NORMAL;
+  const bool use_color = !((flags & RNB_MODE_MVPS) && (flags & RNB_FLAG_NO_ALBEDO));
+  if (use_color) mode |= PM_WITH_COLOR;
+  if (!(flags & RNB_FLAG_FORWARD_ONLY)) mode |= PM_WITH_BACKWARD;
+  (void)L;
+  return mode;
+}
+
+static void carve_render(const Layout& L, Carver& c, int64_t B, int S, int flags, RenderBufs* rb) {
+  rb->pts = c.take<float>(B * S * 3);
+  rb->dists = c.take<float>(B * S);
+  rb->gerr_part = c.take<float>(B * 2);
+  rb->gerr_den = c.take<float>(1);
+  rb->invs_part = c.take<float>(B);
+  carve_points(L, c, B * S, render_mode_of(flags, L), &rb->pb);
+  if (!(render_mode_of(flags, L) & PM_WITH_COLOR)) rb->pb.alb = c.take<float>(rb->pb.Mp * 4);
+}
+
+RNB_API int rnb_render_workspace_bytes(const rnb_model_desc* desc, int64_t B, int32_t S, int32_t flags,
+                                       int64_t* bytes) {
+  RNB_REQUIRE(bytes, "bytes");
+  Layout L;
+  RNB_TRY(make_layout(desc, &L));
+  if (B < 0 || S < 1) RNB_FAIL(RNB_E_INVALID, "bad B/S");
+  Carver c(nullptr, 0);
+  RenderBufs rb;
+  carve_render(L, c, B, S, flags, &rb);
+  *bytes = (int64_t)c.off;
+  return RNB_OK;
+}
+
+static int render_setup(const rnb_model_desc* desc, const rnb_render_args* a, void* ws, size_t ws_bytes, Layout* L,
+                        RenderBufs* rb) {
+  RNB_TRY(make_layout(desc, L));
+  RNB_REQUIRE(a, "args");
+  RNB_REQUIRE(ws, "workspace");
+  if (a->B <= 0 || a->S < 1) RNB_FAIL(RNB_E_INVALID, "bad B/S");
+  const bool mvps = (a->flags & RNB_MODE_MVPS) != 0;
+  if (mvps && (a->n_lights < 1 || !a->lights_dir)) RNB_FAIL(RNB_E_INVALID, "MVPS mode needs lights");
+  if (L->F <= 0) RNB_FAIL(RNB_E_INVALID, "model has no feature head");
+  RNB_REQUIRE(a->rays_o, "rays_o");
+  RNB_REQUIRE(a->rays_d, "rays_d");
+  RNB_REQUIRE(a->z_vals, "z_vals");
+  RNB_REQUIRE(a->variance, "variance");
+  Carver c(ws, ws_bytes);
+  carve_render(*L, c, a->B, a->S, a->flags, rb);
+  if (!c.ok) RNB_FAIL(RNB_E_WORKSPACE, "workspace too small: need %zu bytes, have %zu", c.off, ws_bytes);
+  return RNB_OK;
+}
+
+static CompArgs comp_args_of(const Layout& L, const rnb_render_args* a, const RenderBufs& rb) {
+  CompArgs c;
+  memset(&c, 0, sizeof(c));
+  c.B = a->B;
+  c.S = a->S;
+  c.L = (a->flags & RNB_MODE_MVPS) ? a->n_lights : 1;
+  c.C = L.Co;
+  c.flags = a->flags;
+  c.cos_anneal = a->cos_anneal_ratio;
+  c.rays_d = a->rays_d;
+  c.pts = rb.pts;
+  c.dists = rb.dists;
+  c.sdf = rb.pb.sdf;
+  c.nrm = rb.pb.nrm;
+  c.alb = rb.pb.alb;
+  c.lights = a->lights_dir;
+  c.bg = (a->flags & RNB_MODE_MVPS) ? nullptr : a->background_rgb;
+  c.variance = a->variance;
+  c.color_fine = a->color_fine;
+  c.weights = a->weights;
+  c.cdf = a->cdf_fine;
+  c.gradients = a->gradients;
+  c.inside = a->inside_sphere;
+  c.weight_sum = a->weight_sum;
+  c.weight_max = a->weight_max;
+  c.s_val = a->s_val;
+  c.gerr_part = rb.gerr_part;
+  c.sdf_out = a->sdf;
+  c.albedo_out = (render_mode_of(a->flags, L) & PM_WITH_COLOR) ? a->sampled_albedo : nullptr;
+  return c;
+}
+
+RNB_API int rnb_render_fwd(const rnb_model_desc* desc, const float* packed, const rnb_render_args* a, void* ws,
+                           size_t ws_bytes, rnb_stream_t stream) {
+  RNB_REQUIRE(packed, "packed");
+  hipStream_t s = (hipStream_t)stream;
+  Layout L;
+  RenderBufs rb;
+  RNB_TRY(render_setup(desc, a, ws, ws_bytes, &L, &rb));
+  RNB_REQUIRE(a->color_fine, "color_fine");
+  RNB_REQUIRE(a->weights, "weights");
+  RNB_REQUIRE(a->cdf_fine, "cdf_fine");
+  RNB_REQUIRE(a->gradients, "gradients");
+  RNB_REQUIRE(a->inside_sphere, "inside_sphere");
+  RNB_REQUIRE(a->weight_sum, "weight_sum");
+  RNB_REQUIRE(a->weight_max, "weight_max");
+  RNB_REQUIRE(a->s_val, "s_val");
+  RNB_REQUIRE(a->gradient_error, "gradient_error");
+  const int mode = render_mode_of(a->flags, L);
+  const bool use_color = (mode & PM_WITH_COLOR) != 0;
+  RNB_TRY(launch_fine_points(a->rays_o, a->rays_d, a->z_vals, a->B, a->S, 2.0f / (float)desc->n_samples, rb.pts,
+                             rb.dists, s));
+  RNB_TRY(launch_pe_points(L, rb.pts, a->B * a->S, rb.pb, s));
+  RNB_TRY(sweep_forward(L, packed, rb.pb, use_color, true, nullptr, s));
+  RNB_TRY(sweep_reverse(L, packed, rb.pb, s));
+  if (use_color) RNB_TRY(sweep_color(L, packed, rb.pb, rb.pts, rb.pb.nrm, 4, s));
+  CompArgs c = comp_args_of(L, a, rb);
+  RNB_TRY(launch_composite_fwd(c, a->gradient_error, rb.gerr_den, s));
+  return RNB_OK;
+}
+
+RNB_API int rnb_render_bwd(const rnb_model_desc* desc, const float* packed, const rnb_render_args* a,
+                           const rnb_render_grads* gout, float* packed_grad, float* variance_grad, void* ws,
+                           size_t ws_bytes, rnb_stream_t stream) {
+  RNB_REQUIRE(packed, "packed");
+  RNB_REQUIRE(gout, "gout");
+  RNB_REQUIRE(packed_grad, "packed_grad");
+  RNB_REQUIRE(variance_grad, "variance_grad");
+  hipStream_t s = (hipStream_t)stream;
+  Layout L;
+  RenderBufs rb;
+  RNB_TRY(render_setup(desc, a, ws, ws_bytes, &L, &rb));
+  if (a->flags & RNB_FLAG_FORWARD_ONLY) RNB_FAIL(RNB_E_INVALID, "forward-only render has no backward state");
+  const int mode = render_mode_of(a->flags, L);
+  const bool use_color = (mode & PM_WITH_COLOR) != 0;
+  CompBwdArgs g;
+  memset(&g, 0, sizeof(g));
+  g.f = comp_args_of(L, a, rb);
+  g.weights = a->weights;
+  g.g_color = gout->color_fine;
+  g.g_weights = gout->weights;
+  g.g_cdf = gout->cdf_fine;
+  g.g_gradients = gout->gradients;
+  g.g_weight_sum = gout->weight_sum;
+  g.g_weight_max = gout->weight_max;
+  g.g_s_val = gout->s_val;
+  g.g_gerr = gout->gradient_error;
+  g.gerr_den = rb.gerr_den;
+  g.sbar = rb.pb.sbar;
+  g.nbar = rb.pb.nbar;
+  g.albbar = rb.pb.albbar;
+  g.invs_part = rb.invs_part;
+  RNB_TRY(launch_composite_bwd(g, variance_grad, s));
+  RNB_CHECK_HIP(hipMemsetAsync(packed_grad, 0, (size_t)L.total * sizeof(float), s));
+  RNB_TRY(sweep_backward(L, packed, rb.pb, use_color, packed_grad, s));
+  return RNB_OK;
+}
+
+// Algorithmic MLP FLOPs: multiply-accumulate counts of the real (unpadded) layer shapes.
+RNB_API int rnb_algorithmic_flops(const rnb_model_desc* desc, int64_t B, int32_t flags, double* train_flops,
+                                  double* forward_flops) {
+  Layout L;
+  RNB_TRY(make_layout(desc, &L));
+  double mac_s = 0;   // one SDF forward
+  for (int l = 0; l < L.nh; ++l) mac_s += (double)L.hid[l].N * L.hid[l].K;
+  mac_s += (double)(L.F + 1) * L.H;
+  double mac_c = 0;
+  for (int l = 0; l < L.nc; ++l) mac_c += (double)L.col[l].N * L.col[l].K;
+  mac_c += (double)L.colo.N * L.colo.K;
+  const bool use_color = !((flags & RNB_MODE_MVPS) && (flags & RNB_FLAG_NO_ALBEDO));
+  const double Fs = 2.0 * mac_s, Fc = 2.0 * mac_c;
+  const int S = desc->n_samples + desc->n_importance;
+  const int n_new = desc->n_importance > 0 ? desc->n_importance / desc->up_sample_steps : 0;
+  const double coarse_pts = desc->n_importance > 0 ? desc->n_samples + (double)n_new * (desc->up_sample_steps - 1) : 0;
+  const double per_ray_train = coarse_pts * Fs + S * 6.0 * Fs + (use_color ? S * 3.0 * Fc : 0.0);
+  const double per_ray_fwd = coarse_pts * Fs + S * 2.0 * Fs + (use_color ? S * Fc : 0.0);
+  if (train_flops) *train_flops = per_ray_train * (double)B;
+  if (forward_flops) *forward_flops = per_ray_fwd * (double)B;
+  return RNB_OK;
+}

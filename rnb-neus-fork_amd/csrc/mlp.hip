@@ -1,0 +1,591 @@
+// SDF / albedo network sweeps on a batch of points: forward (F), reverse-mode normal (R), albedo MLP (C)
+// and the explicit backward (C', RA, FB, dW) — see oracle/explicit.py for the mathematical statement and
+// the reference lines each stage replaces (models/fields.py:82-127, :177-215; the backward replaces
+// autograd's double backward invoked at exp_runner.py:261).
+#include "gemm.hip.h"
+#include "rnb_internal.h"
+
+namespace rnb {
+
+// =====================================================================================================
+// point-wise kernels
+// =====================================================================================================
+
+// positional encoding (models/embedder.py:40-46): e = [x, sin(2^k x), cos(2^k x)]_k, padded with zeros
+__global__ void pe_points_kernel(const float* __restrict__ pts, int64_t M, int64_t Mp, float scale, int multires,
+                                 int Ep, float* __restrict__ x4, float* __restrict__ e) {
+  int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= Mp) return;
+  float x[3] = {0.f, 0.f, 0.f};
+  if (row < M) {
+    x[0] = pts[row * 3 + 0] * scale;
+    x[1] = pts[row * 3 + 1] * scale;
+    x[2] = pts[row * 3 + 2] * scale;
+  }
+  x4[row * 4 + 0] = x[0]; x4[row * 4 + 1] = x[1]; x4[row * 4 + 2] = x[2]; x4[row * 4 + 3] = 0.f;
+  float* er = e + row * Ep;
+  er[0] = x[0]; er[1] = x[1]; er[2] = x[2];
+  int c = 3;
+  float f = 1.f;
+  for (int k = 0; k < multires; ++k) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      float s, co;
+      sincosf(x[d] * f, &s, &co);
+      er[c + d] = s;
+      er[c + 3 + d] = co;
+    }
+    c += 6;
+    f *= 2.f;
+  }
+  for (; c < Ep; ++c) er[c] = 0.f;
+}
+
+// sdf head: sdf = (a_last . w_sdf + b_sdf)/scale ; optionally seeds the reverse sweep gz_last = w_sdf * D
+// 32 lanes per point.
+__global__ void sdf_head_kernel(const float* __restrict__ a, int Hp, int H, const float* __restrict__ wsdf,
+                                const float* __restrict__ bsdf, float inv_scale, int64_t Mp,
+                                float* __restrict__ sdf, float* __restrict__ gz) {
+  const int sub = threadIdx.x & 31;
+  int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+  if (row >= Mp) return;
+  const float* ar = a + row * Hp;
+  float acc = 0.f;
+  for (int k = sub; k < Hp; k += 32) {
+    const float av = ar[k];
+    const float w = k < H ? wsdf[k] : 0.f;
+    acc = fmaf(av, w, acc);
+    if (gz) gz[row * Hp + k] = k < H ? w * softplus_D(av) : 0.f;
+  }
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 32);
+  if (sub == 0) sdf[row] = (acc + bsdf[0]) * inv_scale;
+}
+
+// normal = J_pe(x)^T g_e   (d sdf / d pts; models/fields.py:114-127)
+__global__ void normal_kernel(const float* __restrict__ x4, const float* __restrict__ ge, int Ep, int multires,
+                              int64_t Mp, float* __restrict__ nrm) {
+  int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= Mp) return;
+  const float* g = ge + row * Ep;
+  float n[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) n[d] = g[d];
+  float f = 1.f;
+  int c = 3;
+  for (int k = 0; k < multires; ++k) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      float s, co;
+      sincosf(x4[row * 4 + d] * f, &s, &co);
+      n[d] += f * (g[c + d] * co - g[c + 3 + d] * s);
+    }
+    c += 6;
+    f *= 2.f;
+  }
+  nrm[row * 4 + 0] = n[0]; nrm[row * 4 + 1] = n[1]; nrm[row * 4 + 2] = n[2]; nrm[row * 4 + 3] = 0.f;
+}
+
+// albedo-net input columns F.. : [pe_v(p) | pe_v(n) | 0]  (feature columns 0..F-1 are written by the
+// feature-head GEMM).  models/fields.py:179-191 in the packed column order.
+__global__ void color_input_kernel(const float* __restrict__ pts, const float* __restrict__ nrm, int nrm_ld,
+                                   int64_t M, int64_t Mp, int F, int multires, int Cinp,
+                                   float* __restrict__ cin) {
+  int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= Mp) return;
+  float* cr = cin + row * Cinp;
+  int c = F;
+  for (int which = 0; which < 2; ++which) {
+    float v[3] = {0.f, 0.f, 0.f};
+    if (row < M) {
+      if (which == 0) { v[0] = pts[row * 3]; v[1] = pts[row * 3 + 1]; v[2] = pts[row * 3 + 2]; }
+      else { v[0] = nrm[row * nrm_ld]; v[1] = nrm[row * nrm_ld + 1]; v[2] = nrm[row * nrm_ld + 2]; }
+    }
+    cr[c] = v[0]; cr[c + 1] = v[1]; cr[c + 2] = v[2];
+    c += 3;
+    float f = 1.f;
+    for (int k = 0; k < multires; ++k) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        float s, co;
+        sincosf(v[d] * f, &s, &co);
+        cr[c + d] = s;
+        cr[c + 3 + d] = co;
+      }
+      c += 6;
+      f *= 2.f;
+    }
+  }
+  for (; c < Cinp; ++c) cr[c] = 0.f;
+}
+
+// albedo output layer (d_out rows) + sigmoid: 32 lanes per point.
+__global__ void color_out_kernel(const float* __restrict__ ac, int Hcp, int Hc, const float* __restrict__ Wo,
+                                 int ldwo, const float* __restrict__ bo, int Co, int squeeze, int64_t Mp,
+                                 float* __restrict__ alb) {
+  const int sub = threadIdx.x & 31;
+  int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+  if (row >= Mp) return;
+  const float* ar = ac + row * Hcp;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int k = sub; k < Hc; k += 32) {
+    const float av = ar[k];
+    for (int c = 0; c < Co; ++c) acc[c] = fmaf(av, Wo[c * ldwo + k], acc[c]);
+  }
+  for (int c = 0; c < Co; ++c) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) acc[c] += __shfl_xor(acc[c], o, 32);
+  }
+  if (sub == 0) {
+    for (int c = 0; c < 4; ++c) {
+      float v = 0.f;
+      if (c < Co) {
+        v = acc[c] + bo[c];
+        if (squeeze) v = 1.f / (1.f + expf(-v));
+      }
+      alb[row * 4 + c] = v;
+    }
+  }
+}
+
+// backward of the albedo output layer: zo = albbar * alb(1-alb); zc_last = (zo Wo) * relu'(ac);
+// dWo += zo^T ac ; dbo += sum zo.   One workgroup handles `rows_per_blk` points; 256 threads = columns.
+__global__ void color_out_bwd_kernel(const float* __restrict__ albbar, const float* __restrict__ alb,
+                                     const float* __restrict__ ac, int Hcp, int Hc,
+                                     const float* __restrict__ Wo, int ldwo, int Co, int squeeze, int64_t M,
+                                     int rows_per_blk, float* __restrict__ zc, float* __restrict__ dWo,
+                                     float* __restrict__ dbo) {
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_blk;
+  const int64_t r1 = min(M, r0 + rows_per_blk);
+  for (int k = threadIdx.x; k < Hcp; k += blockDim.x) {
+    float w[4] = {0.f, 0.f, 0.f, 0.f}, dw[4] = {0.f, 0.f, 0.f, 0.f};
+    if (k < Hc)
+      for (int c = 0; c < Co; ++c) w[c] = Wo[c * ldwo + k];
+    for (int64_t row = r0; row < r1; ++row) {
+      float zo[4];
+      for (int c = 0; c < 4; ++c) {
+        const float a = alb[row * 4 + c];
+        zo[c] = c < Co ? albbar[row * 4 + c] * (squeeze ? a * (1.f - a) : 1.f) : 0.f;
+      }
+      const float av = ac[row * Hcp + k];
+      float t = 0.f;
+      for (int c = 0; c < Co; ++c) { t = fmaf(zo[c], w[c], t); dw[c] = fmaf(zo[c], av, dw[c]); }
+      zc[row * Hcp + k] = (k < Hc && av > 0.f) ? t : 0.f;
+    }
+    if (k < Hc)
+      for (int c = 0; c < Co; ++c) atomicAdd(dWo + c * ldwo + k, dw[c]);
+  }
+  if (threadIdx.x < Co) {
+    const int c = threadIdx.x;
+    float s = 0.f;
+    for (int64_t row = r0; row < r1; ++row) {
+      const float a = alb[row * 4 + c];
+      s += albbar[row * 4 + c] * (squeeze ? a * (1.f - a) : 1.f);
+    }
+    atomicAdd(dbo + c, s);
+  }
+}
+
+// nbar_total = nbar + J_pe(n)^T cinb[pe(n) block] ;  geb = J_pe(x) nbar_total  (input of the RA sweep)
+__global__ void nbar_geb_kernel(const float* __restrict__ x4, const float* __restrict__ nrm,
+                                const float* __restrict__ nbar_in, const float* __restrict__ cinb, int Cinp,
+                                int pen_off, int multires_view, int with_color, int multires, int Ep,
+                                int64_t M, int64_t Mp, float* __restrict__ geb) {
+  int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= Mp) return;
+  float nb[3] = {0.f, 0.f, 0.f};
+  if (row < M) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) nb[d] = nbar_in[row * 4 + d];
+    if (with_color) {
+      const float* g = cinb + row * Cinp + pen_off;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) nb[d] += g[d];
+      float f = 1.f;
+      int c = 3;
+      for (int k = 0; k < multires_view; ++k) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          float s, co;
+          sincosf(nrm[row * 4 + d] * f, &s, &co);
+          nb[d] += f * (g[c + d] * co - g[c + 3 + d] * s);
+        }
+        c += 6;
+        f *= 2.f;
+      }
+    }
+  }
+  float* o = geb + row * Ep;
+  o[0] = nb[0]; o[1] = nb[1]; o[2] = nb[2];
+  int c = 3;
+  float f = 1.f;
+  for (int k = 0; k < multires; ++k) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      float s, co;
+      sincosf(x4[row * 4 + d] * f, &s, &co);
+      o[c + d] = f * co * nb[d];
+      o[c + 3 + d] = -f * s * nb[d];
+    }
+    c += 6;
+    f *= 2.f;
+  }
+  for (; c < Ep; ++c) o[c] = 0.f;
+}
+
+// gradient of the sdf-head row: dw_sdf[k] += sum_rows ( sbar/scale * a_last + u_last ), db_sdf += sum sbar/scale
+__global__ void sdf_head_bwd_kernel(const float* __restrict__ a, const float* __restrict__ ulast, int Hp, int H,
+                                    const float* __restrict__ sbar, float inv_scale, int64_t M, int rows_per_blk,
+                                    float* __restrict__ dwsdf, float* __restrict__ dbsdf) {
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_blk;
+  const int64_t r1 = min(M, r0 + rows_per_blk);
+  for (int k = threadIdx.x; k < H; k += blockDim.x) {
+    float s = 0.f;
+    for (int64_t row = r0; row < r1; ++row)
+      s += sbar[row] * inv_scale * a[row * Hp + k] + ulast[row * Hp + k];
+    atomicAdd(dwsdf + k, s);
+  }
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int64_t row = r0; row < r1; ++row) s += sbar[row] * inv_scale;
+    atomicAdd(dbsdf, s);
+  }
+}
+
+// strided [rows, ld] (first ncols columns) -> dense [M, ncols]
+__global__ void copy_cols_kernel(const float* __restrict__ src, int ld, int ncols, int64_t M, float* __restrict__ out) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * ncols) return;
+  int64_t row = i / ncols;
+  int col = (int)(i - row * ncols);
+  out[i] = src[row * ld + col];
+}
+// dense [M, ncols] -> strided [Mp, ld] (rows >= M zero-filled)
+__global__ void fill_cols_kernel(const float* __restrict__ src, int ncols, int64_t M, int64_t Mp, int ld,
+                                 float* __restrict__ dst) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Mp * ncols) return;
+  int64_t row = i / ncols;
+  int col = (int)(i - row * ncols);
+  dst[row * ld + col] = row < M ? src[i] : 0.f;
+}
+
+// =====================================================================================================
+// GEMM epilogues
+// =====================================================================================================
+
+// F hidden layer: a = softplus(acc + b); columns >= N_real: PE override (layer feeding the skip layer) or 0
+struct EpiF {
+  const float* b;
+  float* out;
+  int ld;
+  int n_real;
+  const float* e;  // nullptr unless this layer feeds the skip layer
+  int Ep, pe;
+  __device__ void operator()(int row, int col, float v) const {
+    float a;
+    if (col < n_real) a = softplus100(v + b[col]);
+    else if (e != nullptr && col < n_real + pe) a = e[(size_t)row * Ep + (col - n_real)];
+    else a = 0.f;
+    out[(size_t)row * ld + col] = a;
+  }
+};
+// plain linear head (+bias) written to a strided buffer for columns < n_real
+struct EpiBias {
+  const float* b;
+  float* out;
+  int ld;
+  int n_real;
+  __device__ void operator()(int row, int col, float v) const {
+    if (col < n_real) out[(size_t)row * ld + col] = v + b[col];
+  }
+};
+struct EpiRelu {
+  const float* b;
+  float* out;
+  int ld;
+  int n_real;
+  __device__ void operator()(int row, int col, float v) const {
+    out[(size_t)row * ld + col] = col < n_real ? fmaxf(v + b[col], 0.f) : 0.f;
+  }
+};
+// R layer l>=1: g = acc ; skip layer: columns [k_split, k_split+pe) go to ge ; gz_{l-1} = g * D(a_{l-1})
+struct EpiR {
+  const float* a_prev;
+  float* gz_prev;
+  int ld;
+  int k_split;   // number of columns that belong to the previous layer's output
+  float* ge;     // destination of the skip part (or nullptr)
+  int Ep, pe;
+  __device__ void operator()(int row, int col, float v) const {
+    if (col < k_split) {
+      const size_t o = (size_t)row * ld + col;
+      gz_prev[o] = v * softplus_D(a_prev[o]);
+    } else {
+      if (ge != nullptr && col < k_split + pe) ge[(size_t)row * Ep + (col - k_split)] = v;
+      gz_prev[(size_t)row * ld + col] = 0.f;
+    }
+  }
+};
+// R layer 0: ge (+)= acc
+struct EpiR0 {
+  float* ge;
+  int Ep, pe;
+  int accumulate;
+  __device__ void operator()(int row, int col, float v) const {
+    const size_t o = (size_t)row * Ep + col;
+    if (col < pe) ge[o] = accumulate ? ge[o] + v : v;
+    else ge[o] = 0.f;
+  }
+};
+// RA layer l: gzb = acc ; zR_l = 100 gzb gz_l E ; u_{l+1} = gzb D  (PE-adjoint override when feeding the skip)
+struct EpiRA {
+  const float* a;
+  const float* gz;
+  float* zR;
+  float* u_next;
+  int ld;
+  int n_real;
+  const float* geb;  // nullptr unless this layer feeds the skip layer
+  int Ep, pe;
+  __device__ void operator()(int row, int col, float v) const {
+    const size_t o = (size_t)row * ld + col;
+    if (col < n_real) {
+      float D, E;
+      softplus_DE(a[o], D, E);
+      zR[o] = 100.f * v * gz[o] * E;
+      u_next[o] = v * D;
+    } else {
+      zR[o] = 0.f;
+      u_next[o] = (geb != nullptr && col < n_real + pe) ? geb[(size_t)row * Ep + (col - n_real)] : 0.f;
+    }
+  }
+};
+// FB: zb_{l-1} = (acc [+ sbar/scale * w_sdf]) * D(a_{l-1}) + zR_{l-1}
+struct EpiFB {
+  const float* a_prev;
+  const float* zR_prev;
+  float* zb_prev;
+  int ld;
+  int n_real;          // real width of layer l-1's output
+  const float* sbar;   // only for the head step
+  const float* wsdf;
+  float inv_scale;
+  __device__ void operator()(int row, int col, float v) const {
+    const size_t o = (size_t)row * ld + col;
+    if (col < n_real) {
+      if (sbar != nullptr) v = fmaf(sbar[row] * inv_scale, wsdf[col], v);
+      zb_prev[o] = fmaf(v, softplus_D(a_prev[o]), zR_prev[o]);
+    } else {
+      zb_prev[o] = 0.f;
+    }
+  }
+};
+// albedo backward through a relu layer: zc_{l-1} = acc * (ac_{l-1} > 0)
+struct EpiReluMask {
+  const float* ac_prev;
+  float* out;
+  int ld;
+  int n_real;
+  __device__ void operator()(int row, int col, float v) const {
+    const size_t o = (size_t)row * ld + col;
+    out[o] = (col < n_real && ac_prev[o] > 0.f) ? v : 0.f;
+  }
+};
+struct EpiStore {
+  float* out;
+  int ld;
+  __device__ void operator()(int row, int col, float v) const { out[(size_t)row * ld + col] = v; }
+};
+
+// =====================================================================================================
+// launch helpers
+// =====================================================================================================
+template <bool B_KMAJOR, class Epi>
+static int launch_rows(const float* A, int lda, const float* W, int ldw, int64_t Mp, int N, int K, const Epi& epi,
+                       hipStream_t s) {
+  dim3 grid((unsigned)(Mp / BM), (unsigned)((N + BN - 1) / BN));
+  hipLaunchKernelGGL((gemm_rows_kernel<B_KMAJOR, Epi>), grid, dim3(256), 0, s, A, lda, W, ldw, N, K, epi);
+  RNB_CHECK_LAUNCH();
+  return RNB_OK;
+}
+
+static int launch_dw(DwPair p1, DwPair p2, int npairs, int64_t M, int N, int K, float* dW, int lddw, float* db,
+                     int bias_pair, hipStream_t s) {
+  const int tiles = ((N + BM - 1) / BM) * ((K + BN - 1) / BN);
+  int splits = (int)((M + 511) / 512);              // >= 512 points per block
+  const int max_splits = (1024 + tiles - 1) / tiles;  // ~1024 blocks in flight
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  int rows = (int)((M + splits - 1) / splits);
+  rows = (rows + BK - 1) / BK * BK;
+  splits = (int)((M + rows - 1) / rows);
+  dim3 grid((unsigned)((N + BM - 1) / BM), (unsigned)((K + BN - 1) / BN), (unsigned)splits);
+  hipLaunchKernelGGL(gemm_dw_kernel, grid, dim3(256), 0, s, p1, p2, npairs, (int)M, N, K, rows, dW, lddw, db,
+                     bias_pair);
+  RNB_CHECK_LAUNCH();
+  return RNB_OK;
+}
+
+static inline unsigned blocks_for(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
+
+int launch_copy_cols(const float* src, int ld, int ncols, int64_t M, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(copy_cols_kernel, dim3(blocks_for(M * ncols, 256)), dim3(256), 0, s, src, ld, ncols, M, out);
+  RNB_CHECK_LAUNCH();
+  return RNB_OK;
+}
+int launch_fill_cols(const float* src, int ncols, int64_t M, int64_t Mp, int ld, float* dst, hipStream_t s) {
+  hipLaunchKernelGGL(fill_cols_kernel, dim3(blocks_for(Mp * ncols, 256)), dim3(256), 0, s, src, ncols, M, Mp, ld, dst);
+  RNB_CHECK_LAUNCH();
+  return RNB_OK;
+}
+
+int launch_pe_points(const Layout& L, const float* pts, int64_t M, PointBufs& pb, hipStream_t s) {
+  hipLaunchKernelGGL(pe_points_kernel, dim3(blocks_for(pb.Mp, 256)), dim3(256), 0, s, pts, M, pb.Mp, L.sdf_scale,
+                     L.multires, L.Ep, pb.x, pb.e);
+  RNB_CHECK_LAUNCH();
+  return RNB_OK;
+}
+
+// F: forward sweep (models/fields.py:82-104).  Needs pb.e; fills pb.a[*], pb.sdf, optionally the feature
+// block of pb.cin (need_feat) and the reverse-sweep seed pb.gz[nh-1] (need_gz_last).
+int sweep_forward(const Layout& L, const float* packed, PointBufs& pb, bool need_feat, bool need_gz_last,
+                  float* feat_dense, hipStream_t s) {
+  for (int l = 0; l < L.nh; ++l) {
+    const Lin& ln = L.hid[l];
+    const float* in = l == 0 ? pb.e : pb.a[l - 1];
+    const int lda = l == 0 ? L.Ep : L.Hp;
+    EpiF epi{packed + ln.b_off, pb.a[l], L.Hp, ln.N, (l + 1 == L.skip) ? pb.e : nullptr, L.Ep, L.pe};
+    RNB_TRY((launch_rows<false, EpiF>(in, lda, packed + ln.w_off, ln.Kp, pb.Mp, ln.Np, ln.Kp, epi, s)));
+  }
+  hipLaunchKernelGGL(sdf_head_kernel, dim3(blocks_for(pb.Mp * 32, 256)), dim3(256), 0, s, pb.a[L.nh - 1], L.Hp, L.H,
+                     packed + L.wsdf_off, packed + L.bsdf_off, 1.f / L.sdf_scale, pb.Mp, pb.sdf,
+                     need_gz_last ? pb.gz[L.nh - 1] : nullptr);
+  RNB_CHECK_LAUNCH();
+  if (need_feat) {
+    EpiBias epi{packed + L.feat.b_off, pb.cin, L.Cinp, L.F};
+    RNB_TRY((launch_rows<false, EpiBias>(pb.a[L.nh - 1], L.Hp, packed + L.feat.w_off, L.feat.Kp, pb.Mp, L.feat.Np,
+                                         L.feat.Kp, epi, s)));
+    if (feat_dense) {
+      RNB_TRY(launch_copy_cols(pb.cin, L.Cinp, L.F, pb.M, feat_dense, s));
+    }
+  }
+  return RNB_OK;
+}
+
+// R: reverse sweep for the normal (models/fields.py:114-127 without autograd).  Needs pb.a[*], pb.gz[nh-1].
+int sweep_reverse(const Layout& L, const float* packed, PointBufs& pb, hipStream_t s) {
+  for (int l = L.nh - 1; l >= 1; --l) {
+    const Lin& ln = L.hid[l];
+    const bool is_skip = (l == L.skip);
+    EpiR epi{pb.a[l - 1], pb.gz[l - 1], L.Hp, is_skip ? ln.K - L.pe : ln.K, is_skip ? pb.ge : nullptr, L.Ep, L.pe};
+    RNB_TRY((launch_rows<true, EpiR>(pb.gz[l], L.Hp, packed + ln.w_off, ln.Kp, pb.Mp, ln.Kp, ln.Np, epi, s)));
+  }
+  {
+    const Lin& ln = L.hid[0];
+    EpiR0 epi{pb.ge, L.Ep, L.pe, L.skip >= 1 ? 1 : 0};
+    RNB_TRY((launch_rows<true, EpiR0>(pb.gz[0], L.Hp, packed + ln.w_off, ln.Kp, pb.Mp, ln.Kp, ln.Np, epi, s)));
+  }
+  hipLaunchKernelGGL(normal_kernel, dim3(blocks_for(pb.Mp, 256)), dim3(256), 0, s, pb.x, pb.ge, L.Ep, L.multires,
+                     pb.Mp, pb.nrm);
+  RNB_CHECK_LAUNCH();
+  return RNB_OK;
+}
+
+// C: albedo network (models/fields.py:177-215, mode no_view_dir).  Needs the feature block of pb.cin and pb.nrm.
+int sweep_color(const Layout& L, const float* packed, PointBufs& pb, const float* pts, const float* nrm, int nrm_ld,
+                hipStream_t s) {
+  hipLaunchKernelGGL(color_input_kernel, dim3(blocks_for(pb.Mp, 256)), dim3(256), 0, s, pts, nrm, nrm_ld, pb.M, pb.Mp,
+                     L.F, L.multires_view, L.Cinp, pb.cin);
+  RNB_CHECK_LAUNCH();
+  for (int l = 0; l < L.nc; ++l) {
+    const Lin& ln = L.col[l];
+    const float* in = l == 0 ? pb.cin : pb.ac[l - 1];
+    const int lda = l == 0 ? L.Cinp : L.Hcp;
+    EpiRelu epi{packed + ln.b_off, pb.ac[l], L.Hcp, ln.N};
+    RNB_TRY((launch_rows<false, EpiRelu>(in, lda, packed + ln.w_off, ln.Kp, pb.Mp, ln.Np, ln.Kp, epi, s)));
+  }
+  hipLaunchKernelGGL(color_out_kernel, dim3(blocks_for(pb.Mp * 32, 256)), dim3(256), 0, s, pb.ac[L.nc - 1], L.Hcp,
+                     L.Hc, packed + L.colo.w_off, L.colo.Kp, packed + L.colo.b_off, L.Co, L.squeeze, pb.Mp, pb.alb);
+  RNB_CHECK_LAUNCH();
+  return RNB_OK;
+}
+
+// Backward of everything above given pb.sbar, pb.nbar, pb.albbar (from the composite backward).
+// packed_grad (same layout as `packed`) must be zero on entry; it receives dW_eff / db of every layer.
+int sweep_backward(const Layout& L, const float* packed, PointBufs& pb, bool with_color, float* packed_grad,
+                   hipStream_t s) {
+  const int64_t M = pb.M, Mp = pb.Mp;
+  // ---- C': albedo network backward ---------------------------------------------------------------
+  if (with_color) {
+    const int rows_per_blk = 64;
+    hipLaunchKernelGGL(color_out_bwd_kernel, dim3(blocks_for(M, rows_per_blk)), dim3(256), 0, s, pb.albbar, pb.alb,
+                       pb.ac[L.nc - 1], L.Hcp, L.Hc, packed + L.colo.w_off, L.colo.Kp, L.Co, L.squeeze, M,
+                       rows_per_blk, pb.zc[L.nc - 1], packed_grad + L.colo.w_off, packed_grad + L.colo.b_off);
+    RNB_CHECK_LAUNCH();
+    for (int l = L.nc - 1; l >= 0; --l) {
+      const Lin& ln = L.col[l];
+      const float* in = l == 0 ? pb.cin : pb.ac[l - 1];
+      const int ldin = l == 0 ? L.Cinp : L.Hcp;
+      DwPair p{pb.zc[l], L.Hcp, in, ldin};
+      RNB_TRY(launch_dw(p, p, 1, M, ln.Np, ln.Kp, packed_grad + ln.w_off, ln.Kp, packed_grad + ln.b_off, 0, s));
+      if (l > 0) {
+        EpiReluMask epi{pb.ac[l - 1], pb.zc[l - 1], L.Hcp, L.col[l - 1].N};
+        RNB_TRY((launch_rows<true, EpiReluMask>(pb.zc[l], L.Hcp, packed + ln.w_off, ln.Kp, Mp, ln.Kp, ln.Np, epi, s)));
+      } else {
+        EpiStore epi{pb.cinb, L.Cinp};
+        RNB_TRY((launch_rows<true, EpiStore>(pb.zc[0], L.Hcp, packed + ln.w_off, ln.Kp, Mp, ln.Kp, ln.Np, epi, s)));
+      }
+    }
+  }
+  // ---- nbar (+ albedo-net contribution) -> geb = u_0 -----------------------------------------------
+  hipLaunchKernelGGL(nbar_geb_kernel, dim3(blocks_for(Mp, 256)), dim3(256), 0, s, pb.x, pb.nrm, pb.nbar, pb.cinb,
+                     L.Cinp, L.F + L.pev, L.multires_view, with_color ? 1 : 0, L.multires, L.Ep, M, Mp, pb.geb);
+  RNB_CHECK_LAUNCH();
+  // ---- RA: adjoint of the reverse sweep, forward layer order -----------------------------------------
+  for (int l = 0; l < L.nh; ++l) {
+    const Lin& ln = L.hid[l];
+    const float* in = l == 0 ? pb.geb : pb.u[l];
+    const int lda = l == 0 ? L.Ep : L.Hp;
+    EpiRA epi{pb.a[l], pb.gz[l], pb.zR[l], pb.u[l + 1], L.Hp, ln.N, (l + 1 == L.skip) ? pb.geb : nullptr, L.Ep, L.pe};
+    RNB_TRY((launch_rows<false, EpiRA>(in, lda, packed + ln.w_off, ln.Kp, Mp, ln.Np, ln.Kp, epi, s)));
+  }
+  // ---- sdf-head row gradient ---------------------------------------------------------------------
+  {
+    const int rows_per_blk = 128;
+    hipLaunchKernelGGL(sdf_head_bwd_kernel, dim3(blocks_for(M, rows_per_blk)), dim3(256), 0, s, pb.a[L.nh - 1],
+                       pb.u[L.nh], L.Hp, L.H, pb.sbar, 1.f / L.sdf_scale, M, rows_per_blk,
+                       packed_grad + L.wsdf_off, packed_grad + L.bsdf_off);
+    RNB_CHECK_LAUNCH();
+  }
+  // ---- FB head: zb_{nh-1} = (fbar Wf + sbar/scale w_sdf) * D + zR ----------------------------------
+  {
+    EpiFB epi{pb.a[L.nh - 1], pb.zR[L.nh - 1], pb.zb[L.nh - 1], L.Hp, L.hid[L.nh - 1].N, pb.sbar,
+              packed + L.wsdf_off, 1.f / L.sdf_scale};
+    const int K = with_color ? L.feat.Np : 0;   // no_albedo: fbar == 0, the GEMM degenerates to its epilogue
+    RNB_TRY((launch_rows<true, EpiFB>(pb.cinb, L.Cinp, packed + L.feat.w_off, L.feat.Kp, Mp, L.feat.Kp, K, epi, s)));
+    if (with_color) {
+      DwPair p{pb.cinb, L.Cinp, pb.a[L.nh - 1], L.Hp};
+      RNB_TRY(launch_dw(p, p, 1, M, L.feat.Np, L.feat.Kp, packed_grad + L.feat.w_off, L.feat.Kp,
+                        packed_grad + L.feat.b_off, 0, s));
+    }
+  }
+  // ---- FB + dW, layers nh-1 .. 0 -------------------------------------------------------------------
+  for (int l = L.nh - 1; l >= 0; --l) {
+    const Lin& ln = L.hid[l];
+    const float* in = l == 0 ? pb.e : pb.a[l - 1];
+    const int ldin = l == 0 ? L.Ep : L.Hp;
+    const float* uin = l == 0 ? pb.geb : pb.u[l];
+    DwPair p1{pb.gz[l], L.Hp, uin, ldin};
+    DwPair p2{pb.zb[l], L.Hp, in, ldin};
+    RNB_TRY(launch_dw(p1, p2, 2, M, ln.Np, ln.Kp, packed_grad + ln.w_off, ln.Kp, packed_grad + ln.b_off, 1, s));
+    if (l > 0) {
+      const Lin& lp = L.hid[l - 1];
+      EpiFB epi{pb.a[l - 1], pb.zR[l - 1], pb.zb[l - 1], L.Hp, lp.N, nullptr, nullptr, 1.f};
+      RNB_TRY((launch_rows<true, EpiFB>(pb.zb[l], L.Hp, packed + ln.w_off, ln.Kp, Mp, ln.Kp, ln.Np, epi, s)));
+    }
+  }
+  return RNB_OK;
+}
+
+}  // namespace rnb

@@ -1,0 +1,204 @@
+// Internal declarations shared by the translation units of librnbneus_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/rnbneus.h"
+
+namespace rnb {
+
+constexpr int kPad = 32;          // every feature width is padded to the MFMA tile width
+constexpr int kRowPad = 128;      // point counts are padded to the GEMM block height
+inline int pad32(int x) { return (x + kPad - 1) / kPad * kPad; }
+inline int64_t pad_rows(int64_t m) { return (m + kRowPad - 1) / kRowPad * kRowPad; }
+
+void set_error(const char* fmt, ...);
+#define RNB_FAIL(code, ...)        \
+  do {                             \
+    ::rnb::set_error(__VA_ARGS__); \
+    return (code);                 \
+  } while (0)
+#define RNB_CHECK_HIP(expr)                                                          \
+  do {                                                                               \
+    hipError_t e_ = (expr);                                                          \
+    if (e_ != hipSuccess) RNB_FAIL(RNB_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+#define RNB_CHECK_LAUNCH() RNB_CHECK_HIP(hipGetLastError())
+#define RNB_TRY(expr)          \
+  do {                         \
+    int rc_ = (expr);          \
+    if (rc_ != RNB_OK) return rc_; \
+  } while (0)
+
+// One linear layer inside the packed (effective-weight) buffer: W [Np x Kp] row-major, then b [Np].
+struct Lin {
+  int N, K;        // real out / in widths
+  int Np, Kp;      // padded
+  int64_t w_off;   // float offset of W in the packed buffer
+  int64_t b_off;   // float offset of b
+  float scale;     // factor folded into W (1/sqrt2 for the skip layer)
+};
+
+// Packed layout of both networks (see weightnorm.hip for how leaves map onto it).
+struct Layout {
+  // SDF network: nh hidden layers (softplus) + output layer split into sdf row and feature rows
+  int nh;                 // number of hidden (softplus) layers = sdf_n_layers
+  int pe;                 // positional-encoding width (39)
+  int Ep;                 // padded pe width
+  int H, Hp;              // hidden width, padded
+  int skip;               // skip layer index or -1
+  Lin hid[RNB_MAX_LIN];   // hidden layers 0..nh-1
+  int F, Fp;              // feature width (d_out-1), padded
+  Lin feat;               // rows 1.. of the last layer (feature head)
+  int64_t wsdf_off;       // row 0 of the last layer [Hp]
+  int64_t bsdf_off;       // its bias [1] (padded to 32)
+  float sdf_scale;
+  int multires;
+  // albedo network: nc hidden (relu) layers + output layer (d_out rows, sigmoid)
+  int nc;
+  int pev;                // pe width of multires_view (27)
+  int Cin, Cinp;          // input width (F + 2*pev), padded
+  int Hc, Hcp;
+  int Co, Cop;            // d_out, padded to 32
+  Lin col[RNB_MAX_LIN];   // hidden layers 0..nc-1
+  Lin colo;               // output layer
+  int multires_view;
+  int squeeze;
+  int64_t total;          // floats in the packed buffer
+};
+
+int make_layout(const rnb_model_desc* d, Layout* L);
+
+// ---- workspace carving ------------------------------------------------------------------------
+struct Carver {
+  char* base;
+  size_t cap;
+  size_t off = 0;
+  bool ok = true;
+  Carver(void* p, size_t bytes) : base((char*)p), cap(bytes) {}
+  template <class T>
+  T* take(int64_t n) {
+    size_t bytes = ((size_t)n * sizeof(T) + 255) / 256 * 256;
+    T* p = (T*)(base ? base + off : nullptr);
+    off += bytes;
+    if (base && off > cap) ok = false;
+    return p;
+  }
+};
+
+// State of one batch of points going through the SDF (+albedo) network(s).  All activation matrices
+// are [Mp x width_padded] row-major fp32.
+struct PointBufs {
+  int64_t M, Mp;
+  float* x;       // [Mp,4]   scaled points (x,y,z,0)
+  float* e;       // [Mp,Ep]  positional encoding
+  float* a[RNB_MAX_LIN];   // hidden activations a_l  [Mp,Hp]
+  float* gz[RNB_MAX_LIN];  // reverse sweep state gz_l  [Mp,Hp]   (only with_normal)
+  float* ge;      // [Mp,Ep]  d sdf / d e
+  float* sdf;     // [Mp]
+  float* nrm;     // [Mp,4]   d sdf / d x
+  float* cin;     // [Mp,Cinp] albedo-net input  [feat | pe(p) | pe(n) | 0]
+  float* ac[RNB_MAX_LIN];  // albedo hidden activations [Mp,Hcp]
+  float* alb;     // [Mp,4]   albedo (network output)
+  // backward-only
+  float* u[RNB_MAX_LIN];   // RA sweep inputs u_l  (u[0] is [Mp,Ep])
+  float* zR[RNB_MAX_LIN];  // second-order term entering layer l's pre-activation adjoint
+  float* zb[RNB_MAX_LIN];  // pre-activation adjoints of F
+  float* geb;     // [Mp,Ep]  adjoint of ge
+  float* zc[RNB_MAX_LIN];  // albedo-net pre-activation adjoints
+  float* cinb;    // [Mp,Cinp] adjoint of cin
+  float* sbar;    // [Mp]
+  float* nbar;    // [Mp,4]
+  float* albbar;  // [Mp,4]
+};
+
+enum PointMode { PM_SDF_ONLY = 0, PM_WITH_NORMAL = 1, PM_WITH_COLOR = 2, PM_WITH_BACKWARD = 4 };
+void carve_points(const Layout& L, Carver& c, int64_t M, int mode, PointBufs* pb);
+
+// ---- device sweeps (mlp.hip) -------------------------------------------------------------------
+int launch_pe_points(const Layout& L, const float* pts, int64_t M, PointBufs& pb, hipStream_t s);
+int sweep_forward(const Layout& L, const float* packed, PointBufs& pb, bool need_feat, bool need_gz_last,
+                  float* feat_dense, hipStream_t s);
+int sweep_reverse(const Layout& L, const float* packed, PointBufs& pb, hipStream_t s);
+int sweep_color(const Layout& L, const float* packed, PointBufs& pb, const float* pts, const float* nrm, int nrm_ld,
+                hipStream_t s);
+int launch_copy_cols(const float* src, int ld, int ncols, int64_t M, float* out, hipStream_t s);
+int launch_fill_cols(const float* src, int ncols, int64_t M, int64_t Mp, int ld, float* dst, hipStream_t s);
+int sweep_backward(const Layout& L, const float* packed, PointBufs& pb, bool with_color, float* packed_grad,
+                   hipStream_t s);
+
+// ---- sampling / composite ------------------------------------------------------------------------
+int launch_up_sample_step(const float* rays_o, const float* rays_d, const float* z_in, const float* sdf_old,
+                          const float* sdf_new, const int32_t* gather_index, int n_old_for_gather,
+                          int64_t B, int n, int n_new, float inv_s, float* new_z, int32_t* inds,
+                          float* z_out, int32_t* sort_index, float* new_pts, float* sdf_sorted_out,
+                          hipStream_t s);
+
+// ---- composite (composite.hip) -------------------------------------------------------------------
+struct CompArgs {
+  int64_t B;
+  int S, L, C;
+  int flags;
+  float cos_anneal;
+  const float* rays_d;
+  const float* pts;       // [B*S,3]
+  const float* dists;     // [B,S]
+  const float* sdf;       // [Mp]
+  const float* nrm;       // [Mp,4]
+  const float* alb;       // [Mp,4] (network output)
+  const float* lights;    // [L,3] or [L,B,3]
+  const float* bg;        // [3] or nullptr
+  const float* variance;
+  // forward outputs
+  float* color_fine;
+  float* weights;
+  float* cdf;
+  float* gradients;
+  float* inside;
+  float* weight_sum;
+  float* weight_max;
+  float* s_val;
+  float* gerr_part;       // [B,2]
+  float* sdf_out;         // optional copies
+  float* albedo_out;
+};
+
+struct CompBwdArgs {
+  CompArgs f;
+  const float* weights;      // saved forward weights [B,S]
+  const float* g_color;      // cotangents (nullable)
+  const float* g_weights;
+  const float* g_cdf;
+  const float* g_gradients;
+  const float* g_weight_sum;
+  const float* g_weight_max;
+  const float* g_s_val;
+  const float* g_gerr;
+  const float* gerr_den;     // [1]
+  float* sbar;               // [Mp]
+  float* nbar;               // [Mp,4]
+  float* albbar;             // [Mp,4]
+  float* invs_part;          // [B] partial d loss / d inv_s
+};
+
+int launch_fine_points(const float* rays_o, const float* rays_d, const float* z, int64_t B, int S, float sample_dist,
+                       float* pts, float* dists, hipStream_t s);
+int launch_composite_fwd(const CompArgs& a, float* gerr, float* gerr_den, hipStream_t s);
+int launch_composite_bwd(const CompBwdArgs& g, float* dvar, hipStream_t s);
+
+// ---- sampling (sampling.hip) ---------------------------------------------------------------------
+int launch_z_init(const float* rays_o, const float* rays_d, const float* near, const float* far,
+                  const float* t_rand, int64_t B, int n, float* z, float* pts, hipStream_t s);
+int launch_gather_sdf(const float* sdf_old, const float* sdf_new, const int32_t* index, int64_t B, int n, int n_new,
+                      float* out, hipStream_t s);
+
+// ---- weight norm (weightnorm.hip) ------------------------------------------------------------------
+int weightnorm_fwd(const rnb_model_desc* d, const Layout& L, const rnb_mlp_params* sdf, const rnb_mlp_params* color,
+                   float* packed, hipStream_t s);
+int weightnorm_bwd(const rnb_model_desc* d, const Layout& L, const rnb_mlp_params* sdf, const rnb_mlp_params* color,
+                   const float* pgrad, const rnb_mlp_grads* gs, const rnb_mlp_grads* gc, hipStream_t s);
+const char* last_error();
+
+}  // namespace rnb

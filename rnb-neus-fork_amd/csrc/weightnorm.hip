@@ -1,0 +1,188 @@
+// Weight-norm materialisation W = g * v / ||v||_row (torch.nn.utils.weight_norm as applied at
+// models/fields.py:72-74 and :168-170) into the packed layout, and its backward.
+#include "rnb_internal.h"
+
+namespace rnb {
+
+struct WnEntry {
+  const float* g;   // [rows_src] or nullptr (no weight norm)
+  const float* v;   // [rows_src, K]
+  const float* b;   // [rows_src]
+  float* dg;        // backward outputs (same shapes) — nullptr in the forward
+  float* dv;
+  float* db;
+  int src_row0;     // first source row handled by this entry
+  int N;            // real rows handled
+  int Nrows;        // rows of the packed block to write (>= N; the rest is zero)
+  int K, Kp;
+  int row_begin;    // first global row (block index) of this entry
+  int cmap_f;       // >0: albedo layer 0 column permutation, value = F
+  int cmap_2pev;
+  long long w_off, b_off;
+  float scale;
+};
+constexpr int kMaxEntries = 2 * RNB_MAX_LIN + 2;
+struct WnTable {
+  int n;
+  int total_rows;
+  WnEntry e[kMaxEntries];
+};
+
+__device__ inline int cmap(const WnEntry& en, int i) {
+  if (en.cmap_f <= 0) return i;
+  return i < en.cmap_2pev ? en.cmap_f + i : i - en.cmap_2pev;
+}
+
+__device__ inline float block_sum(float v, float* red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += red[i];
+  return t;
+}
+
+__global__ __launch_bounds__(256) void wn_fwd_kernel(WnTable tab, float* __restrict__ packed) {
+  __shared__ float red[4];
+  int ei = 0;
+  while (ei + 1 < tab.n && (int)blockIdx.x >= tab.e[ei + 1].row_begin) ++ei;
+  const WnEntry& en = tab.e[ei];
+  const int r = blockIdx.x - en.row_begin;
+  float* wrow = packed + en.w_off + (long long)r * en.Kp;
+  if (r >= en.N) {
+    for (int c = threadIdx.x; c < en.Kp; c += blockDim.x) wrow[c] = 0.f;
+    if (threadIdx.x == 0) packed[en.b_off + r] = 0.f;
+    return;
+  }
+  const int src = en.src_row0 + r;
+  const float* vrow = en.v + (long long)src * en.K;
+  float mult = en.scale;
+  if (en.g != nullptr) {
+    float ss = 0.f;
+    for (int i = threadIdx.x; i < en.K; i += blockDim.x) ss = fmaf(vrow[i], vrow[i], ss);
+    ss = block_sum(ss, red);
+    mult = en.scale * (en.g[src] / sqrtf(ss));
+  }
+  for (int i = threadIdx.x; i < en.K; i += blockDim.x) wrow[cmap(en, i)] = vrow[i] * mult;
+  for (int c = en.K + threadIdx.x; c < en.Kp; c += blockDim.x) wrow[c] = 0.f;
+  if (threadIdx.x == 0) packed[en.b_off + r] = en.b[src];
+}
+
+__global__ __launch_bounds__(256) void wn_bwd_kernel(WnTable tab, const float* __restrict__ pgrad) {
+  __shared__ float red[4];
+  int ei = 0;
+  while (ei + 1 < tab.n && (int)blockIdx.x >= tab.e[ei + 1].row_begin) ++ei;
+  const WnEntry& en = tab.e[ei];
+  const int r = blockIdx.x - en.row_begin;
+  if (r >= en.N) return;
+  const int src = en.src_row0 + r;
+  const float* vrow = en.v + (long long)src * en.K;
+  const float* dwrow = pgrad + en.w_off + (long long)r * en.Kp;
+  float* dvrow = en.dv + (long long)src * en.K;
+  if (en.g == nullptr) {
+    for (int i = threadIdx.x; i < en.K; i += blockDim.x) dvrow[i] = en.scale * dwrow[cmap(en, i)];
+  } else {
+    float ss = 0.f, t = 0.f;
+    for (int i = threadIdx.x; i < en.K; i += blockDim.x) {
+      const float vv = vrow[i];
+      ss = fmaf(vv, vv, ss);
+      t = fmaf(dwrow[cmap(en, i)], vv, t);
+    }
+    ss = block_sum(ss, red);
+    t = block_sum(t, red);
+    const float inv_norm = 1.f / sqrtf(ss);
+    const float gg = en.g[src];
+    const float coef = en.scale * gg * inv_norm;
+    const float proj = t * inv_norm * inv_norm;   // (v . dW) / ||v||^2
+    for (int i = threadIdx.x; i < en.K; i += blockDim.x) dvrow[i] = coef * (dwrow[cmap(en, i)] - vrow[i] * proj);
+    if (threadIdx.x == 0) en.dg[src] = en.scale * t * inv_norm;
+  }
+  if (threadIdx.x == 0) en.db[src] = pgrad[en.b_off + r];
+}
+
+static void add_entry(WnTable& t, const rnb_mlp_params* p, const rnb_mlp_grads* g, int lin, bool wn, int src_row0,
+                      int N, int Nrows, int K, int Kp, long long w_off, long long b_off, float scale, int cmap_f,
+                      int cmap_2pev) {
+  WnEntry& e = t.e[t.n];
+  e.g = wn ? p->g[lin] : nullptr;
+  e.v = p->v[lin];
+  e.b = p->b[lin];
+  e.dg = (g && wn) ? g->g[lin] : nullptr;
+  e.dv = g ? g->v[lin] : nullptr;
+  e.db = g ? g->b[lin] : nullptr;
+  e.src_row0 = src_row0;
+  e.N = N;
+  e.Nrows = Nrows;
+  e.K = K;
+  e.Kp = Kp;
+  e.row_begin = t.total_rows;
+  e.cmap_f = cmap_f;
+  e.cmap_2pev = cmap_2pev;
+  e.w_off = w_off;
+  e.b_off = b_off;
+  e.scale = scale;
+  t.total_rows += Nrows;
+  t.n++;
+}
+
+static int build_table(const rnb_model_desc* d, const Layout& L, const rnb_mlp_params* sdf,
+                       const rnb_mlp_params* color, const rnb_mlp_grads* gs, const rnb_mlp_grads* gc, WnTable& t) {
+  t.n = 0;
+  t.total_rows = 0;
+  if (!sdf && !color) RNB_FAIL(RNB_E_NULL, "both parameter sets are NULL");
+  if (sdf) {
+    if (sdf->n_lin != L.nh + 1) RNB_FAIL(RNB_E_INVALID, "sdf params: n_lin %d != %d", sdf->n_lin, L.nh + 1);
+    const bool wn = d->sdf_weight_norm != 0;
+    for (int l = 0; l <= L.nh; ++l)
+      if (!sdf->v[l] || !sdf->b[l] || (wn && !sdf->g[l])) RNB_FAIL(RNB_E_NULL, "sdf lin%d has a NULL leaf", l);
+    for (int l = 0; l < L.nh; ++l) {
+      const Lin& ln = L.hid[l];
+      add_entry(t, sdf, gs, l, wn, 0, ln.N, ln.Np, ln.K, ln.Kp, ln.w_off, ln.b_off, ln.scale, 0, 0);
+    }
+    // output layer: row 0 -> sdf head, rows 1.. -> feature head
+    add_entry(t, sdf, gs, L.nh, wn, 0, 1, 1, L.H, L.Hp, L.wsdf_off, L.bsdf_off, 1.f, 0, 0);
+    if (L.F > 0)
+      add_entry(t, sdf, gs, L.nh, wn, 1, L.F, L.feat.Np, L.H, L.feat.Kp, L.feat.w_off, L.feat.b_off, 1.f, 0, 0);
+  }
+  if (color) {
+    if (L.F <= 0) RNB_FAIL(RNB_E_INVALID, "albedo network needs a feature head");
+    if (color->n_lin != L.nc + 1) RNB_FAIL(RNB_E_INVALID, "color params: n_lin %d != %d", color->n_lin, L.nc + 1);
+    const bool wc = d->col_weight_norm != 0;
+    for (int l = 0; l <= L.nc; ++l)
+      if (!color->v[l] || !color->b[l] || (wc && !color->g[l])) RNB_FAIL(RNB_E_NULL, "color lin%d has a NULL leaf", l);
+    for (int l = 0; l < L.nc; ++l) {
+      const Lin& ln = L.col[l];
+      add_entry(t, color, gc, l, wc, 0, ln.N, ln.Np, ln.K, ln.Kp, ln.w_off, ln.b_off, 1.f, l == 0 ? L.F : 0,
+                l == 0 ? 2 * L.pev : 0);
+    }
+    add_entry(t, color, gc, L.nc, wc, 0, L.colo.N, L.colo.Np, L.colo.K, L.colo.Kp, L.colo.w_off, L.colo.b_off, 1.f, 0, 0);
+  }
+  return RNB_OK;
+}
+
+int weightnorm_fwd(const rnb_model_desc* d, const Layout& L, const rnb_mlp_params* sdf, const rnb_mlp_params* color,
+                   float* packed, hipStream_t s) {
+  WnTable t;
+  RNB_TRY(build_table(d, L, sdf, color, nullptr, nullptr, t));
+  hipLaunchKernelGGL(wn_fwd_kernel, dim3(t.total_rows), dim3(256), 0, s, t, packed);
+  RNB_CHECK_LAUNCH();
+  return RNB_OK;
+}
+
+int weightnorm_bwd(const rnb_model_desc* d, const Layout& L, const rnb_mlp_params* sdf, const rnb_mlp_params* color,
+                   const float* pgrad, const rnb_mlp_grads* gs, const rnb_mlp_grads* gc, hipStream_t s) {
+  if (sdf && !gs) RNB_FAIL(RNB_E_NULL, "sdf grads are NULL");
+  if (color && !gc) RNB_FAIL(RNB_E_NULL, "color grads are NULL");
+  WnTable t;
+  RNB_TRY(build_table(d, L, sdf, color, gs, gc, t));
+  for (int i = 0; i < t.n; ++i)
+    if (!t.e[i].dv || !t.e[i].db || (t.e[i].g && !t.e[i].dg)) RNB_FAIL(RNB_E_NULL, "a gradient leaf is NULL");
+  hipLaunchKernelGGL(wn_bwd_kernel, dim3(t.total_rows), dim3(256), 0, s, t, pgrad);
+  RNB_CHECK_LAUNCH();
+  return RNB_OK;
+}
+
+}  // namespace rnb

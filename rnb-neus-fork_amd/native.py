@@ -1,0 +1,137 @@
+"""ctypes binding of librnbneus_hip.so (include/rnbneus.h).  There is no CPU fallback: if the library
+is missing or a symbol is absent, loading fails loudly."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librnbneus_hip.so")
+ABI_VERSION = 1
+MAX_LIN = 16
+
+MODE_CORE = 0
+MODE_MVPS = 1
+FLAG_RELU_SHADING = 2
+FLAG_NO_ALBEDO = 4
+FLAG_LIGHT_PER_RAY = 8
+FLAG_FORWARD_ONLY = 16
+
+c_float_p = C.c_void_p  # device pointers are passed as integers
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [
+        ("sdf_d_in", C.c_int32), ("sdf_d_out", C.c_int32), ("sdf_d_hidden", C.c_int32),
+        ("sdf_n_layers", C.c_int32), ("sdf_skip_in", C.c_int32), ("sdf_multires", C.c_int32),
+        ("sdf_scale", C.c_float), ("sdf_weight_norm", C.c_int32),
+        ("col_d_feature", C.c_int32), ("col_d_in", C.c_int32), ("col_d_out", C.c_int32),
+        ("col_d_hidden", C.c_int32), ("col_n_layers", C.c_int32), ("col_multires_view", C.c_int32),
+        ("col_squeeze_out", C.c_int32), ("col_weight_norm", C.c_int32),
+        ("n_samples", C.c_int32), ("n_importance", C.c_int32), ("up_sample_steps", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+class MlpParams(C.Structure):
+    _fields_ = [("n_lin", C.c_int32), ("pad_", C.c_int32),
+                ("g", C.c_void_p * MAX_LIN), ("v", C.c_void_p * MAX_LIN), ("b", C.c_void_p * MAX_LIN)]
+
+
+MlpGrads = MlpParams  # identical layout (non-const pointers)
+
+
+class RenderArgs(C.Structure):
+    _fields_ = [
+        ("B", C.c_int64), ("S", C.c_int32), ("n_lights", C.c_int32), ("flags", C.c_int32),
+        ("cos_anneal_ratio", C.c_float),
+        ("rays_o", C.c_void_p), ("rays_d", C.c_void_p), ("z_vals", C.c_void_p), ("lights_dir", C.c_void_p),
+        ("background_rgb", C.c_void_p), ("variance", C.c_void_p),
+        ("color_fine", C.c_void_p), ("weights", C.c_void_p), ("cdf_fine", C.c_void_p),
+        ("gradients", C.c_void_p), ("inside_sphere", C.c_void_p), ("weight_sum", C.c_void_p),
+        ("weight_max", C.c_void_p), ("s_val", C.c_void_p), ("gradient_error", C.c_void_p),
+        ("sdf", C.c_void_p), ("sampled_albedo", C.c_void_p),
+    ]
+
+
+class RenderGrads(C.Structure):
+    _fields_ = [("color_fine", C.c_void_p), ("weights", C.c_void_p), ("cdf_fine", C.c_void_p),
+                ("gradients", C.c_void_p), ("weight_sum", C.c_void_p), ("weight_max", C.c_void_p),
+                ("s_val", C.c_void_p), ("gradient_error", C.c_void_p)]
+
+
+_P = C.POINTER
+_SIGNATURES = {
+    "rnb_abi_version": (C.c_int, []),
+    "rnb_last_error_string": (C.c_char_p, []),
+    "rnb_packed_floats": (C.c_int, [_P(ModelDesc), _P(C.c_int64)]),
+    "rnb_weightnorm_fwd": (C.c_int, [_P(ModelDesc), _P(MlpParams), _P(MlpParams), C.c_void_p, C.c_void_p]),
+    "rnb_weightnorm_bwd": (C.c_int, [_P(ModelDesc), _P(MlpParams), _P(MlpParams), C.c_void_p, _P(MlpGrads),
+                                     _P(MlpGrads), C.c_void_p]),
+    "rnb_points_workspace_bytes": (C.c_int, [_P(ModelDesc), C.c_int64, _P(C.c_int64)]),
+    "rnb_sdf_forward": (C.c_int, [_P(ModelDesc), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rnb_sdf_gradient": (C.c_int, [_P(ModelDesc), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rnb_color_forward": (C.c_int, [_P(ModelDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                    C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rnb_up_sample_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
+                                     C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p]),
+    "rnb_gather_sdf": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
+                                 C.c_void_p, C.c_void_p]),
+    "rnb_sample_workspace_bytes": (C.c_int, [_P(ModelDesc), C.c_int64, _P(C.c_int64)]),
+    "rnb_sample_rays": (C.c_int, [_P(ModelDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rnb_render_workspace_bytes": (C.c_int, [_P(ModelDesc), C.c_int64, C.c_int32, C.c_int32, _P(C.c_int64)]),
+    "rnb_render_fwd": (C.c_int, [_P(ModelDesc), C.c_void_p, _P(RenderArgs), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rnb_render_bwd": (C.c_int, [_P(ModelDesc), C.c_void_p, _P(RenderArgs), _P(RenderGrads), C.c_void_p,
+                                 C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rnb_algorithmic_flops": (C.c_int, [_P(ModelDesc), C.c_int64, C.c_int32, _P(C.c_double), _P(C.c_double)]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES.keys())
+
+_lib = None
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def load():
+    """Loads the shared library once and checks every symbol declared in include/rnbneus.h."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeError(
+            f"{LIB_PATH} is missing: build it with `python __graft_entry__.py` (hipcc, gfx950). "
+            "There is no CPU fallback for the renderer.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in _SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise NativeError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = restype
+        fn.argtypes = argtypes
+    v = lib.rnb_abi_version()
+    if v != ABI_VERSION:
+        raise NativeError(f"ABI version mismatch: library {v}, binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc: int):
+    if rc != 0:
+        msg = load().rnb_last_error_string()
+        raise NativeError(f"librnbneus_hip error {rc}: {msg.decode() if msg else '?'}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL).  Tensors must be contiguous fp32/int32."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "native call needs contiguous tensors"
+    return C.c_void_p(t.data_ptr())

@@ -1,0 +1,314 @@
+"""Drop-in NeuSRenderer (models/renderer.py:72-1224) backed by librnbneus_hip.so.
+
+Same constructor, same `render`, `render_rnb`, `render_rnb_warmup`, `extract_geometry` signatures and
+the same dict of tensors (models/renderer.py:638-648, :920-930, :1023-1033).  The returned tensors are
+attached to autograd through one torch.autograd.Function whose backward runs the native explicit
+backward (rnb_render_bwd + rnb_weightnorm_bwd) and returns `.grad`s for every trainable leaf, so the
+reference's `loss.backward(); optimizer.step()` (exp_runner.py:259-263) works unchanged.
+
+Differences that are deliberate and documented in DESIGN.md:
+  * n_outside must be 0 (every shipped config); the NeRF background path is not implemented.
+  * the [B,1] perturbation draw (renderer.py:572) is made here with torch.rand on the rays' device and
+    may be supplied explicitly (`t_rand=`) so that tests can feed the oracle the same randomness.
+  * with data parallelism enabled (`set_data_parallel`) the backward all-reduces the flat gradient
+    buffer over RCCL before returning (mean over ranks).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import native, runtime
+from .fields import _mlp_struct, model_desc
+from .parallel import allreduce_mean_
+
+_OUT_KEYS = ("color_fine", "s_val", "cdf_fine", "weight_sum", "weight_max", "gradients", "weights",
+             "gradient_error", "inside_sphere")
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class _FinePass(torch.autograd.Function):
+    """forward: rnb_weightnorm_fwd (done by the caller) + rnb_render_fwd; backward: rnb_render_bwd +
+    rnb_weightnorm_bwd (+ optional RCCL all-reduce of the flat gradient buffer)."""
+
+    @staticmethod
+    def forward(ctx, renderer, call, *leaves):
+        lib = native.load()
+        desc = renderer.desc
+        dev = call["rays_o"].device
+        B, S = call["z_vals"].shape
+        flags = call["flags"]
+        mvps = bool(flags & native.MODE_MVPS)
+        L = call["lights"].shape[0] if mvps else 1
+        Cd = desc.col_d_out
+        f32 = dict(dtype=torch.float32, device=dev)
+        out = {
+            "color_fine": torch.empty((L, B, Cd) if mvps else (B, 3), **f32),
+            "weights": torch.empty(B, S, **f32),
+            "cdf_fine": torch.empty(B, S, **f32),
+            "gradients": torch.empty(B, S, 3, **f32),
+            "inside_sphere": torch.empty(B, S, **f32),
+            "weight_sum": torch.empty(B, 1, **f32),
+            "weight_max": torch.empty(B, 1, **f32),
+            "s_val": torch.empty(B, 1, **f32),
+            "gradient_error": torch.empty((), **f32),
+        }
+        extras = {}
+        if call.get("want_extras"):
+            extras["sdf"] = torch.empty(B * S, 1, **f32)
+            if not (mvps and (flags & native.FLAG_NO_ALBEDO)):
+                extras["sampled_albedo"] = torch.empty(B, S, Cd, **f32)
+        nbytes = C.c_int64()
+        native.check(lib.rnb_render_workspace_bytes(C.byref(desc), B, S, flags, C.byref(nbytes)))
+        ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+        args = native.RenderArgs()
+        args.B, args.S, args.n_lights, args.flags = B, S, L, flags
+        args.cos_anneal_ratio = float(call["cos_anneal_ratio"])
+        keep = dict(rays_o=call["rays_o"], rays_d=call["rays_d"], z_vals=call["z_vals"], lights=call["lights"],
+                    bg=call["background_rgb"], variance=renderer.deviation_network.variance.detach().reshape(1))
+        args.rays_o, args.rays_d = keep["rays_o"].data_ptr(), keep["rays_d"].data_ptr()
+        args.z_vals = keep["z_vals"].data_ptr()
+        args.lights_dir = keep["lights"].data_ptr() if keep["lights"] is not None else None
+        args.background_rgb = keep["bg"].data_ptr() if keep["bg"] is not None else None
+        args.variance = keep["variance"].data_ptr()
+        for k in ("color_fine", "weights", "cdf_fine", "gradients", "inside_sphere", "weight_sum", "weight_max",
+                  "s_val", "gradient_error"):
+            setattr(args, k, out[k].data_ptr())
+        args.sdf = extras["sdf"].data_ptr() if "sdf" in extras else None
+        args.sampled_albedo = extras["sampled_albedo"].data_ptr() if "sampled_albedo" in extras else None
+        native.check(lib.rnb_render_fwd(C.byref(desc), native.ptr(call["packed"]), C.byref(args), native.ptr(ws),
+                                        ws.numel(), _stream()))
+        ctx.renderer, ctx.call, ctx.args, ctx.keep, ctx.ws, ctx.out = renderer, call, args, keep, ws, out
+        ctx.n_leaves = len(leaves)
+        ctx.mark_non_differentiable(out["inside_sphere"])
+        renderer.last_extras = extras
+        return tuple(out[k] for k in _OUT_KEYS)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        lib = native.load()
+        renderer, call, desc = ctx.renderer, ctx.call, ctx.renderer.desc
+        dev = ctx.ws.device
+        g = dict(zip(_OUT_KEYS, gouts))
+        keepalive = []
+
+        def gp(name):
+            t = g.get(name)
+            if t is None:
+                return None
+            t = t.to(torch.float32).contiguous()
+            keepalive.append(t)
+            return t.data_ptr()
+
+        rg = native.RenderGrads()
+        for k in ("color_fine", "weights", "cdf_fine", "gradients", "weight_sum", "weight_max", "s_val",
+                  "gradient_error"):
+            setattr(rg, k, gp(k))
+        packed_grad = torch.empty_like(call["packed"])
+        flat, views, order = renderer._alloc_flat_grads(call["train_color"], dev)
+        dvar = views[id(renderer.deviation_network.variance)]
+        native.check(lib.rnb_render_bwd(C.byref(desc), native.ptr(call["packed"]), C.byref(ctx.args), C.byref(rg),
+                                        native.ptr(packed_grad), C.c_void_p(dvar.data_ptr()), native.ptr(ctx.ws),
+                                        ctx.ws.numel(), _stream()))
+        sdf_net, col_net = renderer.sdf_network, renderer.color_network
+        sp = _mlp_struct(sdf_net.lins(), sdf_net.weight_norm)
+        sg = _mlp_struct(sdf_net.lins(), sdf_net.weight_norm, grads=views)
+        use_col = call["train_color"]
+        cp = _mlp_struct(col_net.lins(), col_net.weight_norm) if use_col else None
+        cg = _mlp_struct(col_net.lins(), col_net.weight_norm, grads=views) if use_col else None
+        native.check(lib.rnb_weightnorm_bwd(C.byref(desc), C.byref(sp), C.byref(cp) if cp is not None else None,
+                                            native.ptr(packed_grad), C.byref(sg),
+                                            C.byref(cg) if cg is not None else None, _stream()))
+        if renderer.dp_group is not None:
+            # the one exchange step of the path: sum of the flat gradient buffer over xGMI (RCCL)
+            allreduce_mean_(flat, renderer.dp_group)
+        ctx.ws = None
+        grads = []
+        for leaf in call["leaves"]:
+            v = views.get(id(leaf))
+            grads.append(v.view_as(leaf) if v is not None else None)
+        return (None, None) + tuple(grads)
+
+
+class NeuSRenderer:
+    def __init__(self, nerf, sdf_network, deviation_network, color_network, n_samples, n_importance, n_outside,
+                 up_sample_steps, perturb):
+        if n_outside != 0:
+            raise NotImplementedError("n_outside > 0 (NeRF background) is outside the accelerated path; every "
+                                      "shipped config uses n_outside = 0")
+        self.nerf = nerf
+        self.sdf_network = sdf_network
+        self.deviation_network = deviation_network
+        self.color_network = color_network
+        self.n_samples = n_samples
+        self.n_importance = n_importance
+        self.n_outside = n_outside
+        self.up_sample_steps = up_sample_steps
+        self.perturb = perturb
+        # the reference reads self.color_depth without ever setting it (renderer.py:226; patched from
+        # outside at exp_runner.py:125) — default it from the albedo network
+        self.color_depth = color_network.d_out
+        self.desc = model_desc(sdf_network, color_network, n_samples, n_importance, up_sample_steps)
+        self.dp_group = None
+        self.last_z_vals = None
+        self.last_extras = {}
+        self.want_extras = False
+
+    # ------------------------------------------------------------------ data parallel
+    def set_data_parallel(self, group=None, enabled=True):
+        """One process per GPU; the backward all-reduces (mean) the flat gradient buffer over `group`."""
+        self.dp_group = (group if group is not None else dist.group.WORLD) if enabled else None
+
+    # ------------------------------------------------------------------ helpers
+    def _leaves(self, train_color):
+        leaves = list(self.sdf_network.leaves()) + [self.deviation_network.variance]
+        if train_color:
+            leaves += list(self.color_network.leaves())
+        return leaves
+
+    def _alloc_flat_grads(self, train_color, dev):
+        leaves = self._leaves(train_color)
+        total = sum(p.numel() for p in leaves)
+        flat = torch.empty(total, dtype=torch.float32, device=dev)
+        views, off = {}, 0
+        for p in leaves:
+            views[id(p)] = flat[off:off + p.numel()]
+            off += p.numel()
+        return flat, views, leaves
+
+    def _pack(self, use_color):
+        dev = self.sdf_network.lin0.bias.device
+        return runtime.pack_weights(self.desc, self.sdf_network, self.color_network if use_color else None, dev)
+
+    def sample_z_vals(self, rays_o, rays_d, near, far, packed, perturb, t_rand=None):
+        """The no-grad prologue shared by the three wrappers (models/renderer.py:557-608)."""
+        lib = native.load()
+        B = rays_o.shape[0]
+        dev = rays_o.device
+        if perturb > 0:
+            if t_rand is None:
+                t_rand = torch.rand([B, 1], device=dev)
+            t_rand = t_rand.to(torch.float32).reshape(B).contiguous()
+        else:
+            t_rand = None
+        S = self.n_samples + self.n_importance
+        z = torch.empty(B, S, dtype=torch.float32, device=dev)
+        nbytes = C.c_int64()
+        native.check(lib.rnb_sample_workspace_bytes(C.byref(self.desc), B, C.byref(nbytes)))
+        ws = torch.empty(max(nbytes.value, 256), dtype=torch.uint8, device=dev)
+        near = near.to(torch.float32).reshape(B).contiguous()
+        far = far.to(torch.float32).reshape(B).contiguous()
+        native.check(lib.rnb_sample_rays(C.byref(self.desc), native.ptr(packed), native.ptr(rays_o), native.ptr(rays_d),
+                                         native.ptr(near), native.ptr(far), native.ptr(t_rand), B, native.ptr(z),
+                                         native.ptr(ws), ws.numel(), _stream()))
+        return z
+
+    def _run(self, rays_o, rays_d, near, far, lights_dir, perturb_overwrite, background_rgb, cos_anneal_ratio,
+             flags, t_rand, z_vals):
+        if not rays_o.is_cuda:
+            raise RuntimeError("NeuSRenderer: rays must be on the GPU (no CPU path; librnbneus_hip.so only)")
+        dev = rays_o.device
+        B = rays_o.shape[0]
+        rays_o = rays_o.detach().to(torch.float32).contiguous()
+        rays_d = rays_d.detach().to(torch.float32).contiguous()
+        mvps = bool(flags & native.MODE_MVPS)
+        no_albedo = bool(flags & native.FLAG_NO_ALBEDO)
+        use_color = not (mvps and no_albedo)
+        packed = self._pack(use_color)
+        perturb = self.perturb if perturb_overwrite < 0 else perturb_overwrite
+        if z_vals is None:
+            with torch.no_grad():
+                z_vals = self.sample_z_vals(rays_o, rays_d, near, far, packed, perturb, t_rand)
+        else:
+            z_vals = z_vals.detach().to(torch.float32).contiguous()
+        self.last_z_vals = z_vals
+        lights = None
+        if mvps:
+            L = lights_dir.shape[0]
+            lt = lights_dir.detach().to(torch.float32)
+            if lt.numel() == L * 3:
+                lights = lt.reshape(L, 3).contiguous()
+            else:
+                lights = lt.reshape(L, B, 3).contiguous()
+                flags |= native.FLAG_LIGHT_PER_RAY
+        bg = None
+        if background_rgb is not None and not mvps:
+            bg = background_rgb.detach().to(torch.float32).reshape(3).contiguous()
+        # leaves that receive gradients: as in exp_runner.py:105-112 the albedo net is trained unless no_albedo
+        train_color = use_color
+        leaves = self._leaves(train_color)
+        grad_on = torch.is_grad_enabled() and any(p.requires_grad for p in leaves)
+        if not grad_on:
+            flags |= native.FLAG_FORWARD_ONLY
+        call = dict(rays_o=rays_o, rays_d=rays_d, z_vals=z_vals, lights=lights, background_rgb=bg,
+                    cos_anneal_ratio=cos_anneal_ratio, flags=flags, packed=packed, leaves=leaves,
+                    train_color=train_color, want_extras=self.want_extras)
+        outs = _FinePass.apply(self, call, *leaves)
+        return dict(zip(_OUT_KEYS, outs))
+
+    # ------------------------------------------------------------------ reference API
+    def render(self, rays_o, rays_d, near, far, perturb_overwrite=-1, background_rgb=None, cos_anneal_ratio=0.0,
+               t_rand=None, z_vals=None):
+        """models/renderer.py:556-648."""
+        return self._run(rays_o, rays_d, near, far, None, perturb_overwrite, background_rgb, cos_anneal_ratio,
+                         native.MODE_CORE, t_rand, z_vals)
+
+    def render_rnb_warmup(self, rays_o, rays_d, near, far, lights_dir, perturb_overwrite=-1, background_rgb=None,
+                          cos_anneal_ratio=0.0, no_albedo=False, t_rand=None, z_vals=None):
+        """models/renderer.py:828-930 (ReLU on the shading)."""
+        flags = native.MODE_MVPS | native.FLAG_RELU_SHADING | (native.FLAG_NO_ALBEDO if no_albedo else 0)
+        return self._run(rays_o, rays_d, near, far, lights_dir, perturb_overwrite, background_rgb, cos_anneal_ratio,
+                         flags, t_rand, z_vals)
+
+    def render_rnb(self, rays_o, rays_d, near, far, lights_dir, perturb_overwrite=-1, background_rgb=None,
+                   cos_anneal_ratio=0.0, no_albedo=False, t_rand=None, z_vals=None):
+        """models/renderer.py:932-1033."""
+        flags = native.MODE_MVPS | (native.FLAG_NO_ALBEDO if no_albedo else 0)
+        return self._run(rays_o, rays_d, near, far, lights_dir, perturb_overwrite, background_rgb, cos_anneal_ratio,
+                         flags, t_rand, z_vals)
+
+    def color(self, points, normals, view_dirs, feature_vectors):
+        """RenderingNetwork.forward through this renderer's packed weights (view_dirs unused in
+        no_view_dir mode, models/fields.py:190-192)."""
+        packed = self._pack(True)
+        return runtime.color_forward(self.desc, packed, points, normals, feature_vectors)
+
+    def extract_fields(self, bound_min, bound_max, resolution, chunk=64):
+        """SDF grid query of models/renderer.py:10-25 (values negated as at :1224)."""
+        dev = self.sdf_network.lin0.bias.device
+        packed = self._pack(False)
+        X = torch.linspace(float(bound_min[0]), float(bound_max[0]), resolution, device=dev).split(chunk)
+        Y = torch.linspace(float(bound_min[1]), float(bound_max[1]), resolution, device=dev).split(chunk)
+        Z = torch.linspace(float(bound_min[2]), float(bound_max[2]), resolution, device=dev).split(chunk)
+        u = np.zeros([resolution, resolution, resolution], dtype=np.float32)
+        with torch.no_grad():
+            for xi, xs in enumerate(X):
+                for yi, ys in enumerate(Y):
+                    for zi, zs in enumerate(Z):
+                        xx, yy, zz = torch.meshgrid(xs, ys, zs, indexing="ij")
+                        pts = torch.stack([xx.reshape(-1), yy.reshape(-1), zz.reshape(-1)], dim=-1)
+                        val = -runtime.sdf_forward(self.desc, packed, pts, False)
+                        u[xi * chunk: xi * chunk + len(xs), yi * chunk: yi * chunk + len(ys),
+                          zi * chunk: zi * chunk + len(zs)] = val.reshape(len(xs), len(ys), len(zs)).cpu().numpy()
+        return u
+
+    def extract_geometry(self, bound_min, bound_max, resolution, threshold=0.0):
+        """models/renderer.py:1219-1224 / :27-36.  Marching cubes itself is PyMCubes (third party, not
+        vendored by the reference); it is imported lazily exactly as the reference depends on it."""
+        u = self.extract_fields(bound_min, bound_max, resolution)
+        try:
+            import mcubes
+        except ImportError as e:  # pragma: no cover - PyMCubes is not installed in the build image
+            raise ImportError("extract_geometry needs PyMCubes (as the reference does); the SDF grid itself is "
+                              "available from NeuSRenderer.extract_fields") from e
+        vertices, triangles = mcubes.marching_cubes(u, threshold)
+        b_max = bound_max.detach().cpu().numpy()
+        b_min = bound_min.detach().cpu().numpy()
+        vertices = vertices / (resolution - 1.0) * (b_max - b_min)[None, :] + b_min[None, :]
+        return vertices, triangles

@@ -1,0 +1,299 @@
+"""GPU parity tests: the HIP path (through the C ABI, via the drop-in classes) against the pinned CPU
+oracle and the committed golden vectors.  Tolerances: integer sample indices bit-exact
+given identical inputs; fp32 outputs |d| <= 1e-5 + 1e-4*|ref|; parameter gradients rel-L2 <= 1e-3 per
+tensor here (fp32 MFMA vs. CPU GEMM summation order; typically ~1e-6)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import rnb_oracle as O
+from tests.golden_util import Golden, case_names
+
+pytestmark = pytest.mark.gpu
+
+CASES = case_names()
+TINY = [c for c in CASES if c.startswith("tiny")]
+
+
+@pytest.fixture(scope="module")
+def R():
+    assert torch.cuda.is_available(), "GPU tests need a device"
+    import rnb_neus_fork_amd as pkg
+    pkg.native.load()
+    return pkg
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def _build(R, g: Golden):
+    p = g.params()
+    sdf, dev, col, ren = R.build_from_named_params(g.mc, p, _dev())
+    return p, sdf, dev, col, ren
+
+
+def _fine_points(g: Golden):
+    z = g.steps[-1]["z_out"]
+    b = g.batch
+    sd = 2.0 / g.mc.render.n_samples
+    dists = torch.cat([z[:, 1:] - z[:, :-1], torch.full_like(z[:, :1], sd)], -1)
+    mid = z + dists * 0.5
+    return (b["rays_o"][:, None, :] + b["rays_d"][:, None, :] * mid[..., None]).reshape(-1, 3)
+
+
+# ---------------------------------------------------------------------------------------------------
+# point-wise network evaluation
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", CASES)
+def test_sdf_forward_matches_oracle(R, name):
+    g = Golden(name)
+    p, sdf, dev, col, ren = _build(R, g)
+    pts = _fine_points(g)
+    ref = O.sdf_forward(p, g.mc.sdf, pts)
+    out = sdf(pts.to(_dev())).cpu()
+    assert out.shape == ref.shape
+    torch.testing.assert_close(out, ref, rtol=1e-4, atol=2e-5)
+    out1 = sdf.sdf(pts.to(_dev())).cpu()
+    torch.testing.assert_close(out1, ref[:, :1], rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_sdf_gradient_matches_oracle(R, name):
+    g = Golden(name)
+    p, sdf, dev, col, ren = _build(R, g)
+    pts = _fine_points(g)
+    ref = O.sdf_gradient(p, g.mc.sdf, pts, create_graph=False)
+    out = sdf.gradient(pts.to(_dev())).cpu()
+    assert out.shape == (pts.shape[0], 1, 3)
+    torch.testing.assert_close(out[:, 0, :], ref, rtol=2e-4, atol=5e-5)
+
+
+@pytest.mark.parametrize("name", ["tiny_main_sharp", "full_main_sharp"])
+def test_color_forward_matches_oracle(R, name):
+    g = Golden(name)
+    p, sdf, dev, col, ren = _build(R, g)
+    pts = _fine_points(g)
+    gen = torch.Generator().manual_seed(3)
+    normals = torch.randn(pts.shape[0], 3, generator=gen)
+    feats = torch.randn(pts.shape[0], g.mc.color.d_feature, generator=gen) * 0.3
+    ref = O.color_forward(p, g.mc.color, pts, normals, normals, feats)
+    out = col(pts.to(_dev()), normals.to(_dev()), normals.to(_dev()), feats.to(_dev())).cpu()
+    torch.testing.assert_close(out, ref, rtol=1e-4, atol=2e-5)
+    out2 = ren.color(pts.to(_dev()), normals.to(_dev()), None, feats.to(_dev())).cpu()
+    torch.testing.assert_close(out2, ref, rtol=1e-4, atol=2e-5)
+
+
+# ---------------------------------------------------------------------------------------------------
+# hierarchical sampling: integer outputs bit-exact given the reference's own per-step inputs
+# ---------------------------------------------------------------------------------------------------
+def _up_sample_step(R, g, st):
+    lib = R.native.load()
+    d = _dev()
+    z_in = st["z_in"].to(d).contiguous()
+    sdf_in = st["sdf_in"].to(d).contiguous()
+    B, n = z_in.shape
+    n_new = st["new_z"].shape[1]
+    ro = g.batch["rays_o"].to(d).contiguous()
+    rd = g.batch["rays_d"].to(d).contiguous()
+    new_z = torch.empty(B, n_new, device=d)
+    inds = torch.empty(B, n_new, dtype=torch.int32, device=d)
+    z_out = torch.empty(B, n + n_new, device=d)
+    sidx = torch.empty(B, n + n_new, dtype=torch.int32, device=d)
+    R.native.check(lib.rnb_up_sample_step(R.native.ptr(ro), R.native.ptr(rd), R.native.ptr(z_in),
+                                          R.native.ptr(sdf_in), B, n, n_new, float(st["inv_s"]),
+                                          R.native.ptr(new_z), R.native.ptr(inds), R.native.ptr(z_out),
+                                          R.native.ptr(sidx), None))
+    torch.cuda.synchronize()
+    return new_z.cpu(), inds.cpu(), z_out.cpu(), sidx.cpu()
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_up_sample_step_indices_bit_exact(R, name):
+    g = Golden(name)
+    worst = 0.0
+    for i, st in enumerate(g.steps):
+        new_z, inds, z_out, sidx = _up_sample_step(R, g, st)
+        assert torch.equal(inds.long(), st["inds"]), f"step {i}: searchsorted indices differ"
+        assert torch.equal(sidx.long(), st["sort_index"]), f"step {i}: sort index differs"
+        # depths: same arithmetic except torch.sum's vectorised summation order and the device expf
+        dz = (new_z - st["new_z"]).abs().max().item()
+        worst = max(worst, dz)
+        torch.testing.assert_close(new_z, st["new_z"], rtol=0, atol=2e-5)
+        torch.testing.assert_close(z_out, st["z_out"], rtol=0, atol=2e-5)
+        assert bool((z_out[:, 1:] >= z_out[:, :-1]).all()), "merged depths must be sorted"
+    print(f"{name}: max |new_z - ref| over steps = {worst:.3e}")
+
+
+def test_gather_sdf(R):
+    lib = R.native.load()
+    d = _dev()
+    B, n, n_new = 5, 16, 4
+    gen = torch.Generator().manual_seed(1)
+    old = torch.randn(B, n, generator=gen)
+    new = torch.randn(B, n_new, generator=gen)
+    idx = torch.stack([torch.randperm(n + n_new, generator=gen) for _ in range(B)]).int()
+    out = torch.empty(B, n + n_new, device=d)
+    o_d, n_d, i_d = old.to(d), new.to(d), idx.to(d)
+    R.native.check(lib.rnb_gather_sdf(R.native.ptr(o_d), R.native.ptr(n_d), R.native.ptr(i_d), B, n, n_new,
+                                      R.native.ptr(out), None))
+    ref = torch.gather(torch.cat([old, new], -1), 1, idx.long())
+    assert torch.equal(out.cpu(), ref)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_sample_rays_end_to_end(R, name):
+    """Whole prologue on the device.  1-ulp differences of the coarse SDF are amplified by the sharp
+    sigmoids of the up-sampling loop (the CPU oracle shows the same when its weight-norm rounding is
+    changed), so z_vals are compared statistically, not bit-wise."""
+    g = Golden(name)
+    p, sdf, dev, col, ren = _build(R, g)
+    b = {k: v.to(_dev()) for k, v in g.batch.items()}
+    perturb = g.mc.render.perturb if g.perturb_overwrite < 0 else g.perturb_overwrite
+    packed = ren._pack(False)
+    z = ren.sample_z_vals(b["rays_o"], b["rays_d"], b["near"], b["far"], packed, perturb, b["t_rand"]).cpu()
+    ref = g.steps[-1]["z_out"]
+    assert z.shape == ref.shape
+    assert bool((z[:, 1:] >= z[:, :-1]).all())
+    diff = (z - ref).abs()
+    frac_close = (diff < 1e-4).float().mean().item()
+    print(f"{name}: z_vals within 1e-4 of the reference: {100 * frac_close:.1f}%  (max diff {diff.max():.3e})")
+    assert diff.mean().item() < 2e-3
+    assert frac_close > 0.80
+    # coarse depths (before any up-sampling) must agree to rounding
+    z0_ref = g.steps[0]["z_in"]
+    lib = R.native.load()
+    ren0 = R.NeuSRenderer(None, sdf, dev, col, n_samples=g.mc.render.n_samples, n_importance=0, n_outside=0,
+                          up_sample_steps=1, perturb=g.mc.render.perturb)
+    z0 = ren0.sample_z_vals(b["rays_o"], b["rays_d"], b["near"], b["far"], packed, perturb, b["t_rand"]).cpu()
+    assert torch.equal(z0, z0_ref), "initial depths must be bit-exact"
+
+
+# ---------------------------------------------------------------------------------------------------
+# fine pass forward + backward on the reference's own z_vals
+# ---------------------------------------------------------------------------------------------------
+def _render(ren, g, b, z_vals):
+    kw = dict(perturb_overwrite=g.perturb_overwrite, cos_anneal_ratio=g.cos_anneal_ratio, z_vals=z_vals)
+    if g.api == "render":
+        bg = b.get("background_rgb")
+        return ren.render(b["rays_o"], b["rays_d"], b["near"], b["far"], background_rgb=bg, **kw)
+    fn = ren.render_rnb_warmup if g.api == "render_rnb_warmup" else ren.render_rnb
+    return fn(b["rays_o"], b["rays_d"], b["near"], b["far"], b["lights_dir"], no_albedo=g.no_albedo, **kw)
+
+
+def _loss(g, out, b):
+    if g.api == "render":
+        return (out["color_fine"] - b["true_rgb"][0]).abs().mean() + 0.1 * out["gradient_error"] \
+            + 0.1 * torch.nn.functional.binary_cross_entropy(
+                out["weight_sum"].clip(1e-3, 1 - 1e-3), (b["mask"] > 0.5).float())
+    return O.rnb_loss(out, b["true_rgb"], b["mask"])[0]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_fine_pass_golden(R, name):
+    g = Golden(name)
+    p, sdf, dev, col, ren = _build(R, g)
+    b = {k: v.to(_dev()) for k, v in g.batch.items()}
+    z_vals = g.steps[-1]["z_out"].to(_dev())
+    out = _render(ren, g, b, z_vals)
+    for k, ref in g.out.items():
+        if k == "loss":
+            continue
+        got = out[k].detach().cpu()
+        assert got.shape == ref.shape, k
+        torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-5, msg=lambda m: f"{k}: {m}")
+    loss = _loss(g, out, b)
+    torch.testing.assert_close(loss.detach().cpu(), g.out["loss"], rtol=1e-4, atol=1e-5)
+    loss.backward()
+    torch.cuda.synchronize()
+    named = {("sdf." + k): v for k, v in sdf.named_parameters()}
+    named["dev.variance"] = dev.variance
+    named.update({("color." + k): v for k, v in col.named_parameters()})
+    with_grad = {k for k, v in named.items() if v.grad is not None}
+    assert with_grad == set(g.grads.keys())
+    worst = ("", 0.0)
+    for k, ref in g.grads.items():
+        mine = named[k].grad.detach().cpu().reshape(-1)[:: g.grad_stride]
+        denom = max(g.gradnorm[k] / np.sqrt(g.grad_stride), 1e-12)
+        rel = float((mine - ref).double().norm()) / denom
+        if rel > worst[1]:
+            worst = (k, rel)
+        if g.gradnorm[k] < 1e-10:
+            assert float(mine.abs().max()) < 1e-8, k
+        else:
+            assert rel < 1e-3, f"{k}: rel-L2 {rel:.3e}"
+    print(f"{name}: worst gradient rel-L2 = {worst[1]:.2e} ({worst[0]})")
+
+
+def test_full_batch_512_matches_oracle(R):
+    """BASELINE config 2 shape (512 rays x (64+64), full-size nets): HIP vs the CPU oracle on the z_vals
+    the device sampled, outputs + a subset of parameter gradients."""
+    mc = O.ModelConf()
+    torch.manual_seed(0)
+    p = O.init_params(mc)
+    with torch.no_grad():   # leave the structured zero blocks of the geometric init
+        for k, v in p.items():
+            if k.endswith("weight_v") or k.endswith("bias"):
+                v.add_(0.02 * torch.randn(v.shape, generator=torch.Generator().manual_seed(hash(k) % 1000)))
+        p["dev.variance"].fill_(0.45)
+    sdf, dev, col, ren = R.build_from_named_params(mc, p, _dev())
+    batch = O.synthetic_batch(512, seed=21, step=3, warmup=False)
+    b = {k: v.to(_dev()) for k, v in batch.items()}
+    out = ren.render_rnb(b["rays_o"], b["rays_d"], b["near"], b["far"], b["lights_dir"], cos_anneal_ratio=1.0,
+                         t_rand=b["t_rand"])
+    loss = O.rnb_loss(out, b["true_rgb"], b["mask"])[0]
+    loss.backward()
+    torch.cuda.synchronize()
+    z = ren.last_z_vals.cpu()
+    pr = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    ref = O.render_rnb(pr, mc, batch["rays_o"], batch["rays_d"], batch["near"], batch["far"], batch["lights_dir"],
+                       cos_anneal_ratio=1.0, z_vals=z)
+    ref_loss = O.rnb_loss(ref, batch["true_rgb"], batch["mask"])[0]
+    ref_loss.backward()
+    for k in ("color_fine", "weights", "weight_sum", "gradients", "cdf_fine", "gradient_error"):
+        torch.testing.assert_close(out[k].detach().cpu(), ref[k].detach(), rtol=2e-4, atol=2e-5,
+                                   msg=lambda m: f"{k}: {m}")
+    torch.testing.assert_close(loss.detach().cpu(), ref_loss.detach(), rtol=1e-4, atol=1e-5)
+    named = {("sdf." + k): v for k, v in sdf.named_parameters()}
+    named["dev.variance"] = dev.variance
+    named.update({("color." + k): v for k, v in col.named_parameters()})
+    for k, v in named.items():
+        rg = pr[k].grad
+        rel = float((v.grad.cpu() - rg).norm() / rg.norm().clamp_min(1e-20))
+        assert rel < 1e-3, f"{k}: rel-L2 {rel:.3e}"
+
+
+def test_size_independent_properties(R):
+    """Properties that hold at any size: weights in [0,1] with sum <= 1; colour is linear in the light
+    directions (render_rnb has no ReLU); no_albedo with unit lights reproduces sum_s w * (n.l)."""
+    mc = O.ModelConf()
+    torch.manual_seed(1)
+    p = O.init_params(mc)
+    sdf, dev, col, ren = R.build_from_named_params(mc, p, _dev())
+    batch = O.synthetic_batch(256, seed=5, step=1, warmup=False)
+    b = {k: v.to(_dev()) for k, v in batch.items()}
+    with torch.no_grad():
+        o1 = ren.render_rnb(b["rays_o"], b["rays_d"], b["near"], b["far"], b["lights_dir"], cos_anneal_ratio=1.0,
+                            t_rand=b["t_rand"])
+        z = ren.last_z_vals
+        o2 = ren.render_rnb(b["rays_o"], b["rays_d"], b["near"], b["far"], 2.0 * b["lights_dir"],
+                            cos_anneal_ratio=1.0, z_vals=z)
+        o3 = ren.render_rnb(b["rays_o"], b["rays_d"], b["near"], b["far"], b["lights_dir"], cos_anneal_ratio=1.0,
+                            z_vals=z, no_albedo=True)
+    w = o1["weights"]
+    assert bool((w >= 0).all()) and bool((w <= 1).all())
+    assert bool((o1["weight_sum"] <= 1.0 + 1e-5).all())
+    torch.testing.assert_close(o2["color_fine"], 2.0 * o1["color_fine"], rtol=1e-5, atol=1e-6)
+    sh = (o3["gradients"][None] * b["lights_dir"]).sum(-1)
+    expect = (o3["weights"][None] * sh).sum(-1, keepdim=True).expand(-1, -1, 3)
+    torch.testing.assert_close(o3["color_fine"], expect, rtol=1e-4, atol=1e-5)
+    assert torch.equal(o1["weights"], o3["weights"])
+
+
+def test_missing_library_fails_loudly(R, monkeypatch, tmp_path):
+    monkeypatch.setattr(R.native, "_lib", None)
+    monkeypatch.setattr(R.native, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(R.native.NativeError):
+        R.native.load()

@@ -1,0 +1,130 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol of include/rnbneus.h, argument
+validation / error reporting of entry points that do not touch the GPU, and the host-side drop-in
+classes (parameter names, order, initial values, state_dict round trip).  No compute calls."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+
+import rnb_neus_fork_amd as R
+from oracle import rnb_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    text = open(os.path.join(ROOT, "include", "rnbneus.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rnb_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = R.native.load()
+    declared = _header_symbols()
+    assert len(declared) >= 17
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/rnbneus.h but not exported"
+    assert set(declared) == set(R.native.EXPORTED_SYMBOLS)
+    assert lib.rnb_abi_version() == 1
+
+
+def _desc(**over):
+    mc = O.ModelConf()
+    sdf = R.SDFNetwork(d_in=3, d_out=257, d_hidden=256, n_layers=8, skip_in=[4], multires=6)
+    col = R.RenderingNetwork(d_feature=256, mode="no_view_dir", d_in=6, d_out=3, d_hidden=256, n_layers=2,
+                             multires_view=4)
+    d = R.model_desc(sdf, col)
+    for k, v in over.items():
+        setattr(d, k, v)
+    return d
+
+
+def test_packed_layout_size_and_workspace_queries():
+    lib = R.native.load()
+    d = _desc()
+    n = C.c_int64()
+    R.native.check(lib.rnb_packed_floats(C.byref(d), C.byref(n)))
+    # 8 hidden layers + feature head + sdf row + albedo net, all padded to multiples of 32
+    expect = (256 * 64 + 256) + 7 * (256 * 256 + 256) + (256 * 256 + 256) + 256 + 32 \
+        + (256 * 320 + 256) + (256 * 256 + 256) + (32 * 256 + 32)
+    assert n.value == expect
+    b = C.c_int64()
+    R.native.check(lib.rnb_render_workspace_bytes(C.byref(d), 512, 128, R.native.MODE_MVPS, C.byref(b)))
+    fwd_bwd = b.value
+    R.native.check(lib.rnb_render_workspace_bytes(C.byref(d), 512, 128,
+                                                  R.native.MODE_MVPS | R.native.FLAG_FORWARD_ONLY, C.byref(b)))
+    assert 0 < b.value < fwd_bwd < 8 << 30
+    tf, ff = C.c_double(), C.c_double()
+    R.native.check(lib.rnb_algorithmic_flops(C.byref(d), 512, R.native.MODE_MVPS, C.byref(tf), C.byref(ff)))
+    assert abs(tf.value / 512 - 1.035e9) < 0.01e9      # ~1.035 GFLOP per training ray
+    assert abs(ff.value / 512 - 0.423e9) < 0.01e9
+
+
+def test_invalid_arguments_are_reported_not_fatal():
+    lib = R.native.load()
+    n = C.c_int64()
+    d = _desc(sdf_d_in=2)
+    rc = lib.rnb_packed_floats(C.byref(d), C.byref(n))
+    assert rc == -1 and b"sdf_d_in" in lib.rnb_last_error_string()
+    d = _desc(sdf_skip_in=0)
+    assert lib.rnb_packed_floats(C.byref(d), C.byref(n)) == -1
+    d = _desc()
+    assert lib.rnb_packed_floats(C.byref(d), None) == -4
+    with pytest.raises(R.native.NativeError):
+        R.native.check(lib.rnb_packed_floats(None, C.byref(n)))
+    b = C.c_int64()
+    d = _desc(n_importance=63)
+    assert lib.rnb_sample_workspace_bytes(C.byref(d), 512, C.byref(b)) == -1
+
+
+def test_drop_in_modules_match_reference_names_order_and_init():
+    mc = O.ModelConf()
+    torch.manual_seed(0)
+    p = O.init_params(mc)
+    torch.manual_seed(0)
+    sdf = R.SDFNetwork(d_in=3, d_out=257, d_hidden=256, n_layers=8, skip_in=[4], multires=6, bias=0.5, scale=1.0,
+                       geometric_init=True, weight_norm=True)
+    dev = R.SingleVarianceNetwork(0.3)
+    col = R.RenderingNetwork(d_feature=256, mode="no_view_dir", d_in=6, d_out=3, d_hidden=256, n_layers=2,
+                             weight_norm=True, multires_view=4, squeeze_out=True)
+    names = ["sdf." + k for k, _ in sdf.named_parameters()] + ["dev." + k for k, _ in dev.named_parameters()] \
+        + ["color." + k for k, _ in col.named_parameters()]
+    assert names == O.param_order(mc)
+    assert sum(v.numel() for v in sdf.parameters()) == 529076
+    assert sum(v.numel() for v in col.parameters()) == 146694
+    for k, v in list(sdf.state_dict().items()):
+        assert torch.equal(v, p["sdf." + k]), k
+    for k, v in list(col.state_dict().items()):
+        assert torch.equal(v, p["color." + k]), k
+    sd = sdf.state_dict()
+    sdf2 = R.SDFNetwork(d_in=3, d_out=257, d_hidden=256, n_layers=8, skip_in=[4], multires=6)
+    sdf2.load_state_dict(sd)
+    assert all(torch.equal(a, b) for a, b in zip(sdf.parameters(), sdf2.parameters()))
+    ren = R.NeuSRenderer(None, sdf, dev, col, n_samples=64, n_importance=64, n_outside=0, up_sample_steps=4,
+                         perturb=1.0)
+    assert ren.color_depth == 3 and ren.n_samples == 64 and ren.n_importance == 64
+    assert [id(x) for x in ren._leaves(True)] == [id(x) for x in list(sdf.parameters()) + list(dev.parameters())
+                                                  + list(col.parameters())]
+
+
+def test_unsupported_configurations_raise():
+    with pytest.raises(NotImplementedError):
+        R.RenderingNetwork(d_feature=256, mode="idr", d_in=9, d_out=3, d_hidden=256, n_layers=2)
+    sdf = R.SDFNetwork(d_in=3, d_out=65, d_hidden=64, n_layers=8, skip_in=[4], multires=6)
+    col = R.RenderingNetwork(d_feature=64, mode="no_view_dir", d_in=6, d_out=3, d_hidden=64, n_layers=2,
+                             multires_view=4)
+    with pytest.raises(NotImplementedError):
+        R.NeuSRenderer(None, sdf, R.SingleVarianceNetwork(0.3), col, 64, 64, 32, 4, 1.0)
+    ren = R.NeuSRenderer(None, sdf, R.SingleVarianceNetwork(0.3), col, 16, 16, 0, 4, 1.0)
+    o = torch.zeros(4, 3)
+    with pytest.raises(RuntimeError, match="GPU"):
+        ren.render(o, o, o[:, :1], o[:, :1])      # CPU tensors: there is no CPU path
+
+
+def test_embedder_matches_oracle():
+    fn, dim = R.get_embedder(6, 3)
+    x = torch.randn(10, 3)
+    assert dim == 39
+    assert torch.equal(fn(x), O.embed(x, 6))
