@@ -213,6 +213,14 @@ int rnb_render_bwd(const rnb_model_desc* desc, const float* packed, const rnb_re
 int rnb_algorithmic_flops(const rnb_model_desc* desc, int64_t B, int32_t flags, double* train_flops,
                           double* forward_flops);
 
+/* Measurement aid for bench.py (not part of the reference's interface): while enabled, every launch of
+ * the fp32-MFMA layer-GEMM kernels (gemm_rows_kernel<...>, gemm_dw_kernel) is bracketed by HIP events on
+ * its launch stream.  After the caller has synchronised, rnb_profile_collect returns the summed device
+ * time (ms), the number of launches and their summed algorithmic FLOPs (real layer shapes) since the
+ * last enable/collect.  This is the only mutable global state of the library; it is off by default. */
+int rnb_profile_enable(int on);
+int rnb_profile_collect(double* gemm_ms, int64_t* gemm_launches, double* gemm_flops);
+
 #ifdef __cplusplus
 }
 #endif

@@ -399,6 +399,11 @@ RNB_API int rnb_render_bwd(const rnb_model_desc* desc, const float* packed, cons
   return RNB_OK;
 }
 
+RNB_API int rnb_profile_enable(int on) { return profile_enable(on); }
+RNB_API int rnb_profile_collect(double* gemm_ms, int64_t* gemm_launches, double* gemm_flops) {
+  return profile_collect(gemm_ms, gemm_launches, gemm_flops);
+}
+
 // Algorithmic MLP FLOPs: multiply-accumulate counts of the real (unpadded) layer shapes.
 RNB_API int rnb_algorithmic_flops(const rnb_model_desc* desc, int64_t B, int32_t flags, double* train_flops,
                                   double* forward_flops) {

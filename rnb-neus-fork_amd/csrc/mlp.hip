@@ -401,17 +401,21 @@ struct EpiStore {
 // =====================================================================================================
 // launch helpers
 // =====================================================================================================
+// algorithmic FLOPs of one layer-shaped GEMM over M points: real (unpadded) layer shape
+static inline double mm_flops(int64_t M, const Lin& ln) { return 2.0 * (double)M * ln.N * ln.K; }
+
 template <bool B_KMAJOR, class Epi>
 static int launch_rows(const float* A, int lda, const float* W, int ldw, int64_t Mp, int N, int K, const Epi& epi,
-                       hipStream_t s) {
+                       double flops, hipStream_t s) {
   dim3 grid((unsigned)(Mp / BM), (unsigned)((N + BN - 1) / BN));
+  ProfScope prof(flops, s);
   hipLaunchKernelGGL((gemm_rows_kernel<B_KMAJOR, Epi>), grid, dim3(256), 0, s, A, lda, W, ldw, N, K, epi);
   RNB_CHECK_LAUNCH();
   return RNB_OK;
 }
 
 static int launch_dw(DwPair p1, DwPair p2, int npairs, int64_t M, int N, int K, float* dW, int lddw, float* db,
-                     int bias_pair, hipStream_t s) {
+                     int bias_pair, double flops, hipStream_t s) {
   const int tiles = ((N + BM - 1) / BM) * ((K + BN - 1) / BN);
   int splits = (int)((M + 511) / 512);              // >= 512 points per block
   const int max_splits = (1024 + tiles - 1) / tiles;  // ~1024 blocks in flight
@@ -421,6 +425,7 @@ static int launch_dw(DwPair p1, DwPair p2, int npairs, int64_t M, int N, int K, 
   rows = (rows + BK - 1) / BK * BK;
   splits = (int)((M + rows - 1) / rows);
   dim3 grid((unsigned)((N + BM - 1) / BM), (unsigned)((K + BN - 1) / BN), (unsigned)splits);
+  ProfScope prof(flops, s);
   hipLaunchKernelGGL(gemm_dw_kernel, grid, dim3(256), 0, s, p1, p2, npairs, (int)M, N, K, rows, dW, lddw, db,
                      bias_pair);
   RNB_CHECK_LAUNCH();
@@ -456,7 +461,7 @@ int sweep_forward(const Layout& L, const float* packed, PointBufs& pb, bool need
     const float* in = l == 0 ? pb.e : pb.a[l - 1];
     const int lda = l == 0 ? L.Ep : L.Hp;
     EpiF epi{packed + ln.b_off, pb.a[l], L.Hp, ln.N, (l + 1 == L.skip) ? pb.e : nullptr, L.Ep, L.pe};
-    RNB_TRY((launch_rows<false, EpiF>(in, lda, packed + ln.w_off, ln.Kp, pb.Mp, ln.Np, ln.Kp, epi, s)));
+    RNB_TRY((launch_rows<false, EpiF>(in, lda, packed + ln.w_off, ln.Kp, pb.Mp, ln.Np, ln.Kp, epi, mm_flops(pb.M, ln), s)));
   }
   hipLaunchKernelGGL(sdf_head_kernel, dim3(blocks_for(pb.Mp * 32, 256)), dim3(256), 0, s, pb.a[L.nh - 1], L.Hp, L.H,
                      packed + L.wsdf_off, packed + L.bsdf_off, 1.f / L.sdf_scale, pb.Mp, pb.sdf,
@@ -465,7 +470,7 @@ int sweep_forward(const Layout& L, const float* packed, PointBufs& pb, bool need
   if (need_feat) {
     EpiBias epi{packed + L.feat.b_off, pb.cin, L.Cinp, L.F};
     RNB_TRY((launch_rows<false, EpiBias>(pb.a[L.nh - 1], L.Hp, packed + L.feat.w_off, L.feat.Kp, pb.Mp, L.feat.Np,
-                                         L.feat.Kp, epi, s)));
+                                         L.feat.Kp, epi, mm_flops(pb.M, L.feat), s)));
     if (feat_dense) {
       RNB_TRY(launch_copy_cols(pb.cin, L.Cinp, L.F, pb.M, feat_dense, s));
     }
@@ -479,12 +484,12 @@ int sweep_reverse(const Layout& L, const float* packed, PointBufs& pb, hipStream
     const Lin& ln = L.hid[l];
     const bool is_skip = (l == L.skip);
     EpiR epi{pb.a[l - 1], pb.gz[l - 1], L.Hp, is_skip ? ln.K - L.pe : ln.K, is_skip ? pb.ge : nullptr, L.Ep, L.pe};
-    RNB_TRY((launch_rows<true, EpiR>(pb.gz[l], L.Hp, packed + ln.w_off, ln.Kp, pb.Mp, ln.Kp, ln.Np, epi, s)));
+    RNB_TRY((launch_rows<true, EpiR>(pb.gz[l], L.Hp, packed + ln.w_off, ln.Kp, pb.Mp, ln.Kp, ln.Np, epi, mm_flops(pb.M, ln), s)));
   }
   {
     const Lin& ln = L.hid[0];
     EpiR0 epi{pb.ge, L.Ep, L.pe, L.skip >= 1 ? 1 : 0};
-    RNB_TRY((launch_rows<true, EpiR0>(pb.gz[0], L.Hp, packed + ln.w_off, ln.Kp, pb.Mp, ln.Kp, ln.Np, epi, s)));
+    RNB_TRY((launch_rows<true, EpiR0>(pb.gz[0], L.Hp, packed + ln.w_off, ln.Kp, pb.Mp, ln.Kp, ln.Np, epi, mm_flops(pb.M, ln), s)));
   }
   hipLaunchKernelGGL(normal_kernel, dim3(blocks_for(pb.Mp, 256)), dim3(256), 0, s, pb.x, pb.ge, L.Ep, L.multires,
                      pb.Mp, pb.nrm);
@@ -503,7 +508,7 @@ int sweep_color(const Layout& L, const float* packed, PointBufs& pb, const float
     const float* in = l == 0 ? pb.cin : pb.ac[l - 1];
     const int lda = l == 0 ? L.Cinp : L.Hcp;
     EpiRelu epi{packed + ln.b_off, pb.ac[l], L.Hcp, ln.N};
-    RNB_TRY((launch_rows<false, EpiRelu>(in, lda, packed + ln.w_off, ln.Kp, pb.Mp, ln.Np, ln.Kp, epi, s)));
+    RNB_TRY((launch_rows<false, EpiRelu>(in, lda, packed + ln.w_off, ln.Kp, pb.Mp, ln.Np, ln.Kp, epi, mm_flops(pb.M, ln), s)));
   }
   hipLaunchKernelGGL(color_out_kernel, dim3(blocks_for(pb.Mp * 32, 256)), dim3(256), 0, s, pb.ac[L.nc - 1], L.Hcp,
                      L.Hc, packed + L.colo.w_off, L.colo.Kp, packed + L.colo.b_off, L.Co, L.squeeze, pb.Mp, pb.alb);
@@ -528,13 +533,13 @@ int sweep_backward(const Layout& L, const float* packed, PointBufs& pb, bool wit
       const float* in = l == 0 ? pb.cin : pb.ac[l - 1];
       const int ldin = l == 0 ? L.Cinp : L.Hcp;
       DwPair p{pb.zc[l], L.Hcp, in, ldin};
-      RNB_TRY(launch_dw(p, p, 1, M, ln.Np, ln.Kp, packed_grad + ln.w_off, ln.Kp, packed_grad + ln.b_off, 0, s));
+      RNB_TRY(launch_dw(p, p, 1, M, ln.Np, ln.Kp, packed_grad + ln.w_off, ln.Kp, packed_grad + ln.b_off, 0, mm_flops(M, ln), s));
       if (l > 0) {
         EpiReluMask epi{pb.ac[l - 1], pb.zc[l - 1], L.Hcp, L.col[l - 1].N};
-        RNB_TRY((launch_rows<true, EpiReluMask>(pb.zc[l], L.Hcp, packed + ln.w_off, ln.Kp, Mp, ln.Kp, ln.Np, epi, s)));
+        RNB_TRY((launch_rows<true, EpiReluMask>(pb.zc[l], L.Hcp, packed + ln.w_off, ln.Kp, Mp, ln.Kp, ln.Np, epi, mm_flops(M, ln), s)));
       } else {
         EpiStore epi{pb.cinb, L.Cinp};
-        RNB_TRY((launch_rows<true, EpiStore>(pb.zc[0], L.Hcp, packed + ln.w_off, ln.Kp, Mp, ln.Kp, ln.Np, epi, s)));
+        RNB_TRY((launch_rows<true, EpiStore>(pb.zc[0], L.Hcp, packed + ln.w_off, ln.Kp, Mp, ln.Kp, ln.Np, epi, mm_flops(M, ln), s)));
       }
     }
   }
@@ -548,7 +553,7 @@ int sweep_backward(const Layout& L, const float* packed, PointBufs& pb, bool wit
     const float* in = l == 0 ? pb.geb : pb.u[l];
     const int lda = l == 0 ? L.Ep : L.Hp;
     EpiRA epi{pb.a[l], pb.gz[l], pb.zR[l], pb.u[l + 1], L.Hp, ln.N, (l + 1 == L.skip) ? pb.geb : nullptr, L.Ep, L.pe};
-    RNB_TRY((launch_rows<false, EpiRA>(in, lda, packed + ln.w_off, ln.Kp, Mp, ln.Np, ln.Kp, epi, s)));
+    RNB_TRY((launch_rows<false, EpiRA>(in, lda, packed + ln.w_off, ln.Kp, Mp, ln.Np, ln.Kp, epi, mm_flops(M, ln), s)));
   }
   // ---- sdf-head row gradient ---------------------------------------------------------------------
   {
@@ -563,11 +568,12 @@ int sweep_backward(const Layout& L, const float* packed, PointBufs& pb, bool wit
     EpiFB epi{pb.a[L.nh - 1], pb.zR[L.nh - 1], pb.zb[L.nh - 1], L.Hp, L.hid[L.nh - 1].N, pb.sbar,
               packed + L.wsdf_off, 1.f / L.sdf_scale};
     const int K = with_color ? L.feat.Np : 0;   // no_albedo: fbar == 0, the GEMM degenerates to its epilogue
-    RNB_TRY((launch_rows<true, EpiFB>(pb.cinb, L.Cinp, packed + L.feat.w_off, L.feat.Kp, Mp, L.feat.Kp, K, epi, s)));
+    RNB_TRY((launch_rows<true, EpiFB>(pb.cinb, L.Cinp, packed + L.feat.w_off, L.feat.Kp, Mp, L.feat.Kp, K, epi,
+                                      with_color ? mm_flops(M, L.feat) : 0.0, s)));
     if (with_color) {
       DwPair p{pb.cinb, L.Cinp, pb.a[L.nh - 1], L.Hp};
       RNB_TRY(launch_dw(p, p, 1, M, L.feat.Np, L.feat.Kp, packed_grad + L.feat.w_off, L.feat.Kp,
-                        packed_grad + L.feat.b_off, 0, s));
+                        packed_grad + L.feat.b_off, 0, mm_flops(M, L.feat), s));
     }
   }
   // ---- FB + dW, layers nh-1 .. 0 -------------------------------------------------------------------
@@ -578,11 +584,12 @@ int sweep_backward(const Layout& L, const float* packed, PointBufs& pb, bool wit
     const float* uin = l == 0 ? pb.geb : pb.u[l];
     DwPair p1{pb.gz[l], L.Hp, uin, ldin};
     DwPair p2{pb.zb[l], L.Hp, in, ldin};
-    RNB_TRY(launch_dw(p1, p2, 2, M, ln.Np, ln.Kp, packed_grad + ln.w_off, ln.Kp, packed_grad + ln.b_off, 1, s));
+    RNB_TRY(launch_dw(p1, p2, 2, M, ln.Np, ln.Kp, packed_grad + ln.w_off, ln.Kp, packed_grad + ln.b_off, 1,
+                      2.0 * mm_flops(M, ln), s));
     if (l > 0) {
       const Lin& lp = L.hid[l - 1];
       EpiFB epi{pb.a[l - 1], pb.zR[l - 1], pb.zb[l - 1], L.Hp, lp.N, nullptr, nullptr, 1.f};
-      RNB_TRY((launch_rows<true, EpiFB>(pb.zb[l], L.Hp, packed + ln.w_off, ln.Kp, Mp, ln.Kp, ln.Np, epi, s)));
+      RNB_TRY((launch_rows<true, EpiFB>(pb.zb[l], L.Hp, packed + ln.w_off, ln.Kp, Mp, ln.Kp, ln.Np, epi, mm_flops(M, ln), s)));
     }
   }
   return RNB_OK;

@@ -201,4 +201,21 @@ int weightnorm_bwd(const rnb_model_desc* d, const Layout& L, const rnb_mlp_param
                    const float* pgrad, const rnb_mlp_grads* gs, const rnb_mlp_grads* gc, hipStream_t s);
 const char* last_error();
 
+// ---- optional GEMM event instrumentation (prof.hip) ----------------------------------------------
+bool prof_enabled();
+void prof_begin(double flops, hipStream_t s);
+void prof_end(hipStream_t s);
+int profile_enable(int on);
+int profile_collect(double* ms, int64_t* launches, double* flops);
+struct ProfScope {
+  hipStream_t s;
+  bool on;
+  ProfScope(double flops, hipStream_t st) : s(st), on(prof_enabled()) {
+    if (on) prof_begin(flops, s);
+  }
+  ~ProfScope() {
+    if (on) prof_end(s);
+  }
+};
+
 }  // namespace rnb

@@ -198,14 +198,18 @@ def test_fine_pass_golden(R, name):
     b = {k: v.to(_dev()) for k, v in g.batch.items()}
     z_vals = g.steps[-1]["z_out"].to(_dev())
     out = _render(ren, g, b, z_vals)
+    # cdf = sigmoid(inv_s * sdf) turns an fp32-rounding-level SDF difference d into up to inv_s*d/4, so
+    # the absolute tolerance of everything downstream of the CDFs scales with inv_s (403 when sharpened)
+    inv_s = float(torch.exp(p["dev.variance"] * 10.0))
+    atol = 1e-5 + 2.5e-7 * inv_s
     for k, ref in g.out.items():
         if k == "loss":
             continue
         got = out[k].detach().cpu()
         assert got.shape == ref.shape, k
-        torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-5, msg=lambda m: f"{k}: {m}")
+        torch.testing.assert_close(got, ref, rtol=1e-4, atol=atol, msg=lambda m: f"{k}: {m}")
     loss = _loss(g, out, b)
-    torch.testing.assert_close(loss.detach().cpu(), g.out["loss"], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(loss.detach().cpu(), g.out["loss"], rtol=1e-4, atol=atol)
     loss.backward()
     torch.cuda.synchronize()
     named = {("sdf." + k): v for k, v in sdf.named_parameters()}
