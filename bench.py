@@ -54,7 +54,9 @@ def cpu_baseline(rays, steps, warmup_mode, no_albedo):
     """The oracle (a PyTorch-CPU restatement with the reference's op structure: two fine SDF forwards,
     autograd double backward, Adam) timed on this box's host cores on a bounded sample."""
     O, mc = make_oracle_conf()
-    threads = os.cpu_count() or 1
+    # the GPU box grants 16 host cores per GPU; os.cpu_count() reports the whole host
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = int(os.environ.get("RNB_CPU_THREADS", min(avail, 16)))
     torch.set_num_threads(threads)
     torch.manual_seed(0)
     p = O.init_params(mc)
@@ -73,6 +75,7 @@ def cpu_baseline(rays, steps, warmup_mode, no_albedo):
         loss.backward()
         opt.step()
         dt = time.perf_counter() - t0
+        print(f"[bench] cpu baseline step {it}: {dt:.2f} s", file=sys.stderr, flush=True)
         if it > 0:
             times.append(dt)
     times.sort()
@@ -141,6 +144,9 @@ def main():
 
     for i in range(args.warmup):
         step(i)
+    torch.cuda.synchronize()
+    if rank == 0:
+        print(f"[bench] warm-up done ({args.warmup} steps)", file=sys.stderr, flush=True)
     use_events = not args.no_gemm_events
     barrier()
     if use_events:
@@ -159,6 +165,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     final_loss = float(loss.detach())
+    if rank == 0:
+        print(f"[bench] timed region done: {elapsed:.3f} s for {args.steps} steps", file=sys.stderr, flush=True)
 
     if rank == 0:
         flags = R.native.MODE_MVPS | (R.native.FLAG_NO_ALBEDO if args.no_albedo else 0)

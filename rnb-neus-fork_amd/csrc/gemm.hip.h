@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dw_kernel(DwPair p1, DwPair p2, i
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-  float bsum = 0.f;
+  double bsum = 0.0;   // bias gradients are long signed sums: keep the per-block partial in fp64
   const bool do_bias = (db != nullptr) && blockIdx.y == 0 && tid < 128 && (n_blk + tid < N);
 
   if (m_begin < m_end) {
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dw_kernel(DwPair p1, DwPair p2, i
         }
         if (do_bias && pi == bias_pair) {
 #pragma unroll 8
-          for (int kk = 0; kk < BK; ++kk) bsum += Xs[kk * LDN + tid];
+          for (int kk = 0; kk < BK; ++kk) bsum += (double)Xs[kk * LDN + tid];
         }
         mma_step<true, true>(Xs, Ys, wm, wn, lane, on0, on1, acc);
         __syncthreads();
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dw_kernel(DwPair p1, DwPair p2, i
       }
     }
   }
-  if (do_bias) atomicAdd(db + n_blk + tid, bsum);
+  if (do_bias) atomicAdd(db + n_blk + tid, (float)bsum);
 }
 
 // ---- activation helpers ----------------------------------------------------------------------------

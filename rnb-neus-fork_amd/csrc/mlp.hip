@@ -240,15 +240,15 @@ __global__ void sdf_head_bwd_kernel(const float* __restrict__ a, const float* __
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_blk;
   const int64_t r1 = min(M, r0 + rows_per_blk);
   for (int k = threadIdx.x; k < H; k += blockDim.x) {
-    float s = 0.f;
+    double s = 0.0;
     for (int64_t row = r0; row < r1; ++row)
-      s += sbar[row] * inv_scale * a[row * Hp + k] + ulast[row * Hp + k];
-    atomicAdd(dwsdf + k, s);
+      s += (double)(sbar[row] * inv_scale * a[row * Hp + k] + ulast[row * Hp + k]);
+    atomicAdd(dwsdf + k, (float)s);
   }
   if (threadIdx.x == 0) {
-    float s = 0.f;
-    for (int64_t row = r0; row < r1; ++row) s += sbar[row] * inv_scale;
-    atomicAdd(dbsdf, s);
+    double s = 0.0;
+    for (int64_t row = r0; row < r1; ++row) s += (double)(sbar[row] * inv_scale);
+    atomicAdd(dbsdf, (float)s);
   }
 }
 

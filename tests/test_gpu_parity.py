@@ -251,22 +251,30 @@ def test_full_batch_512_matches_oracle(R):
     loss.backward()
     torch.cuda.synchronize()
     z = ren.last_z_vals.cpu()
-    pr = {k: v.clone().requires_grad_(True) for k, v in p.items()}
-    ref = O.render_rnb(pr, mc, batch["rays_o"], batch["rays_d"], batch["near"], batch["far"], batch["lights_dir"],
-                       cos_anneal_ratio=1.0, z_vals=z)
-    ref_loss = O.rnb_loss(ref, batch["true_rgb"], batch["mask"])[0]
+    torch.set_num_threads(16)
+    # ground truth in float64 (bias gradients are sums of 65,536 signed terms: an fp32 CPU sum is itself
+    # only good to ~1e-3 there, so both fp32 implementations are measured against the fp64 oracle)
+    pr = {k: v.double().requires_grad_(True) for k, v in p.items()}
+    b64 = {k: v.double() for k, v in batch.items()}
+    ref = O.render_rnb(pr, mc, b64["rays_o"], b64["rays_d"], b64["near"], b64["far"], b64["lights_dir"],
+                       cos_anneal_ratio=1.0, z_vals=z.double())
+    ref_loss = O.rnb_loss(ref, b64["true_rgb"], b64["mask"])[0]
     ref_loss.backward()
     for k in ("color_fine", "weights", "weight_sum", "gradients", "cdf_fine", "gradient_error"):
-        torch.testing.assert_close(out[k].detach().cpu(), ref[k].detach(), rtol=2e-4, atol=2e-5,
+        torch.testing.assert_close(out[k].detach().cpu().double(), ref[k].detach().double(), rtol=2e-4, atol=2e-5,
                                    msg=lambda m: f"{k}: {m}")
-    torch.testing.assert_close(loss.detach().cpu(), ref_loss.detach(), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(loss.detach().cpu().double(), ref_loss.detach(), rtol=1e-4, atol=1e-5)
     named = {("sdf." + k): v for k, v in sdf.named_parameters()}
     named["dev.variance"] = dev.variance
     named.update({("color." + k): v for k, v in col.named_parameters()})
+    worst = ("", 0.0)
     for k, v in named.items():
         rg = pr[k].grad
-        rel = float((v.grad.cpu() - rg).norm() / rg.norm().clamp_min(1e-20))
+        rel = float((v.grad.cpu().double() - rg).norm() / rg.norm().clamp_min(1e-20))
+        if rel > worst[1]:
+            worst = (k, rel)
         assert rel < 1e-3, f"{k}: rel-L2 {rel:.3e}"
+    print(f"B=512 vs fp64 oracle: worst gradient rel-L2 = {worst[1]:.2e} ({worst[0]})")
 
 
 def test_size_independent_properties(R):
