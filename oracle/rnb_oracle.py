@@ -432,7 +432,7 @@ def render_rnb(p, mc: ModelConf, rays_o, rays_d, near, far, lights_dir, t_rand=N
 def rnb_loss(render_out, true_rgb, mask, igr_weight=0.1, mask_weight=0.1):
     n_lights = true_rgb.shape[0]
     if mask_weight > 0.0:
-        mask = (mask > 0.5).float()
+        mask = (mask > 0.5).to(render_out["weight_sum"].dtype)   # `.float()` in the reference (fp32 run)
     else:
         mask = torch.ones_like(mask)
     mask_sum = mask.sum() + 1e-5
