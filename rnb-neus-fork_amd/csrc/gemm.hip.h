@@ -1,10 +1,12 @@
 // fp32 MFMA GEMM building blocks for gfx950 (v_mfma_f32_32x32x2_f32: exact fp32, k-ordered fma chain).
 //
-// One workgroup = 256 threads = 4 wave64 arranged 2x2; block tile 128x128, K-step 32; each wave owns a
-// 64x64 sub-tile = 2x2 MFMA tiles of 32x32 (4 x 16 accumulator registers per lane).  Operand tiles are
-// staged through LDS with a register prefetch of the next K-step (global loads in flight while the
-// matrix cores run).  fp32 MFMA retires 2 k per 64 cycles per SIMD, so operand bandwidth is far from
-// binding; the layouts below are chosen for conflict-free ds_read_b128 / ds_read_b32.
+// One workgroup = 256 threads = 4 wave64 arranged 2(M) x 2(N); block tile 128 x BN (BN = 128 or 256),
+// K-step 32; each wave owns a 64 x BN/2 sub-tile = 2 x TN MFMA tiles of 32x32 (16 accumulator registers
+// per tile per lane).  Operand tiles are staged through LDS with a register prefetch of the next K-step
+// (global loads in flight while the matrix cores run).  fp32 MFMA retires 2 k per 64 cycles per SIMD, so
+// operand bandwidth is far from binding; the layouts are chosen for conflict-free ds_read_b128 /
+// ds_read_b32.  All tile/wave indices are kept in SGPRs (readfirstlane) so every MFMA runs with full
+// EXEC and no per-instruction branching; partially filled column blocks take a separate guarded path.
 //
 // The reduction index inside a K-step is permuted: within each group of 8 k, lane half h (= lane>>5)
 // supplies k = 8q+4h+c for MFMA step c (one 16-byte LDS read feeds 4 MFMAs).  A and B use the same
@@ -17,241 +19,286 @@ namespace rnb {
 typedef float v16f __attribute__((ext_vector_type(16)));
 
 constexpr int BM = 128;
-constexpr int BN = 128;
 constexpr int BK = 32;
-constexpr int LDK = BK + 4;   // pitch of a k-contiguous tile  [128][36]
-constexpr int LDN = 128;      // pitch of a k-major tile       [32][128]
-constexpr int TILE_FLOATS = 128 * LDK;  // 4608 floats >= 32*128
+constexpr int LDK = BK + 4;   // pitch (floats) of a k-contiguous tile  [rows][36]
+
+__device__ inline int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
 // ---- global -> register staging ------------------------------------------------------------------
-// k-contiguous source: element (r, k) at src[r*ld + k]; tile = rows r0..r0+127, k0..k0+31.
-// Rows >= rmax are zero-filled.
+// k-contiguous source: element (r, k) at src[r*ld + k]; tile = ROWS rows from r0, k0..k0+31.
+template <int ROWS, bool GUARD>
 __device__ inline void load_rows(const float* __restrict__ src, int ld, int r0, int k0, int rmax, int tid,
-                                 float4 (&v)[4]) {
+                                 float4 (&v)[ROWS / 32]) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int idx = tid + 256 * i;
-    int r = idx >> 3, c4 = idx & 7;
-    if (r0 + r < rmax)
+  for (int i = 0; i < ROWS / 32; ++i) {
+    const int idx = tid + 256 * i;
+    const int r = idx >> 3, c4 = idx & 7;
+    if constexpr (!GUARD) {
       v[i] = *reinterpret_cast<const float4*>(src + (size_t)(r0 + r) * ld + k0 + c4 * 4);
-    else
-      v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {   // branch-free: load from a clamped (valid) row, then select
+      const bool ok = r0 + r < rmax;
+      const int rr = ok ? r0 + r : rmax - 1;
+      const float4 t = *reinterpret_cast<const float4*>(src + (size_t)rr * ld + k0 + c4 * 4);
+      v[i] = make_float4(ok ? t.x : 0.f, ok ? t.y : 0.f, ok ? t.z : 0.f, ok ? t.w : 0.f);
+    }
   }
 }
-__device__ inline void store_rows(float* __restrict__ T, int tid, const float4 (&v)[4]) {
+template <int ROWS>
+__device__ inline void store_rows(float* __restrict__ T, int tid, const float4 (&v)[ROWS / 32]) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int idx = tid + 256 * i;
-    int r = idx >> 3, c4 = idx & 7;
+  for (int i = 0; i < ROWS / 32; ++i) {
+    const int idx = tid + 256 * i;
+    const int r = idx >> 3, c4 = idx & 7;
     *reinterpret_cast<float4*>(T + r * LDK + c4 * 4) = v[i];
   }
 }
-// k-major source: element (k, c) at src[k*ld + c]; tile = k rows k0..k0+31, columns c0..c0+127.
-// k >= kmax or c >= cmax are zero-filled.
+// k-major source: element (k, c) at src[k*ld + c]; tile = 32 k rows from k0, COLS columns from c0.
+template <int COLS, bool GUARD>
 __device__ inline void load_kmajor(const float* __restrict__ src, int ld, int k0, int c0, int kmax, int cmax,
-                                   int tid, float4 (&v)[4]) {
+                                   int tid, float4 (&v)[COLS / 32]) {
+  constexpr int C4 = COLS / 4;   // float4 per k row
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int idx = tid + 256 * i;
-    int kk = idx >> 5, c4 = idx & 31;
-    if (k0 + kk < kmax && c0 + c4 * 4 < cmax)
+  for (int i = 0; i < COLS / 32; ++i) {
+    const int idx = tid + 256 * i;
+    const int kk = idx / C4, c4 = idx % C4;
+    if constexpr (!GUARD) {
       v[i] = *reinterpret_cast<const float4*>(src + (size_t)(k0 + kk) * ld + c0 + c4 * 4);
-    else
-      v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {   // branch-free: clamp to a valid element, then select
+      const bool ok = (k0 + kk < kmax) && (c0 + c4 * 4 < cmax);
+      const int kr = k0 + kk < kmax ? k0 + kk : kmax - 1;
+      const int cc = c0 + c4 * 4 < cmax ? c0 + c4 * 4 : cmax - 4;
+      const float4 t = *reinterpret_cast<const float4*>(src + (size_t)kr * ld + cc);
+      v[i] = make_float4(ok ? t.x : 0.f, ok ? t.y : 0.f, ok ? t.z : 0.f, ok ? t.w : 0.f);
+    }
   }
 }
-__device__ inline void store_kmajor(float* __restrict__ T, int tid, const float4 (&v)[4]) {
+template <int COLS>
+__device__ inline void store_kmajor(float* __restrict__ T, int tid, const float4 (&v)[COLS / 32]) {
+  constexpr int C4 = COLS / 4;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int idx = tid + 256 * i;
-    int kk = idx >> 5, c4 = idx & 31;
-    *reinterpret_cast<float4*>(T + kk * LDN + c4 * 4) = v[i];
+  for (int i = 0; i < COLS / 32; ++i) {
+    const int idx = tid + 256 * i;
+    const int kk = idx / C4, c4 = idx % C4;
+    *reinterpret_cast<float4*>(T + kk * COLS + c4 * 4) = v[i];
   }
 }
 
 // ---- LDS -> MFMA fragments ---------------------------------------------------------------------
-template <bool KMAJOR>
+// PITCH: LDK for k-contiguous tiles, the tile width for k-major tiles.
+template <bool KMAJOR, int PITCH>
 __device__ inline void frag4(const float* __restrict__ T, int idx, int q, int h, float (&o)[4]) {
   if constexpr (!KMAJOR) {
-    float4 t = *reinterpret_cast<const float4*>(T + idx * LDK + q * 8 + h * 4);
+    const float4 t = *reinterpret_cast<const float4*>(T + idx * PITCH + q * 8 + h * 4);
     o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
   } else {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) o[c] = T[(q * 8 + h * 4 + c) * LDN + idx];
+    for (int c = 0; c < 4; ++c) o[c] = T[(q * 8 + h * 4 + c) * PITCH + idx];
   }
 }
 
-// One K-step (32 k) of a wave's 64x64 sub-tile.  tile_on[j] says whether column tile j is inside N.
-template <bool A_KMAJOR, bool B_KMAJOR>
-__device__ inline void mma_step(const float* __restrict__ As, const float* __restrict__ Bs, int wm, int wn,
-                                int lane, bool on0, bool on1, v16f (&acc)[2][2]) {
+// One K-step (32 k) of a wave's 64 x (32*TN) sub-tile.  `mask` bit j = column tile j is inside N
+// (wave-uniform, only consulted when GUARD).
+template <bool A_KMAJOR, int A_PITCH, bool B_KMAJOR, int B_PITCH, int TN, bool GUARD>
+__device__ inline void mma_step(const float* __restrict__ As, const float* __restrict__ Bs, int a_base, int b_base,
+                                int lane, unsigned mask, v16f (&acc)[2][TN]) {
   const int i = lane & 31, h = lane >> 5;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    float a0[4], a1[4], b0[4], b1[4];
-    frag4<A_KMAJOR>(As, wm * 64 + i, q, h, a0);
-    frag4<A_KMAJOR>(As, wm * 64 + 32 + i, q, h, a1);
-    frag4<B_KMAJOR>(Bs, wn * 64 + i, q, h, b0);
-    frag4<B_KMAJOR>(Bs, wn * 64 + 32 + i, q, h, b1);
+    float a[2][4], b[TN][4];
+    frag4<A_KMAJOR, A_PITCH>(As, a_base + i, q, h, a[0]);
+    frag4<A_KMAJOR, A_PITCH>(As, a_base + 32 + i, q, h, a[1]);
+#pragma unroll
+    for (int tj = 0; tj < TN; ++tj) frag4<B_KMAJOR, B_PITCH>(Bs, b_base + 32 * tj + i, q, h, b[tj]);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      if (on0) {
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[c], b0[c], acc[0][0], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[c], b0[c], acc[1][0], 0, 0, 0);
-      }
-      if (on1) {
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[c], b1[c], acc[0][1], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[c], b1[c], acc[1][1], 0, 0, 0);
+#pragma unroll
+      for (int tj = 0; tj < TN; ++tj) {
+        if (!GUARD || ((mask >> tj) & 1u)) {
+          acc[0][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][c], b[tj][c], acc[0][tj], 0, 0, 0);
+          acc[1][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1][c], b[tj][c], acc[1][tj], 0, 0, 0);
+        }
       }
     }
+    // keep the fragment loads of the next k-group behind this group's MFMAs: hoisting all four groups'
+    // ds_reads to the top costs 4x the fragment registers and spills the staging registers
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
-// Accumulator element (tile ti,tj ; register r) of lane `lane` -> (row, col) inside the 128x128 block.
-__device__ inline int acc_row(int wm, int ti, int r, int lane) {
-  return wm * 64 + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-}
-__device__ inline int acc_col(int wn, int tj, int lane) { return wn * 64 + tj * 32 + (lane & 31); }
+// Accumulator element (tile ti ; register r) of lane `lane` -> row inside the wave's 64-row band.
+__device__ inline int acc_row(int ti, int r, int lane) { return ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
-template <class Epi>
-__device__ inline void run_epilogue(const v16f (&acc)[2][2], int m_blk, int n_blk, int wm, int wn, int lane,
-                                    bool on0, bool on1, const Epi& epi) {
+template <int TN, class Epi>
+__device__ inline void run_epilogue(const v16f (&acc)[2][TN], int row0, int col0, int lane, unsigned mask,
+                                    const Epi& epi) {
 #pragma unroll
-  for (int tj = 0; tj < 2; ++tj) {
-    if (!(tj == 0 ? on0 : on1)) continue;
-    const int col = n_blk + acc_col(wn, tj, lane);
+  for (int tj = 0; tj < TN; ++tj) {
+    if (!((mask >> tj) & 1u)) continue;
+    const int col = col0 + tj * 32 + (lane & 31);
 #pragma unroll
     for (int ti = 0; ti < 2; ++ti) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m_blk + acc_row(wm, ti, r, lane);
-        epi(row, col, acc[ti][tj][r]);
-      }
+      for (int r = 0; r < 16; ++r) epi(row0 + acc_row(ti, r, lane), col, acc[ti][tj][r]);
     }
   }
+}
+
+template <int TN>
+__device__ inline void zero_acc(v16f (&acc)[2][TN]) {
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 }
 
 // ---- C[M x N] = A[M x K] * op(B) ------------------------------------------------------------------
 //   B_KMAJOR == false ("NT"): B given as W[N][K] (k contiguous): C = A W^T      (forward-shaped layers)
 //   B_KMAJOR == true  ("NN"): B given as W[K][N] (n contiguous): C = A W        (reverse-shaped layers)
-// M is a multiple of 128 (padded buffers), N and K multiples of 32.  grid = (M/128, ceil(N/128)).
-template <bool B_KMAJOR, class Epi>
-__global__ __launch_bounds__(256, 2) void gemm_rows_kernel(const float* __restrict__ A, int lda,
-                                                           const float* __restrict__ W, int ldw, int N,
-                                                           int K, Epi epi) {
-  __shared__ __attribute__((aligned(16))) float smem[2 * TILE_FLOATS];
-  float* As = smem;
-  float* Bs = smem + TILE_FLOATS;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int m_blk = blockIdx.x * BM, n_blk = blockIdx.y * BN;
-  const bool on0 = n_blk + wn * 64 < N, on1 = n_blk + wn * 64 + 32 < N;
-
-  v16f acc[2][2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-  float4 ra[4], rb[4];
+// M is a multiple of 128 (padded buffers), N and K multiples of 32.  grid = (M/128, ceil(N/BN)).
+template <bool B_KMAJOR, int BN, bool GUARD>
+__device__ inline void rows_main_loop(const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw,
+                                      int N, int K, int m_blk, int n_blk, int wm, int wn, unsigned mask,
+                                      float* __restrict__ As, float* __restrict__ Bs, v16f (&acc)[2][BN / 64]) {
+  constexpr int TN = BN / 64;
+  constexpr int B_PITCH = B_KMAJOR ? BN : LDK;
+  const int tid = threadIdx.x, lane = tid & 63;
+  float4 ra[BM / 32], rb[BN / 32];
   const int nk = K / BK;
   if (nk > 0) {
-    load_rows(A, lda, m_blk, 0, 0x7fffffff, tid, ra);
-    if constexpr (!B_KMAJOR) load_rows(W, ldw, n_blk, 0, N, tid, rb);
-    else load_kmajor(W, ldw, 0, n_blk, K, N, tid, rb);
+    load_rows<BM, false>(A, lda, m_blk, 0, 0, tid, ra);
+    if constexpr (!B_KMAJOR) load_rows<BN, GUARD>(W, ldw, n_blk, 0, N, tid, rb);
+    else load_kmajor<BN, GUARD>(W, ldw, 0, n_blk, K, N, tid, rb);
   }
   for (int kt = 0; kt < nk; ++kt) {
-    store_rows(As, tid, ra);
-    if constexpr (!B_KMAJOR) store_rows(Bs, tid, rb);
-    else store_kmajor(Bs, tid, rb);
+    store_rows<BM>(As, tid, ra);
+    if constexpr (!B_KMAJOR) store_rows<BN>(Bs, tid, rb);
+    else store_kmajor<BN>(Bs, tid, rb);
     __syncthreads();
     if (kt + 1 < nk) {
       const int k0 = (kt + 1) * BK;
-      load_rows(A, lda, m_blk, k0, 0x7fffffff, tid, ra);
-      if constexpr (!B_KMAJOR) load_rows(W, ldw, n_blk, k0, N, tid, rb);
-      else load_kmajor(W, ldw, k0, n_blk, K, N, tid, rb);
+      load_rows<BM, false>(A, lda, m_blk, k0, 0, tid, ra);
+      if constexpr (!B_KMAJOR) load_rows<BN, GUARD>(W, ldw, n_blk, k0, N, tid, rb);
+      else load_kmajor<BN, GUARD>(W, ldw, k0, n_blk, K, N, tid, rb);
     }
-    mma_step<false, B_KMAJOR>(As, Bs, wm, wn, lane, on0, on1, acc);
+    mma_step<false, LDK, B_KMAJOR, B_PITCH, TN, GUARD>(As, Bs, wm * 64, wn * (BN / 2), lane, mask, acc);
     __syncthreads();
   }
-  run_epilogue(acc, m_blk, n_blk, wm, wn, lane, on0, on1, epi);
+}
+
+template <bool B_KMAJOR, int BN, class Epi>
+__global__ __launch_bounds__(256, BN == 256 ? 2 : 3) void gemm_rows_kernel(const float* __restrict__ A, int lda,
+                                                                           const float* __restrict__ W, int ldw,
+                                                                           int N, int K, Epi epi) {
+  constexpr int TN = BN / 64;
+  constexpr int B_FLOATS = B_KMAJOR ? BK * BN : BN * LDK;
+  __shared__ __attribute__((aligned(16))) float smem[BM * LDK + B_FLOATS];
+  float* As = smem;
+  float* Bs = smem + BM * LDK;
+  const int lane = threadIdx.x & 63;
+  const int wave = wave_id();
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m_blk = blockIdx.x * BM, n_blk = blockIdx.y * BN;
+  // column tiles of this wave that lie inside N (wave-uniform)
+  unsigned mask = 0;
+#pragma unroll
+  for (int tj = 0; tj < TN; ++tj)
+    if (n_blk + wn * (BN / 2) + tj * 32 < N) mask |= 1u << tj;
+
+  v16f acc[2][TN];
+  zero_acc<TN>(acc);
+  if (n_blk + BN <= N)
+    rows_main_loop<B_KMAJOR, BN, false>(A, lda, W, ldw, N, K, m_blk, n_blk, wm, wn, mask, As, Bs, acc);
+  else
+    rows_main_loop<B_KMAJOR, BN, true>(A, lda, W, ldw, N, K, m_blk, n_blk, wm, wn, mask, As, Bs, acc);
+  run_epilogue<TN, Epi>(acc, m_blk + wm * 64, n_blk + wn * (BN / 2), lane, mask, epi);
 }
 
 // ---- dW[N x K] += X1^T Y1 (+ X2^T Y2), reduction over the M points, split over blockIdx.z ---------
 //   X* [M x N] (ldx), Y* [M x K] (ldy); rows >= M are masked.  grid = (ceil(N/128), ceil(K/128), splits).
 //   Partial tiles are accumulated into dW with float atomics (dW zero-initialised by the caller);
-//   colsum(Xb) over the same rows is added to db when db != nullptr (by the blockIdx.y == 0 blocks).
+//   colsum(X) of pair `bias_pair` over the same rows is added to db when db != nullptr (by the
+//   blockIdx.y == 0 blocks).
 struct DwPair {
   const float* X;
   int ldx;
   const float* Y;
   int ldy;
 };
-__global__ __launch_bounds__(256, 2) void gemm_dw_kernel(DwPair p1, DwPair p2, int npairs, int M, int N, int K,
+
+template <bool GUARD>
+__device__ inline void dw_main_loop(const DwPair& p, int m_begin, int m_end, int N, int K, int n_blk, int k_blk,
+                                    int wm, int wn, unsigned mask, bool do_bias, double& bsum,
+                                    float* __restrict__ Xs, float* __restrict__ Ys, v16f (&acc)[2][2]) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  float4 rx[4], ry[4];
+  load_kmajor<128, GUARD>(p.X, p.ldx, m_begin, n_blk, m_end, N, tid, rx);
+  load_kmajor<128, GUARD>(p.Y, p.ldy, m_begin, k_blk, m_end, K, tid, ry);
+  for (int m0 = m_begin; m0 < m_end; m0 += BK) {
+    store_kmajor<128>(Xs, tid, rx);
+    store_kmajor<128>(Ys, tid, ry);
+    __syncthreads();
+    if (m0 + BK < m_end) {
+      load_kmajor<128, GUARD>(p.X, p.ldx, m0 + BK, n_blk, m_end, N, tid, rx);
+      load_kmajor<128, GUARD>(p.Y, p.ldy, m0 + BK, k_blk, m_end, K, tid, ry);
+    }
+    if (do_bias) {
+#pragma unroll 8
+      for (int kk = 0; kk < BK; ++kk) bsum += (double)Xs[kk * 128 + tid];
+    }
+    mma_step<true, 128, true, 128, 2, GUARD>(Xs, Ys, wm * 64, wn * 64, lane, mask, acc);
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256, 3) void gemm_dw_kernel(DwPair p1, DwPair p2, int npairs, int M, int N, int K,
                                                          int rows_per_split, float* __restrict__ dW, int lddw,
                                                          float* __restrict__ db, int bias_pair) {
-  __shared__ __attribute__((aligned(16))) float smem[2 * TILE_FLOATS];
+  __shared__ __attribute__((aligned(16))) float smem[2 * BK * 128];
   float* Xs = smem;
-  float* Ys = smem + TILE_FLOATS;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* Ys = smem + BK * 128;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = wave_id();
   const int wm = wave >> 1, wn = wave & 1;
-  const int n_blk = blockIdx.x * BM, k_blk = blockIdx.y * BN;
+  const int n_blk = blockIdx.x * 128, k_blk = blockIdx.y * 128;
   const int m_begin = blockIdx.z * rows_per_split;
   const int m_end = min(M, m_begin + rows_per_split);
-  const bool on0 = k_blk + wn * 64 < K, on1 = k_blk + wn * 64 + 32 < K;
-  const bool row_on0 = n_blk + wm * 64 < N, row_on1 = n_blk + wm * 64 + 32 < N;
-  (void)row_on0; (void)row_on1;
+  unsigned mask = 0;
+#pragma unroll
+  for (int tj = 0; tj < 2; ++tj)
+    if (k_blk + wn * 64 + tj * 32 < K) mask |= 1u << tj;
+  // fully inside: no row tail (multiple of the K-step) and both column blocks complete
+  const bool full = ((m_end - m_begin) % BK == 0) && (n_blk + 128 <= N) && (k_blk + 128 <= K);
 
   v16f acc[2][2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  zero_acc<2>(acc);
   double bsum = 0.0;   // bias gradients are long signed sums: keep the per-block partial in fp64
-  const bool do_bias = (db != nullptr) && blockIdx.y == 0 && tid < 128 && (n_blk + tid < N);
+  const bool bias_blk = (db != nullptr) && blockIdx.y == 0 && tid < 128 && (n_blk + tid < N);
 
   if (m_begin < m_end) {
     for (int pi = 0; pi < npairs; ++pi) {
       const DwPair p = pi == 0 ? p1 : p2;
-      float4 rx[4], ry[4];
-      load_kmajor(p.X, p.ldx, m_begin, n_blk, m_end, N, tid, rx);
-      load_kmajor(p.Y, p.ldy, m_begin, k_blk, m_end, K, tid, ry);
-      for (int m0 = m_begin; m0 < m_end; m0 += BK) {
-        store_kmajor(Xs, tid, rx);
-        store_kmajor(Ys, tid, ry);
-        __syncthreads();
-        if (m0 + BK < m_end) {
-          load_kmajor(p.X, p.ldx, m0 + BK, n_blk, m_end, N, tid, rx);
-          load_kmajor(p.Y, p.ldy, m0 + BK, k_blk, m_end, K, tid, ry);
-        }
-        if (do_bias && pi == bias_pair) {
-#pragma unroll 8
-          for (int kk = 0; kk < BK; ++kk) bsum += (double)Xs[kk * LDN + tid];
-        }
-        mma_step<true, true>(Xs, Ys, wm, wn, lane, on0, on1, acc);
-        __syncthreads();
-      }
+      const bool do_bias = bias_blk && pi == bias_pair;
+      if (full) dw_main_loop<false>(p, m_begin, m_end, N, K, n_blk, k_blk, wm, wn, mask, do_bias, bsum, Xs, Ys, acc);
+      else dw_main_loop<true>(p, m_begin, m_end, N, K, n_blk, k_blk, wm, wn, mask, do_bias, bsum, Xs, Ys, acc);
     }
   }
   // atomics: each register of a 32x32 accumulator is two 128-byte row segments per wave instruction
 #pragma unroll
   for (int tj = 0; tj < 2; ++tj) {
-    if (!(tj == 0 ? on0 : on1)) continue;
-    const int col = k_blk + acc_col(wn, tj, lane);
+    if (!((mask >> tj) & 1u)) continue;
+    const int col = k_blk + wn * 64 + tj * 32 + (lane & 31);
 #pragma unroll
     for (int ti = 0; ti < 2; ++ti) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = n_blk + acc_row(wm, ti, r, lane);
+        const int row = n_blk + wm * 64 + acc_row(ti, r, lane);
         if (row < N) atomicAdd(dW + (size_t)row * lddw + col, acc[ti][tj][r]);
       }
     }
   }
-  if (do_bias) atomicAdd(db + n_blk + tid, (float)bsum);
+  if (bias_blk) atomicAdd(db + n_blk + tid, (float)bsum);
 }
 
 // ---- activation helpers ----------------------------------------------------------------------------

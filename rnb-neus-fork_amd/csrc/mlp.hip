@@ -407,16 +407,21 @@ static inline double mm_flops(int64_t M, const Lin& ln) { return 2.0 * (double)M
 template <bool B_KMAJOR, class Epi>
 static int launch_rows(const float* A, int lda, const float* W, int ldw, int64_t Mp, int N, int K, const Epi& epi,
                        double flops, hipStream_t s) {
-  dim3 grid((unsigned)(Mp / BM), (unsigned)((N + BN - 1) / BN));
   ProfScope prof(flops, s);
-  hipLaunchKernelGGL((gemm_rows_kernel<B_KMAJOR, Epi>), grid, dim3(256), 0, s, A, lda, W, ldw, N, K, epi);
+  if (N >= 256) {   // 128 x 256 tiles: the 256-wide layers of the full model run as one wave of 2 blocks / CU
+    dim3 grid((unsigned)(Mp / BM), (unsigned)((N + 255) / 256));
+    hipLaunchKernelGGL((gemm_rows_kernel<B_KMAJOR, 256, Epi>), grid, dim3(256), 0, s, A, lda, W, ldw, N, K, epi);
+  } else {
+    dim3 grid((unsigned)(Mp / BM), (unsigned)((N + 127) / 128));
+    hipLaunchKernelGGL((gemm_rows_kernel<B_KMAJOR, 128, Epi>), grid, dim3(256), 0, s, A, lda, W, ldw, N, K, epi);
+  }
   RNB_CHECK_LAUNCH();
   return RNB_OK;
 }
 
 static int launch_dw(DwPair p1, DwPair p2, int npairs, int64_t M, int N, int K, float* dW, int lddw, float* db,
                      int bias_pair, double flops, hipStream_t s) {
-  const int tiles = ((N + BM - 1) / BM) * ((K + BN - 1) / BN);
+  const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
   int splits = (int)((M + 511) / 512);              // >= 512 points per block
   const int max_splits = (1024 + tiles - 1) / tiles;  // ~1024 blocks in flight
   if (splits > max_splits) splits = max_splits;
@@ -424,7 +429,7 @@ static int launch_dw(DwPair p1, DwPair p2, int npairs, int64_t M, int N, int K, 
   int rows = (int)((M + splits - 1) / splits);
   rows = (rows + BK - 1) / BK * BK;
   splits = (int)((M + rows - 1) / rows);
-  dim3 grid((unsigned)((N + BM - 1) / BM), (unsigned)((K + BN - 1) / BN), (unsigned)splits);
+  dim3 grid((unsigned)((N + 127) / 128), (unsigned)((K + 127) / 128), (unsigned)splits);
   ProfScope prof(flops, s);
   hipLaunchKernelGGL(gemm_dw_kernel, grid, dim3(256), 0, s, p1, p2, npairs, (int)M, N, K, rows, dW, lddw, db,
                      bias_pair);
