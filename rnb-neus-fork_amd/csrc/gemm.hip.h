@@ -17,6 +17,13 @@
 namespace rnb {
 
 typedef float v16f __attribute__((ext_vector_type(16)));
+// native 4-vector for register staging (HIP's float4 struct is not split by SROA when it sits in an
+// array: the staging arrays then live in scratch memory)
+typedef float vf4 __attribute__((ext_vector_type(4)));
+__device__ inline vf4 make_vf4(float a, float b, float c, float d) {
+  vf4 r = {a, b, c, d};
+  return r;
+}
 
 constexpr int BM = 128;
 constexpr int BK = 32;
@@ -28,58 +35,58 @@ __device__ inline int wave_id() { return __builtin_amdgcn_readfirstlane((int)(th
 // k-contiguous source: element (r, k) at src[r*ld + k]; tile = ROWS rows from r0, k0..k0+31.
 template <int ROWS, bool GUARD>
 __device__ inline void load_rows(const float* __restrict__ src, int ld, int r0, int k0, int rmax, int tid,
-                                 float4 (&v)[ROWS / 32]) {
+                                 vf4 (&v)[ROWS / 32]) {
 #pragma unroll
   for (int i = 0; i < ROWS / 32; ++i) {
     const int idx = tid + 256 * i;
     const int r = idx >> 3, c4 = idx & 7;
     if constexpr (!GUARD) {
-      v[i] = *reinterpret_cast<const float4*>(src + (size_t)(r0 + r) * ld + k0 + c4 * 4);
+      v[i] = *reinterpret_cast<const vf4*>(src + (size_t)(r0 + r) * ld + k0 + c4 * 4);
     } else {   // branch-free: load from a clamped (valid) row, then select
       const bool ok = r0 + r < rmax;
       const int rr = ok ? r0 + r : rmax - 1;
-      const float4 t = *reinterpret_cast<const float4*>(src + (size_t)rr * ld + k0 + c4 * 4);
-      v[i] = make_float4(ok ? t.x : 0.f, ok ? t.y : 0.f, ok ? t.z : 0.f, ok ? t.w : 0.f);
+      const vf4 t = *reinterpret_cast<const vf4*>(src + (size_t)rr * ld + k0 + c4 * 4);
+      v[i] = make_vf4(ok ? t.x : 0.f, ok ? t.y : 0.f, ok ? t.z : 0.f, ok ? t.w : 0.f);
     }
   }
 }
 template <int ROWS>
-__device__ inline void store_rows(float* __restrict__ T, int tid, const float4 (&v)[ROWS / 32]) {
+__device__ inline void store_rows(float* __restrict__ T, int tid, const vf4 (&v)[ROWS / 32]) {
 #pragma unroll
   for (int i = 0; i < ROWS / 32; ++i) {
     const int idx = tid + 256 * i;
     const int r = idx >> 3, c4 = idx & 7;
-    *reinterpret_cast<float4*>(T + r * LDK + c4 * 4) = v[i];
+    *reinterpret_cast<vf4*>(T + r * LDK + c4 * 4) = v[i];
   }
 }
 // k-major source: element (k, c) at src[k*ld + c]; tile = 32 k rows from k0, COLS columns from c0.
 template <int COLS, bool GUARD>
 __device__ inline void load_kmajor(const float* __restrict__ src, int ld, int k0, int c0, int kmax, int cmax,
-                                   int tid, float4 (&v)[COLS / 32]) {
-  constexpr int C4 = COLS / 4;   // float4 per k row
+                                   int tid, vf4 (&v)[COLS / 32]) {
+  constexpr int C4 = COLS / 4;   // vf4 per k row
 #pragma unroll
   for (int i = 0; i < COLS / 32; ++i) {
     const int idx = tid + 256 * i;
     const int kk = idx / C4, c4 = idx % C4;
     if constexpr (!GUARD) {
-      v[i] = *reinterpret_cast<const float4*>(src + (size_t)(k0 + kk) * ld + c0 + c4 * 4);
+      v[i] = *reinterpret_cast<const vf4*>(src + (size_t)(k0 + kk) * ld + c0 + c4 * 4);
     } else {   // branch-free: clamp to a valid element, then select
       const bool ok = (k0 + kk < kmax) && (c0 + c4 * 4 < cmax);
       const int kr = k0 + kk < kmax ? k0 + kk : kmax - 1;
       const int cc = c0 + c4 * 4 < cmax ? c0 + c4 * 4 : cmax - 4;
-      const float4 t = *reinterpret_cast<const float4*>(src + (size_t)kr * ld + cc);
-      v[i] = make_float4(ok ? t.x : 0.f, ok ? t.y : 0.f, ok ? t.z : 0.f, ok ? t.w : 0.f);
+      const vf4 t = *reinterpret_cast<const vf4*>(src + (size_t)kr * ld + cc);
+      v[i] = make_vf4(ok ? t.x : 0.f, ok ? t.y : 0.f, ok ? t.z : 0.f, ok ? t.w : 0.f);
     }
   }
 }
 template <int COLS>
-__device__ inline void store_kmajor(float* __restrict__ T, int tid, const float4 (&v)[COLS / 32]) {
+__device__ inline void store_kmajor(float* __restrict__ T, int tid, const vf4 (&v)[COLS / 32]) {
   constexpr int C4 = COLS / 4;
 #pragma unroll
   for (int i = 0; i < COLS / 32; ++i) {
     const int idx = tid + 256 * i;
     const int kk = idx / C4, c4 = idx % C4;
-    *reinterpret_cast<float4*>(T + kk * COLS + c4 * 4) = v[i];
+    *reinterpret_cast<vf4*>(T + kk * COLS + c4 * 4) = v[i];
   }
 }
 
@@ -88,7 +95,7 @@ __device__ inline void store_kmajor(float* __restrict__ T, int tid, const float4
 template <bool KMAJOR, int PITCH>
 __device__ inline void frag4(const float* __restrict__ T, int idx, int q, int h, float (&o)[4]) {
   if constexpr (!KMAJOR) {
-    const float4 t = *reinterpret_cast<const float4*>(T + idx * PITCH + q * 8 + h * 4);
+    const vf4 t = *reinterpret_cast<const vf4*>(T + idx * PITCH + q * 8 + h * 4);
     o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
   } else {
 #pragma unroll
@@ -128,17 +135,41 @@ __device__ inline void mma_step(const float* __restrict__ As, const float* __res
 // Accumulator element (tile ti ; register r) of lane `lane` -> row inside the wave's 64-row band.
 __device__ inline int acc_row(int ti, int r, int lane) { return ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
+// Epilogue through LDS: the MFMA accumulator layout (one column per lane, rows spread over registers)
+// would make every global access a 4-byte-per-lane access of two 128-byte row segments.  Each wave
+// instead transposes its sub-tile through a private LDS strip, 16 rows at a time, and then walks it
+// row-major with 16 bytes per lane: the epilogue functor sees 4 consecutive columns of one row
+// (`epi.apply4(row, col, v)`, col % 4 == 0) and issues dwordx4 loads/stores (512 contiguous bytes per
+// half-wave).  `strip` = this wave's [16][32*TN + 4] floats of the (now idle) staging LDS.
 template <int TN, class Epi>
-__device__ inline void run_epilogue(const v16f (&acc)[2][TN], int row0, int col0, int lane, unsigned mask,
-                                    const Epi& epi) {
+__device__ inline void run_epilogue(const v16f (&acc)[2][TN], float* __restrict__ strip, int row0, int col0,
+                                    int lane, unsigned mask, const Epi& epi) {
+  constexpr int W = 32 * TN;   // columns of the wave's sub-tile
+  constexpr int P = W + 4;     // strip pitch (floats)
+  constexpr int C4 = W / 4;    // 16-byte groups per row
+  const int h = lane >> 5, cl = lane & 31;
 #pragma unroll
-  for (int tj = 0; tj < TN; ++tj) {
-    if (!((mask >> tj) & 1u)) continue;
-    const int col = col0 + tj * 32 + (lane & 31);
+  for (int ti = 0; ti < 2; ++ti) {
 #pragma unroll
-    for (int ti = 0; ti < 2; ++ti) {
+    for (int half = 0; half < 2; ++half) {
+      // registers 8*half .. 8*half+7 of every column tile hold rows 16*half .. 16*half+15
 #pragma unroll
-      for (int r = 0; r < 16; ++r) epi(row0 + acc_row(ti, r, lane), col, acc[ti][tj][r]);
+      for (int tj = 0; tj < TN; ++tj) {
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+          const int rl = (rr & 3) + 8 * (rr >> 2) + 4 * h;
+          strip[rl * P + tj * 32 + cl] = acc[ti][tj][half * 8 + rr];
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int it = 0; it < W / 16; ++it) {
+        const int idx = it * 64 + lane;
+        const int rl = idx / C4, c4 = idx % C4;
+        const vf4 v = *reinterpret_cast<const vf4*>(strip + rl * P + c4 * 4);
+        if ((mask >> (c4 >> 3)) & 1u) epi.apply4(row0 + ti * 32 + half * 16 + rl, col0 + c4 * 4, v);
+      }
+      __builtin_amdgcn_wave_barrier();
     }
   }
 }
@@ -164,7 +195,7 @@ __device__ inline void rows_main_loop(const float* __restrict__ A, int lda, cons
   constexpr int TN = BN / 64;
   constexpr int B_PITCH = B_KMAJOR ? BN : LDK;
   const int tid = threadIdx.x, lane = tid & 63;
-  float4 ra[BM / 32], rb[BN / 32];
+  vf4 ra[BM / 32], rb[BN / 32];
   const int nk = K / BK;
   if (nk > 0) {
     load_rows<BM, false>(A, lda, m_blk, 0, 0, tid, ra);
@@ -187,7 +218,10 @@ __device__ inline void rows_main_loop(const float* __restrict__ A, int lda, cons
   }
 }
 
-template <bool B_KMAJOR, int BN, class Epi>
+// GUARD (chosen by the host: N % BN != 0) selects the variant whose B staging is bounds-checked and whose
+// MFMAs are skipped for column tiles outside N.  One variant per kernel: two inlined copies of the main
+// loop in one kernel exceed the backend's alloca-promotion budget and push the staging registers to scratch.
+template <bool B_KMAJOR, int BN, bool GUARD, class Epi>
 __global__ __launch_bounds__(256, BN == 256 ? 2 : 3) void gemm_rows_kernel(const float* __restrict__ A, int lda,
                                                                            const float* __restrict__ W, int ldw,
                                                                            int N, int K, Epi epi) {
@@ -208,11 +242,11 @@ __global__ __launch_bounds__(256, BN == 256 ? 2 : 3) void gemm_rows_kernel(const
 
   v16f acc[2][TN];
   zero_acc<TN>(acc);
-  if (n_blk + BN <= N)
-    rows_main_loop<B_KMAJOR, BN, false>(A, lda, W, ldw, N, K, m_blk, n_blk, wm, wn, mask, As, Bs, acc);
-  else
-    rows_main_loop<B_KMAJOR, BN, true>(A, lda, W, ldw, N, K, m_blk, n_blk, wm, wn, mask, As, Bs, acc);
-  run_epilogue<TN, Epi>(acc, m_blk + wm * 64, n_blk + wn * (BN / 2), lane, mask, epi);
+  rows_main_loop<B_KMAJOR, BN, GUARD>(A, lda, W, ldw, N, K, m_blk, n_blk, wm, wn, mask, As, Bs, acc);
+  // the main loop ends with a barrier: the staging tiles are idle and become the transpose strips
+  static_assert(4 * 16 * (32 * TN + 4) <= BM * LDK + B_FLOATS, "epilogue strips must fit in the staging LDS");
+  run_epilogue<TN, Epi>(acc, smem + wave * 16 * (32 * TN + 4), m_blk + wm * 64, n_blk + wn * (BN / 2), lane, mask,
+                        epi);
 }
 
 // ---- dW[N x K] += X1^T Y1 (+ X2^T Y2), reduction over the M points, split over blockIdx.z ---------
@@ -232,7 +266,7 @@ __device__ inline void dw_main_loop(const DwPair& p, int m_begin, int m_end, int
                                     int wm, int wn, unsigned mask, bool do_bias, double& bsum,
                                     float* __restrict__ Xs, float* __restrict__ Ys, v16f (&acc)[2][2]) {
   const int tid = threadIdx.x, lane = tid & 63;
-  float4 rx[4], ry[4];
+  vf4 rx[4], ry[4];
   load_kmajor<128, GUARD>(p.X, p.ldx, m_begin, n_blk, m_end, N, tid, rx);
   load_kmajor<128, GUARD>(p.Y, p.ldy, m_begin, k_blk, m_end, K, tid, ry);
   for (int m0 = m_begin; m0 < m_end; m0 += BK) {
@@ -252,6 +286,8 @@ __device__ inline void dw_main_loop(const DwPair& p, int m_begin, int m_end, int
   }
 }
 
+// GUARD (host: N % 128 || K % 128 || M % 32) as for gemm_rows_kernel.
+template <bool GUARD>
 __global__ __launch_bounds__(256, 3) void gemm_dw_kernel(DwPair p1, DwPair p2, int npairs, int M, int N, int K,
                                                          int rows_per_split, float* __restrict__ dW, int lddw,
                                                          float* __restrict__ db, int bias_pair) {
@@ -268,8 +304,6 @@ __global__ __launch_bounds__(256, 3) void gemm_dw_kernel(DwPair p1, DwPair p2, i
 #pragma unroll
   for (int tj = 0; tj < 2; ++tj)
     if (k_blk + wn * 64 + tj * 32 < K) mask |= 1u << tj;
-  // fully inside: no row tail (multiple of the K-step) and both column blocks complete
-  const bool full = ((m_end - m_begin) % BK == 0) && (n_blk + 128 <= N) && (k_blk + 128 <= K);
 
   v16f acc[2][2];
   zero_acc<2>(acc);
@@ -280,8 +314,7 @@ __global__ __launch_bounds__(256, 3) void gemm_dw_kernel(DwPair p1, DwPair p2, i
     for (int pi = 0; pi < npairs; ++pi) {
       const DwPair p = pi == 0 ? p1 : p2;
       const bool do_bias = bias_blk && pi == bias_pair;
-      if (full) dw_main_loop<false>(p, m_begin, m_end, N, K, n_blk, k_blk, wm, wn, mask, do_bias, bsum, Xs, Ys, acc);
-      else dw_main_loop<true>(p, m_begin, m_end, N, K, n_blk, k_blk, wm, wn, mask, do_bias, bsum, Xs, Ys, acc);
+      dw_main_loop<GUARD>(p, m_begin, m_end, N, K, n_blk, k_blk, wm, wn, mask, do_bias, bsum, Xs, Ys, acc);
     }
   }
   // atomics: each register of a 32x32 accumulator is two 128-byte row segments per wave instruction
@@ -306,6 +339,25 @@ __global__ __launch_bounds__(256, 3) void gemm_dw_kernel(DwPair p1, DwPair p2, i
 __device__ inline float softplus100(float z) {
   const float t = z * 100.f;
   return t > 20.f ? z : log1pf(expf(t)) * 0.01f;
+}
+// softplus and its derivative in one go: a = softplus(z), D = sigmoid(100 z) (= exactly 1 above the
+// threshold, like PyTorch's softplus backward).  e = exp(t) through the hardware exp2 with a two-term
+// Cody-Waite reduction (|rel err| ~ 1 ulp for t <= 20), log1p(e) = log(u) * e / (u - 1) with u = fl(1 + e)
+// (the classic rounding-compensated form; hardware log2).  ~20 VALU instructions per element.
+__device__ inline void softplus_aD(float z, float& a, float& D) {
+  const float t = z * 100.f;
+  if (t > 20.f) { a = z; D = 1.f; return; }
+  const float tc = fmaxf(t, -87.f);
+  const float n = rintf(tc * 1.44269504088896341f);
+  // tc - n ln2 with ln2 = hi + lo, hi = fl(ln2) = 0.693147182464599609375, lo = -1.904654299957768e-9
+  const float r = fmaf(n, 1.90465429995776804e-09f, fmaf(n, -0.693147182464599609375f, tc));
+  const float e = ldexpf(__builtin_amdgcn_exp2f(r * 1.44269504088896341f), (int)n);
+  const float u = 1.f + e;
+  const float um1 = u - 1.f;
+  const float lg = __builtin_amdgcn_logf(u) * 0.693147180559945309f;
+  const float l1p = um1 == 0.f ? e : lg * (e / um1);
+  a = l1p * 0.01f;
+  D = e / u;
 }
 // D = d softplus / dz = sigmoid(100 z) expressed through a = softplus(z):  D = 1 - exp(-100 a)
 // (exactly 1 above the threshold, where a == z); E = 1 - D, and softplus'' = 100 D E.

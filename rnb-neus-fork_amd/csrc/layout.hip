@@ -105,6 +105,7 @@ void carve_points(const Layout& L, Carver& c, int64_t M, int mode, PointBufs* pb
   pb->sdf = c.take<float>(Mp);
   if (mode & (PM_WITH_NORMAL | PM_WITH_COLOR | PM_WITH_BACKWARD)) {
     for (int l = 0; l < L.nh; ++l) pb->gz[l] = c.take<float>(Mp * L.Hp);
+    for (int l = 0; l < L.nh; ++l) pb->D[l] = c.take<float>(Mp * L.Hp);
     pb->ge = c.take<float>(Mp * L.Ep);
     pb->nrm = c.take<float>(Mp * 4);
   }

@@ -43,9 +43,9 @@ __global__ void pe_points_kernel(const float* __restrict__ pts, int64_t M, int64
 
 // sdf head: sdf = (a_last . w_sdf + b_sdf)/scale ; optionally seeds the reverse sweep gz_last = w_sdf * D
 // 32 lanes per point.
-__global__ void sdf_head_kernel(const float* __restrict__ a, int Hp, int H, const float* __restrict__ wsdf,
-                                const float* __restrict__ bsdf, float inv_scale, int64_t Mp,
-                                float* __restrict__ sdf, float* __restrict__ gz) {
+__global__ void sdf_head_kernel(const float* __restrict__ a, const float* __restrict__ D, int Hp, int H,
+                                const float* __restrict__ wsdf, const float* __restrict__ bsdf, float inv_scale,
+                                int64_t Mp, float* __restrict__ sdf, float* __restrict__ gz) {
   const int sub = threadIdx.x & 31;
   int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
   if (row >= Mp) return;
@@ -55,7 +55,7 @@ __global__ void sdf_head_kernel(const float* __restrict__ a, int Hp, int H, cons
     const float av = ar[k];
     const float w = k < H ? wsdf[k] : 0.f;
     acc = fmaf(av, w, acc);
-    if (gz) gz[row * Hp + k] = k < H ? w * softplus_D(av) : 0.f;
+    if (gz) gz[row * Hp + k] = k < H ? w * D[row * Hp + k] : 0.f;
   }
 #pragma unroll
   for (int o = 16; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 32);
@@ -271,33 +271,56 @@ __global__ void fill_cols_kernel(const float* __restrict__ src, int ncols, int64
 }
 
 // =====================================================================================================
-// GEMM epilogues
+// GEMM epilogues.  apply4(row, col, v): 4 consecutive columns col..col+3 (col % 4 == 0) of one output row.
+// All activation matrices have a padded leading dimension (multiple of 32), so 16-byte accesses are
+// aligned and in bounds; columns >= the real width are written as zeros (or the skip-connection payload).
 // =====================================================================================================
+__device__ inline vf4 ld4(const float* p) { return *reinterpret_cast<const vf4*>(p); }
+__device__ inline void st4(float* p, vf4 v) { *reinterpret_cast<vf4*>(p) = v; }
 
-// F hidden layer: a = softplus(acc + b); columns >= N_real: PE override (layer feeding the skip layer) or 0
+// F hidden layer: a = softplus(acc + b), D = softplus'(acc + b); columns >= N_real: PE override (layer
+// feeding the skip layer) or 0
 struct EpiF {
   const float* b;
   float* out;
+  float* outD;     // nullptr when no derivative is needed (no-grad SDF evaluation)
   int ld;
   int n_real;
   const float* e;  // nullptr unless this layer feeds the skip layer
   int Ep, pe;
-  __device__ void operator()(int row, int col, float v) const {
-    float a;
-    if (col < n_real) a = softplus100(v + b[col]);
-    else if (e != nullptr && col < n_real + pe) a = e[(size_t)row * Ep + (col - n_real)];
-    else a = 0.f;
-    out[(size_t)row * ld + col] = a;
+  __device__ void apply4(int row, int col, vf4 v) const {
+    const vf4 bb = ld4(b + col);
+    vf4 a, D;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int cc = col + c;
+      float ac, Dc;
+      if (cc < n_real) softplus_aD(v[c] + bb[c], ac, Dc);
+      else {
+        ac = (e != nullptr && cc < n_real + pe) ? e[(size_t)row * Ep + (cc - n_real)] : 0.f;
+        Dc = 0.f;
+      }
+      a[c] = ac;
+      D[c] = Dc;
+    }
+    st4(out + (size_t)row * ld + col, a);
+    if (outD) st4(outD + (size_t)row * ld + col, D);
   }
 };
-// plain linear head (+bias) written to a strided buffer for columns < n_real
+// plain linear head (+bias) written to a strided buffer for columns < n_real (n_real % 4 == 0 not assumed)
 struct EpiBias {
   const float* b;
   float* out;
   int ld;
   int n_real;
-  __device__ void operator()(int row, int col, float v) const {
-    if (col < n_real) out[(size_t)row * ld + col] = v + b[col];
+  __device__ void apply4(int row, int col, vf4 v) const {
+    if (col + 3 < n_real) {
+      st4(out + (size_t)row * ld + col, v + ld4(b + col));
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (col + c < n_real) out[(size_t)row * ld + col + c] = v[c] + b[col + c];
+    }
   }
 };
 struct EpiRelu {
@@ -305,25 +328,38 @@ struct EpiRelu {
   float* out;
   int ld;
   int n_real;
-  __device__ void operator()(int row, int col, float v) const {
-    out[(size_t)row * ld + col] = col < n_real ? fmaxf(v + b[col], 0.f) : 0.f;
+  __device__ void apply4(int row, int col, vf4 v) const {
+    const vf4 bb = ld4(b + col);
+    vf4 o;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) o[c] = col + c < n_real ? fmaxf(v[c] + bb[c], 0.f) : 0.f;
+    st4(out + (size_t)row * ld + col, o);
   }
 };
-// R layer l>=1: g = acc ; skip layer: columns [k_split, k_split+pe) go to ge ; gz_{l-1} = g * D(a_{l-1})
+// R layer l>=1: g = acc ; skip layer: columns [k_split, k_split+pe) go to ge ; gz_{l-1} = g * D_{l-1}
 struct EpiR {
-  const float* a_prev;
+  const float* D_prev;
   float* gz_prev;
   int ld;
   int k_split;   // number of columns that belong to the previous layer's output
   float* ge;     // destination of the skip part (or nullptr)
   int Ep, pe;
-  __device__ void operator()(int row, int col, float v) const {
-    if (col < k_split) {
-      const size_t o = (size_t)row * ld + col;
-      gz_prev[o] = v * softplus_D(a_prev[o]);
+  __device__ void apply4(int row, int col, vf4 v) const {
+    const size_t o = (size_t)row * ld + col;
+    if (col + 3 < k_split) {
+      st4(gz_prev + o, v * ld4(D_prev + o));
     } else {
-      if (ge != nullptr && col < k_split + pe) ge[(size_t)row * Ep + (col - k_split)] = v;
-      gz_prev[(size_t)row * ld + col] = 0.f;
+      vf4 g;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int cc = col + c;
+        if (cc < k_split) g[c] = v[c] * D_prev[o + c];
+        else {
+          if (ge != nullptr && cc < k_split + pe) ge[(size_t)row * Ep + (cc - k_split)] = v[c];
+          g[c] = 0.f;
+        }
+      }
+      st4(gz_prev + o, g);
     }
   }
 };
@@ -332,15 +368,18 @@ struct EpiR0 {
   float* ge;
   int Ep, pe;
   int accumulate;
-  __device__ void operator()(int row, int col, float v) const {
+  __device__ void apply4(int row, int col, vf4 v) const {
     const size_t o = (size_t)row * Ep + col;
-    if (col < pe) ge[o] = accumulate ? ge[o] + v : v;
-    else ge[o] = 0.f;
+    vf4 g = accumulate ? ld4(ge + o) : make_vf4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) g[c] = col + c < pe ? g[c] + v[c] : 0.f;
+    st4(ge + o, g);
   }
 };
-// RA layer l: gzb = acc ; zR_l = 100 gzb gz_l E ; u_{l+1} = gzb D  (PE-adjoint override when feeding the skip)
+// RA layer l: gzb = acc ; zR_l = 100 gzb gz_l (1 - D_l) ; u_{l+1} = gzb D_l  (PE-adjoint override when
+// feeding the skip layer)
 struct EpiRA {
-  const float* a;
+  const float* D;
   const float* gz;
   float* zR;
   float* u_next;
@@ -348,22 +387,28 @@ struct EpiRA {
   int n_real;
   const float* geb;  // nullptr unless this layer feeds the skip layer
   int Ep, pe;
-  __device__ void operator()(int row, int col, float v) const {
+  __device__ void apply4(int row, int col, vf4 v) const {
     const size_t o = (size_t)row * ld + col;
-    if (col < n_real) {
-      float D, E;
-      softplus_DE(a[o], D, E);
-      zR[o] = 100.f * v * gz[o] * E;
-      u_next[o] = v * D;
-    } else {
-      zR[o] = 0.f;
-      u_next[o] = (geb != nullptr && col < n_real + pe) ? geb[(size_t)row * Ep + (col - n_real)] : 0.f;
+    const vf4 Dv = ld4(D + o), gzv = ld4(gz + o);
+    vf4 zr, un;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int cc = col + c;
+      if (cc < n_real) {
+        zr[c] = 100.f * v[c] * gzv[c] * (1.f - Dv[c]);
+        un[c] = v[c] * Dv[c];
+      } else {
+        zr[c] = 0.f;
+        un[c] = (geb != nullptr && cc < n_real + pe) ? geb[(size_t)row * Ep + (cc - n_real)] : 0.f;
+      }
     }
+    st4(zR + o, zr);
+    st4(u_next + o, un);
   }
 };
-// FB: zb_{l-1} = (acc [+ sbar/scale * w_sdf]) * D(a_{l-1}) + zR_{l-1}
+// FB: zb_{l-1} = (acc [+ sbar/scale * w_sdf]) * D_{l-1} + zR_{l-1}
 struct EpiFB {
-  const float* a_prev;
+  const float* D_prev;
   const float* zR_prev;
   float* zb_prev;
   int ld;
@@ -371,14 +416,19 @@ struct EpiFB {
   const float* sbar;   // only for the head step
   const float* wsdf;
   float inv_scale;
-  __device__ void operator()(int row, int col, float v) const {
+  __device__ void apply4(int row, int col, vf4 v) const {
     const size_t o = (size_t)row * ld + col;
-    if (col < n_real) {
-      if (sbar != nullptr) v = fmaf(sbar[row] * inv_scale, wsdf[col], v);
-      zb_prev[o] = fmaf(v, softplus_D(a_prev[o]), zR_prev[o]);
-    } else {
-      zb_prev[o] = 0.f;
+    const vf4 Dv = ld4(D_prev + o), zr = ld4(zR_prev + o);
+    if (sbar != nullptr) {
+      const float sb = sbar[row] * inv_scale;
+      const vf4 w = ld4(wsdf + col);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[c] = fmaf(sb, w[c], v[c]);
     }
+    vf4 zb;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) zb[c] = col + c < n_real ? fmaf(v[c], Dv[c], zr[c]) : 0.f;
+    st4(zb_prev + o, zb);
   }
 };
 // albedo backward through a relu layer: zc_{l-1} = acc * (ac_{l-1} > 0)
@@ -387,15 +437,19 @@ struct EpiReluMask {
   float* out;
   int ld;
   int n_real;
-  __device__ void operator()(int row, int col, float v) const {
+  __device__ void apply4(int row, int col, vf4 v) const {
     const size_t o = (size_t)row * ld + col;
-    out[o] = (col < n_real && ac_prev[o] > 0.f) ? v : 0.f;
+    const vf4 a = ld4(ac_prev + o);
+    vf4 r;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) r[c] = (col + c < n_real && a[c] > 0.f) ? v[c] : 0.f;
+    st4(out + o, r);
   }
 };
 struct EpiStore {
   float* out;
   int ld;
-  __device__ void operator()(int row, int col, float v) const { out[(size_t)row * ld + col] = v; }
+  __device__ void apply4(int row, int col, vf4 v) const { st4(out + (size_t)row * ld + col, v); }
 };
 
 // =====================================================================================================
@@ -410,10 +464,16 @@ static int launch_rows(const float* A, int lda, const float* W, int ldw, int64_t
   ProfScope prof(flops, s);
   if (N >= 256) {   // 128 x 256 tiles: the 256-wide layers of the full model run as one wave of 2 blocks / CU
     dim3 grid((unsigned)(Mp / BM), (unsigned)((N + 255) / 256));
-    hipLaunchKernelGGL((gemm_rows_kernel<B_KMAJOR, 256, Epi>), grid, dim3(256), 0, s, A, lda, W, ldw, N, K, epi);
+    if (N % 256 == 0)
+      hipLaunchKernelGGL((gemm_rows_kernel<B_KMAJOR, 256, false, Epi>), grid, dim3(256), 0, s, A, lda, W, ldw, N, K, epi);
+    else
+      hipLaunchKernelGGL((gemm_rows_kernel<B_KMAJOR, 256, true, Epi>), grid, dim3(256), 0, s, A, lda, W, ldw, N, K, epi);
   } else {
     dim3 grid((unsigned)(Mp / BM), (unsigned)((N + 127) / 128));
-    hipLaunchKernelGGL((gemm_rows_kernel<B_KMAJOR, 128, Epi>), grid, dim3(256), 0, s, A, lda, W, ldw, N, K, epi);
+    if (N % 128 == 0)
+      hipLaunchKernelGGL((gemm_rows_kernel<B_KMAJOR, 128, false, Epi>), grid, dim3(256), 0, s, A, lda, W, ldw, N, K, epi);
+    else
+      hipLaunchKernelGGL((gemm_rows_kernel<B_KMAJOR, 128, true, Epi>), grid, dim3(256), 0, s, A, lda, W, ldw, N, K, epi);
   }
   RNB_CHECK_LAUNCH();
   return RNB_OK;
@@ -431,8 +491,12 @@ static int launch_dw(DwPair p1, DwPair p2, int npairs, int64_t M, int N, int K, 
   splits = (int)((M + rows - 1) / rows);
   dim3 grid((unsigned)((N + 127) / 128), (unsigned)((K + 127) / 128), (unsigned)splits);
   ProfScope prof(flops, s);
-  hipLaunchKernelGGL(gemm_dw_kernel, grid, dim3(256), 0, s, p1, p2, npairs, (int)M, N, K, rows, dW, lddw, db,
-                     bias_pair);
+  if (N % 128 == 0 && K % 128 == 0 && M % BK == 0)
+    hipLaunchKernelGGL(gemm_dw_kernel<false>, grid, dim3(256), 0, s, p1, p2, npairs, (int)M, N, K, rows, dW, lddw,
+                       db, bias_pair);
+  else
+    hipLaunchKernelGGL(gemm_dw_kernel<true>, grid, dim3(256), 0, s, p1, p2, npairs, (int)M, N, K, rows, dW, lddw,
+                       db, bias_pair);
   RNB_CHECK_LAUNCH();
   return RNB_OK;
 }
@@ -465,11 +529,11 @@ int sweep_forward(const Layout& L, const float* packed, PointBufs& pb, bool need
     const Lin& ln = L.hid[l];
     const float* in = l == 0 ? pb.e : pb.a[l - 1];
     const int lda = l == 0 ? L.Ep : L.Hp;
-    EpiF epi{packed + ln.b_off, pb.a[l], L.Hp, ln.N, (l + 1 == L.skip) ? pb.e : nullptr, L.Ep, L.pe};
+    EpiF epi{packed + ln.b_off, pb.a[l], pb.D[l], L.Hp, ln.N, (l + 1 == L.skip) ? pb.e : nullptr, L.Ep, L.pe};
     RNB_TRY((launch_rows<false, EpiF>(in, lda, packed + ln.w_off, ln.Kp, pb.Mp, ln.Np, ln.Kp, epi, mm_flops(pb.M, ln), s)));
   }
-  hipLaunchKernelGGL(sdf_head_kernel, dim3(blocks_for(pb.Mp * 32, 256)), dim3(256), 0, s, pb.a[L.nh - 1], L.Hp, L.H,
-                     packed + L.wsdf_off, packed + L.bsdf_off, 1.f / L.sdf_scale, pb.Mp, pb.sdf,
+  hipLaunchKernelGGL(sdf_head_kernel, dim3(blocks_for(pb.Mp * 32, 256)), dim3(256), 0, s, pb.a[L.nh - 1],
+                     pb.D[L.nh - 1], L.Hp, L.H, packed + L.wsdf_off, packed + L.bsdf_off, 1.f / L.sdf_scale, pb.Mp, pb.sdf,
                      need_gz_last ? pb.gz[L.nh - 1] : nullptr);
   RNB_CHECK_LAUNCH();
   if (need_feat) {
@@ -488,7 +552,7 @@ int sweep_reverse(const Layout& L, const float* packed, PointBufs& pb, hipStream
   for (int l = L.nh - 1; l >= 1; --l) {
     const Lin& ln = L.hid[l];
     const bool is_skip = (l == L.skip);
-    EpiR epi{pb.a[l - 1], pb.gz[l - 1], L.Hp, is_skip ? ln.K - L.pe : ln.K, is_skip ? pb.ge : nullptr, L.Ep, L.pe};
+    EpiR epi{pb.D[l - 1], pb.gz[l - 1], L.Hp, is_skip ? ln.K - L.pe : ln.K, is_skip ? pb.ge : nullptr, L.Ep, L.pe};
     RNB_TRY((launch_rows<true, EpiR>(pb.gz[l], L.Hp, packed + ln.w_off, ln.Kp, pb.Mp, ln.Kp, ln.Np, epi, mm_flops(pb.M, ln), s)));
   }
   {
@@ -557,7 +621,7 @@ int sweep_backward(const Layout& L, const float* packed, PointBufs& pb, bool wit
     const Lin& ln = L.hid[l];
     const float* in = l == 0 ? pb.geb : pb.u[l];
     const int lda = l == 0 ? L.Ep : L.Hp;
-    EpiRA epi{pb.a[l], pb.gz[l], pb.zR[l], pb.u[l + 1], L.Hp, ln.N, (l + 1 == L.skip) ? pb.geb : nullptr, L.Ep, L.pe};
+    EpiRA epi{pb.D[l], pb.gz[l], pb.zR[l], pb.u[l + 1], L.Hp, ln.N, (l + 1 == L.skip) ? pb.geb : nullptr, L.Ep, L.pe};
     RNB_TRY((launch_rows<false, EpiRA>(in, lda, packed + ln.w_off, ln.Kp, Mp, ln.Np, ln.Kp, epi, mm_flops(M, ln), s)));
   }
   // ---- sdf-head row gradient ---------------------------------------------------------------------
@@ -570,7 +634,7 @@ int sweep_backward(const Layout& L, const float* packed, PointBufs& pb, bool wit
   }
   // ---- FB head: zb_{nh-1} = (fbar Wf + sbar/scale w_sdf) * D + zR ----------------------------------
   {
-    EpiFB epi{pb.a[L.nh - 1], pb.zR[L.nh - 1], pb.zb[L.nh - 1], L.Hp, L.hid[L.nh - 1].N, pb.sbar,
+    EpiFB epi{pb.D[L.nh - 1], pb.zR[L.nh - 1], pb.zb[L.nh - 1], L.Hp, L.hid[L.nh - 1].N, pb.sbar,
               packed + L.wsdf_off, 1.f / L.sdf_scale};
     const int K = with_color ? L.feat.Np : 0;   // no_albedo: fbar == 0, the GEMM degenerates to its epilogue
     RNB_TRY((launch_rows<true, EpiFB>(pb.cinb, L.Cinp, packed + L.feat.w_off, L.feat.Kp, Mp, L.feat.Kp, K, epi,
@@ -593,7 +657,7 @@ int sweep_backward(const Layout& L, const float* packed, PointBufs& pb, bool wit
                       2.0 * mm_flops(M, ln), s));
     if (l > 0) {
       const Lin& lp = L.hid[l - 1];
-      EpiFB epi{pb.a[l - 1], pb.zR[l - 1], pb.zb[l - 1], L.Hp, lp.N, nullptr, nullptr, 1.f};
+      EpiFB epi{pb.D[l - 1], pb.zR[l - 1], pb.zb[l - 1], L.Hp, lp.N, nullptr, nullptr, 1.f};
       RNB_TRY((launch_rows<true, EpiFB>(pb.zb[l], L.Hp, packed + ln.w_off, ln.Kp, Mp, ln.Kp, ln.Np, epi, mm_flops(M, ln), s)));
     }
   }

@@ -95,6 +95,7 @@ struct PointBufs {
   float* x;       // [Mp,4]   scaled points (x,y,z,0)
   float* e;       // [Mp,Ep]  positional encoding
   float* a[RNB_MAX_LIN];   // hidden activations a_l  [Mp,Hp]
+  float* D[RNB_MAX_LIN];   // softplus'(z_l) = sigmoid(100 z_l)  [Mp,Hp]   (only with_normal; else nullptr)
   float* gz[RNB_MAX_LIN];  // reverse sweep state gz_l  [Mp,Hp]   (only with_normal)
   float* ge;      // [Mp,Ep]  d sdf / d e
   float* sdf;     // [Mp]

@@ -267,14 +267,22 @@ def test_full_batch_512_matches_oracle(R):
     named = {("sdf." + k): v for k, v in sdf.named_parameters()}
     named["dev.variance"] = dev.variance
     named.update({("color." + k): v for k, v in col.named_parameters()})
-    worst = ("", 0.0)
+    # the same step with the oracle in fp32 (the reference's own arithmetic) calibrates how well each
+    # gradient is conditioned: e.g. d loss / d (sdf bias) is a sum of 65,536 cancelling terms
+    p32 = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    ref32 = O.render_rnb(p32, mc, batch["rays_o"], batch["rays_d"], batch["near"], batch["far"],
+                         batch["lights_dir"], cos_anneal_ratio=1.0, z_vals=z)
+    O.rnb_loss(ref32, batch["true_rgb"], batch["mask"])[0].backward()
+    worst = ("", 0.0, 0.0)
     for k, v in named.items():
         rg = pr[k].grad
-        rel = float((v.grad.cpu().double() - rg).norm() / rg.norm().clamp_min(1e-20))
+        den = rg.norm().clamp_min(1e-20)
+        rel = float((v.grad.cpu().double() - rg).norm() / den)
+        rel32 = float((p32[k].grad.double() - rg).norm() / den)
         if rel > worst[1]:
-            worst = (k, rel)
-        assert rel < 1e-3, f"{k}: rel-L2 {rel:.3e}"
-    print(f"B=512 vs fp64 oracle: worst gradient rel-L2 = {worst[1]:.2e} ({worst[0]})")
+            worst = (k, rel, rel32)
+        assert rel < max(1e-3, 3.0 * rel32), f"{k}: rel-L2 {rel:.3e} (fp32 CPU oracle: {rel32:.3e})"
+    print(f"B=512 vs fp64 oracle: worst gradient rel-L2 = {worst[1]:.2e} ({worst[0]}; fp32 CPU oracle {worst[2]:.2e})")
 
 
 def test_size_independent_properties(R):
