@@ -1,4 +1,6 @@
 // C-ABI entry points of librnbneus_hip.so (declared in include/rnbneus.h).
+#include <stdlib.h>
+
 #include "rnb_internal.h"
 
 using namespace rnb;
@@ -62,6 +64,23 @@ static int points_setup(const rnb_model_desc* desc, int64_t n, void* ws, size_t 
   return RNB_OK;
 }
 
+// positional encoding + forward sweep: fused single-launch kernel for the 256-wide network, generic
+// per-layer GEMM chain otherwise.  RNB_NO_FUSED=1 in the environment forces the generic path (A/B testing).
+static bool use_fused(const Layout& L) {
+  static const bool disabled = getenv("RNB_NO_FUSED") != nullptr;
+  return !disabled && fused_supported(L);
+}
+static int forward_points(const Layout& L, const float* packed, const float* pts, int64_t n, PointBufs& pb,
+                          bool save, bool need_feat, bool need_gz_last, float* feat_dense, hipStream_t s) {
+  if (use_fused(L)) {
+    RNB_TRY(fused_forward(L, packed, pts, n, pb, save, need_feat, need_gz_last, s));
+    if (need_feat && feat_dense) RNB_TRY(launch_copy_cols(pb.cin, L.Cinp, L.F, n, feat_dense, s));
+    return RNB_OK;
+  }
+  RNB_TRY(launch_pe_points(L, pts, n, pb, s));
+  return sweep_forward(L, packed, pb, need_feat, need_gz_last, feat_dense, s);
+}
+
 RNB_API int rnb_sdf_forward(const rnb_model_desc* desc, const float* packed, const float* pts, int64_t n,
                             float* sdf_out, float* feat_out, void* ws, size_t ws_bytes, rnb_stream_t stream) {
   RNB_REQUIRE(packed, "packed");
@@ -72,8 +91,7 @@ RNB_API int rnb_sdf_forward(const rnb_model_desc* desc, const float* packed, con
   Layout L;
   PointBufs pb;
   RNB_TRY(points_setup(desc, n, ws, ws_bytes, &L, &pb));
-  RNB_TRY(launch_pe_points(L, pts, n, pb, s));
-  RNB_TRY(sweep_forward(L, packed, pb, feat_out != nullptr, false, feat_out, s));
+  RNB_TRY(forward_points(L, packed, pts, n, pb, false, feat_out != nullptr, false, feat_out, s));
   RNB_CHECK_HIP(hipMemcpyAsync(sdf_out, pb.sdf, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, s));
   return RNB_OK;
 }
@@ -88,8 +106,7 @@ RNB_API int rnb_sdf_gradient(const rnb_model_desc* desc, const float* packed, co
   Layout L;
   PointBufs pb;
   RNB_TRY(points_setup(desc, n, ws, ws_bytes, &L, &pb));
-  RNB_TRY(launch_pe_points(L, pts, n, pb, s));
-  RNB_TRY(sweep_forward(L, packed, pb, false, true, nullptr, s));
+  RNB_TRY(forward_points(L, packed, pts, n, pb, true, false, true, nullptr, s));
   RNB_TRY(sweep_reverse(L, packed, pb, s));
   RNB_TRY(launch_copy_cols(pb.nrm, 4, 3, n, grad_out, s));
   if (sdf_out) RNB_CHECK_HIP(hipMemcpyAsync(sdf_out, pb.sdf, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -212,8 +229,7 @@ RNB_API int rnb_sample_rays(const rnb_model_desc* desc, const float* packed, con
   const int n_new = desc->n_importance / steps;
 
   RNB_TRY(launch_z_init(rays_o, rays_d, near, far, t_rand, B, n0, sb.z[0], sb.pts, s));
-  RNB_TRY(launch_pe_points(L, sb.pts, B * n0, sb.pb, s));
-  RNB_TRY(sweep_forward(L, packed, sb.pb, false, false, nullptr, s));
+  RNB_TRY(forward_points(L, packed, sb.pts, B * n0, sb.pb, false, false, false, nullptr, s));
   RNB_CHECK_HIP(hipMemcpyAsync(sb.sdf[0], sb.pb.sdf, (size_t)B * n0 * sizeof(float), hipMemcpyDeviceToDevice, s));
   int cur = 0;
   int n = n0;
@@ -228,8 +244,7 @@ RNB_API int rnb_sample_rays(const rnb_model_desc* desc, const float* packed, con
       Carver c2((char*)ws + sb.pb_off, ws_bytes - sb.pb_off);
       PointBufs pbn;
       carve_points(L, c2, B * n_new, PM_SDF_ONLY, &pbn);
-      RNB_TRY(launch_pe_points(L, sb.pts, B * n_new, pbn, s));
-      RNB_TRY(sweep_forward(L, packed, pbn, false, false, nullptr, s));
+      RNB_TRY(forward_points(L, packed, sb.pts, B * n_new, pbn, false, false, false, nullptr, s));
       RNB_TRY(launch_gather_sdf(sb.sdf[cur], pbn.sdf, sb.index, B, n, n_new, sb.sdf[cur ^ 1], s));
     }
     cur ^= 1;
@@ -353,8 +368,7 @@ RNB_API int rnb_render_fwd(const rnb_model_desc* desc, const float* packed, cons
   const bool use_color = (mode & PM_WITH_COLOR) != 0;
   RNB_TRY(launch_fine_points(a->rays_o, a->rays_d, a->z_vals, a->B, a->S, 2.0f / (float)desc->n_samples, rb.pts,
                              rb.dists, s));
-  RNB_TRY(launch_pe_points(L, rb.pts, a->B * a->S, rb.pb, s));
-  RNB_TRY(sweep_forward(L, packed, rb.pb, use_color, true, nullptr, s));
+  RNB_TRY(forward_points(L, packed, rb.pts, a->B * a->S, rb.pb, true, use_color, true, nullptr, s));
   RNB_TRY(sweep_reverse(L, packed, rb.pb, s));
   if (use_color) RNB_TRY(sweep_color(L, packed, rb.pb, rb.pts, rb.pb.nrm, 4, s));
   CompArgs c = comp_args_of(L, a, rb);

@@ -1,0 +1,270 @@
+// Fused SDF-network sweeps for the shipped network shape (hidden width 256): one workgroup carries a tile
+// of 64 points through ALL layers.  Activations stay in LDS between layers, weights stream from L2
+// straight into MFMA B-fragments (each 128-byte weight line is fetched once per workgroup and consumed by
+// four back-to-back 16-byte loads), and what the backward pass needs is written to HBM with fire-and-forget
+// stores that overlap the next layer's matrix work.  Replaces, per sweep, the chain of per-layer GEMM
+// launches of mlp.hip (which remain the generic path for other widths).
+//
+//   fused_forward_kernel   positional encoding + F sweep (+ sdf head, + feature head)
+//                          models/embedder.py:40-46, models/fields.py:82-104
+#include "gemm.hip.h"
+#include "rnb_internal.h"
+
+namespace rnb {
+
+constexpr int FT = 64;        // points per workgroup
+constexpr int FH = 256;       // hidden width of the fused path
+constexpr int FP = FH + 4;    // LDS pitch of the activation tile
+constexpr int FEP = 40;       // LDS pitch of the positional-encoding copy kept for the skip connection
+
+struct FusedFwdArgs {
+  const float* pts;     // [M,3]
+  int64_t M;
+  const float* packed;
+  int nh, skip, pe, multires, Ep;
+  float scale;
+  int n_real[RNB_MAX_LIN];
+  int Kp[RNB_MAX_LIN];
+  long long w_off[RNB_MAX_LIN], b_off[RNB_MAX_LIN];
+  long long wsdf_off, bsdf_off;
+  int with_feat, F, Cinp;
+  long long wf_off, bf_off;
+  float* cin;           // [Mp,Cinp] feature block destination (with_feat)
+  float* sdf;           // [Mp]
+  // saved state (SAVE only)
+  float* x4;            // [Mp,4]
+  float* e;             // [Mp,Ep]
+  float* a[RNB_MAX_LIN];
+  float* D[RNB_MAX_LIN];
+  float* gz_last;       // [Mp,256] seed of the reverse sweep: w_sdf * D_last (optional)
+};
+
+// One 64 x 64 output block per wave: C[64 rows][n0..n0+63] = X[64][K] * W[n][K]^T, K a multiple of 32.
+// k-permutation inside each 32-k block: lane half h takes k = 32Q + 16h + 4q + c, so every lane streams 64
+// contiguous bytes of its weight row per block.
+__device__ inline void load_b_block(const float* __restrict__ W, int K, int n0, int Q, int lane, vf4 (&b)[2][4]) {
+  const int j = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int tj = 0; tj < 2; ++tj) {
+    const float* p = W + (size_t)(n0 + tj * 32 + j) * K + Q * 32 + h * 16;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) b[tj][q] = *reinterpret_cast<const vf4*>(p + q * 4);
+  }
+}
+
+__device__ inline void layer_mma_nt(const float* __restrict__ X, const float* __restrict__ W, int K, int n0, int lane,
+                                    v16f (&acc)[2][2]) {
+  const int i = lane & 31, h = lane >> 5;
+  const int nQ = K / 32;
+  vf4 bn[2][4];
+  load_b_block(W, K, n0, 0, lane, bn);
+  for (int Q = 0; Q < nQ; ++Q) {
+    vf4 b[2][4];
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) b[tj][q] = bn[tj][q];
+    if (Q + 1 < nQ) load_b_block(W, K, n0, Q + 1, lane, bn);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const vf4 a0 = *reinterpret_cast<const vf4*>(X + i * FP + Q * 32 + h * 16 + q * 4);
+      const vf4 a1 = *reinterpret_cast<const vf4*>(X + (32 + i) * FP + Q * 32 + h * 16 + q * 4);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[c], b[0][q][c], acc[0][0], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[c], b[0][q][c], acc[1][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[c], b[1][q][c], acc[0][1], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[c], b[1][q][c], acc[1][1], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+template <bool SAVE>
+__global__ __launch_bounds__(256, 2) void fused_forward_kernel(FusedFwdArgs g) {
+  __shared__ __attribute__((aligned(16))) float lds[FT * FP + FT * FEP];
+  float* X = lds;
+  float* E = lds + FT * FP;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = wave_id();
+  const int64_t row0 = (int64_t)blockIdx.x * FT;
+  const int n0 = wave * 64;
+
+  // ---- positional encoding of the tile: X[:, 0:Ep] = [x, sin(2^k x), cos(2^k x)], zero padded -------
+  {
+    const int p = tid & 63, part = tid >> 6;
+    const int64_t row = row0 + p;
+    float x[3] = {0.f, 0.f, 0.f};
+    if (row < g.M) {
+      x[0] = g.pts[row * 3] * g.scale;
+      x[1] = g.pts[row * 3 + 1] * g.scale;
+      x[2] = g.pts[row * 3 + 2] * g.scale;
+    }
+    float* xr = X + p * FP;
+    float* er = E + p * FEP;
+    if (part == 0) {
+      xr[0] = x[0]; xr[1] = x[1]; xr[2] = x[2];
+      er[0] = x[0]; er[1] = x[1]; er[2] = x[2];
+      for (int c = g.pe; c < g.Ep; ++c) xr[c] = 0.f;
+      if (SAVE) {
+        g.x4[row * 4] = x[0]; g.x4[row * 4 + 1] = x[1]; g.x4[row * 4 + 2] = x[2]; g.x4[row * 4 + 3] = 0.f;
+      }
+    }
+    for (int k = part; k < g.multires; k += 4) {
+      const float f = (float)(1 << k);
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        float s, co;
+        sincosf(x[d] * f, &s, &co);
+        const int c = 3 + 6 * k + d;
+        xr[c] = s; xr[c + 3] = co;
+        er[c] = s; er[c + 3] = co;
+      }
+    }
+  }
+  __syncthreads();
+  if (SAVE) {   // e is an operand of the backward (dW of layer 0) and of the R sweep: 64 x Ep floats
+    for (int idx = tid; idx < FT * g.Ep; idx += 256) {
+      const int r = idx / g.Ep, c = idx - r * g.Ep;
+      g.e[(row0 + r) * g.Ep + c] = X[r * FP + c];
+    }
+  }
+
+  const int h = lane >> 5, cl = lane & 31;
+  v16f acc[2][2];
+  for (int l = 0; l < g.nh; ++l) {
+    zero_acc<2>(acc);
+    layer_mma_nt(X, g.packed + g.w_off[l], g.Kp[l], n0, lane, acc);
+    __syncthreads();   // every wave has finished reading the input activations
+    const float* bias = g.packed + g.b_off[l];
+    const int n_real = g.n_real[l];
+    const bool pe_tail = (l + 1 == g.skip);
+    const bool last = (l + 1 == g.nh);
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj) {
+      const int col = n0 + tj * 32 + cl;
+      const float bc = bias[col];
+      const float ws = (SAVE && last && g.gz_last) ? g.packed[g.wsdf_off + col] : 0.f;
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          float a, D;
+          if (col < n_real) softplus_aD(acc[ti][tj][r] + bc, a, D);
+          else {
+            a = (pe_tail && col < n_real + g.pe) ? E[row * FEP + (col - n_real)] : 0.f;
+            D = 0.f;
+          }
+          X[row * FP + col] = a;
+          if (SAVE) {
+            const size_t o = (size_t)(row0 + row) * FH + col;
+            g.a[l][o] = a;
+            g.D[l][o] = D;
+            if (last && g.gz_last) g.gz_last[o] = ws * D;
+          }
+        }
+      }
+    }
+    __syncthreads();   // the new activations are visible to every wave
+  }
+
+  // ---- sdf head: row 0 of the output layer (models/fields.py:104, :106-108) -----------------------------
+  {
+    const float* ws = g.packed + g.wsdf_off;
+    float w[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) w[u] = ws[lane + 64 * u];
+    const float bs = g.packed[g.bsdf_off];
+    for (int rr = 0; rr < 16; ++rr) {
+      const int row = wave * 16 + rr;
+      float s = 0.f;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s = fmaf(X[row * FP + lane + 64 * u], w[u], s);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+      if (lane == 0) g.sdf[row0 + row] = (s + bs) / g.scale;
+    }
+  }
+  // ---- feature head: rows 1.. of the output layer, written into the albedo network's input ------------
+  if (g.with_feat) {
+    zero_acc<2>(acc);
+    layer_mma_nt(X, g.packed + g.wf_off, FH, n0, lane, acc);
+    const float* bias = g.packed + g.bf_off;
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj) {
+      const int col = n0 + tj * 32 + cl;
+      if (col < g.F) {
+        const float bc = bias[col];
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            g.cin[(size_t)(row0 + row) * g.Cinp + col] = acc[ti][tj][r] + bc;
+          }
+        }
+      }
+    }
+  }
+}
+
+bool fused_supported(const Layout& L) {
+  if (L.Hp != FH || L.H != FH) return false;
+  if (L.Ep > 64 || L.pe > FEP) return false;
+  if (L.nh < 1) return false;
+  for (int l = 0; l < L.nh; ++l)
+    if (L.hid[l].Np != FH || (L.hid[l].Kp != FH && l != 0)) return false;
+  if (L.F > FH) return false;
+  return true;
+}
+
+// Fused replacement of launch_pe_points + sweep_forward (same outputs; pb.a / pb.D only when `save`).
+int fused_forward(const Layout& L, const float* packed, const float* pts, int64_t M, PointBufs& pb, bool save,
+                  bool need_feat, bool need_gz_last, hipStream_t s) {
+  FusedFwdArgs g;
+  memset(&g, 0, sizeof(g));
+  g.pts = pts;
+  g.M = M;
+  g.packed = packed;
+  g.nh = L.nh;
+  g.skip = L.skip;
+  g.pe = L.pe;
+  g.multires = L.multires;
+  g.Ep = L.Ep;
+  g.scale = L.sdf_scale;
+  for (int l = 0; l < L.nh; ++l) {
+    g.n_real[l] = L.hid[l].N;
+    g.Kp[l] = L.hid[l].Kp;
+    g.w_off[l] = L.hid[l].w_off;
+    g.b_off[l] = L.hid[l].b_off;
+    g.a[l] = pb.a[l];
+    g.D[l] = pb.D[l];
+  }
+  g.wsdf_off = L.wsdf_off;
+  g.bsdf_off = L.bsdf_off;
+  g.with_feat = need_feat ? 1 : 0;
+  g.F = L.F;
+  g.Cinp = L.Cinp;
+  g.wf_off = L.feat.w_off;
+  g.bf_off = L.feat.b_off;
+  g.cin = pb.cin;
+  g.sdf = pb.sdf;
+  g.x4 = pb.x;
+  g.e = pb.e;
+  g.gz_last = need_gz_last ? pb.gz[L.nh - 1] : nullptr;
+  const unsigned blocks = (unsigned)(pb.Mp / FT);
+  // algorithmic FLOPs of the sweep (real layer shapes), for the optional event instrumentation
+  double fl = 0;
+  for (int l = 0; l < L.nh; ++l) fl += 2.0 * (double)M * L.hid[l].N * L.hid[l].K;
+  fl += 2.0 * (double)M * L.H;
+  if (need_feat) fl += 2.0 * (double)M * L.F * L.H;
+  ProfScope prof(fl, s);
+  if (save) hipLaunchKernelGGL(fused_forward_kernel<true>, dim3(blocks), dim3(256), 0, s, g);
+  else hipLaunchKernelGGL(fused_forward_kernel<false>, dim3(blocks), dim3(256), 0, s, g);
+  RNB_CHECK_LAUNCH();
+  return RNB_OK;
+}
+
+}  // namespace rnb

@@ -130,6 +130,11 @@ int launch_fill_cols(const float* src, int ncols, int64_t M, int64_t Mp, int ld,
 int sweep_backward(const Layout& L, const float* packed, PointBufs& pb, bool with_color, float* packed_grad,
                    hipStream_t s);
 
+// ---- fused sweeps for hidden width 256 (fused.hip) ---------------------------------------------------
+bool fused_supported(const Layout& L);
+int fused_forward(const Layout& L, const float* packed, const float* pts, int64_t M, PointBufs& pb, bool save,
+                  bool need_feat, bool need_gz_last, hipStream_t s);
+
 // ---- sampling / composite ------------------------------------------------------------------------
 int launch_up_sample_step(const float* rays_o, const float* rays_d, const float* z_in, const float* sdf_old,
                           const float* sdf_new, const int32_t* gather_index, int n_old_for_gather,
