@@ -146,14 +146,15 @@ __global__ __launch_bounds__(256, 2) void fused_forward_kernel(FusedFwdArgs g) {
       const int col = n0 + tj * 32 + cl;
       const float bc = bias[col];
       const float ws = (SAVE && last && g.gz_last) ? g.packed[g.wsdf_off + col] : 0.f;
+      const bool tile_full = n0 + tj * 32 + 32 <= n_real;   // wave-uniform: no per-element column checks
 #pragma unroll
       for (int ti = 0; ti < 2; ++ti) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
           float a, D;
-          if (col < n_real) softplus_aD(acc[ti][tj][r] + bc, a, D);
-          else {
+          softplus_aD(acc[ti][tj][r] + bc, a, D);
+          if (!tile_full && col >= n_real) {   // only the tile straddling the skip connection's PE columns
             a = (pe_tail && col < n_real + g.pe) ? E[row * FEP + (col - n_real)] : 0.f;
             D = 0.f;
           }

@@ -345,9 +345,9 @@ __device__ inline float softplus100(float z) {
 // Cody-Waite reduction (|rel err| ~ 1 ulp for t <= 20), log1p(e) = log(u) * e / (u - 1) with u = fl(1 + e)
 // (the classic rounding-compensated form; hardware log2).  ~20 VALU instructions per element.
 __device__ inline void softplus_aD(float z, float& a, float& D) {
+  // branch-free (selects only): the epilogues run this 64x per lane next to the matrix pipe
   const float t = z * 100.f;
-  if (t > 20.f) { a = z; D = 1.f; return; }
-  const float tc = fmaxf(t, -87.f);
+  const float tc = fminf(fmaxf(t, -87.f), 20.f);
   const float n = rintf(tc * 1.44269504088896341f);
   // tc - n ln2 with ln2 = hi + lo, hi = fl(ln2) = 0.693147182464599609375, lo = -1.904654299957768e-9
   const float r = fmaf(n, 1.90465429995776804e-09f, fmaf(n, -0.693147182464599609375f, tc));
@@ -355,9 +355,11 @@ __device__ inline void softplus_aD(float z, float& a, float& D) {
   const float u = 1.f + e;
   const float um1 = u - 1.f;
   const float lg = __builtin_amdgcn_logf(u) * 0.693147180559945309f;
-  const float l1p = um1 == 0.f ? e : lg * (e / um1);
-  a = l1p * 0.01f;
-  D = e / u;
+  const float corr = e * __builtin_amdgcn_rcpf(um1 == 0.f ? 1.f : um1);   // e / (u - 1): rounding of 1 + e
+  const float l1p = um1 == 0.f ? e : lg * corr;
+  const bool lin = t > 20.f;
+  a = lin ? z : l1p * 0.01f;
+  D = lin ? 1.f : e * __builtin_amdgcn_rcpf(u);
 }
 // D = d softplus / dz = sigmoid(100 z) expressed through a = softplus(z):  D = 1 - exp(-100 a)
 // (exactly 1 above the threshold, where a == z); E = 1 - D, and softplus'' = 100 D E.
