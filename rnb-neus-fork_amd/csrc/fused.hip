@@ -1,5 +1,5 @@
 // Fused SDF-network sweeps for the shipped network shape (hidden width 256): one workgroup carries a tile
-// of 64 points through ALL layers.  Activations stay in LDS between layers, weights stream from L2
+// of 64 (or 32) points through ALL layers.  Activations stay in LDS between layers, weights stream from L2
 // straight into MFMA B-fragments (each 128-byte weight line is fetched once per workgroup and consumed by
 // four back-to-back 16-byte loads), and what the backward pass needs is written to HBM with fire-and-forget
 // stores that overlap the next layer's matrix work.  Replaces, per sweep, the chain of per-layer GEMM
@@ -12,7 +12,6 @@
 
 namespace rnb {
 
-constexpr int FT = 64;        // points per workgroup
 constexpr int FH = 256;       // hidden width of the fused path
 constexpr int FP = FH + 4;    // LDS pitch of the activation tile
 constexpr int FEP = 40;       // LDS pitch of the positional-encoding copy kept for the skip connection
@@ -39,7 +38,11 @@ struct FusedFwdArgs {
   float* gz_last;       // [Mp,256] seed of the reverse sweep: w_sdf * D_last (optional)
 };
 
-// One 64 x 64 output block per wave: C[64 rows][n0..n0+63] = X[64][K] * W[n][K]^T, K a multiple of 32.
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory counter,
+// i.e. it would wait for the fire-and-forget global stores of the previous epilogue to reach memory.
+__device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// One (32*TI) x 64 output block per wave: C[rows][n0..n0+63] = X[rows][K] * W[n][K]^T, K a multiple of 32.
 // k-permutation inside each 32-k block: lane half h takes k = 32Q + 16h + 4q + c, so every lane streams 64
 // contiguous bytes of its weight row per block.
 __device__ inline void load_b_block(const float* __restrict__ W, int K, int n0, int Q, int lane, vf4 (&b)[2][4]) {
@@ -52,8 +55,9 @@ __device__ inline void load_b_block(const float* __restrict__ W, int K, int n0, 
   }
 }
 
+template <int TI>
 __device__ inline void layer_mma_nt(const float* __restrict__ X, const float* __restrict__ W, int K, int n0, int lane,
-                                    v16f (&acc)[2][2]) {
+                                    v16f (&acc)[TI][2]) {
   const int i = lane & 31, h = lane >> 5;
   const int nQ = K / 32;
   vf4 bn[2][4];
@@ -67,22 +71,38 @@ __device__ inline void layer_mma_nt(const float* __restrict__ X, const float* __
     if (Q + 1 < nQ) load_b_block(W, K, n0, Q + 1, lane, bn);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const vf4 a0 = *reinterpret_cast<const vf4*>(X + i * FP + Q * 32 + h * 16 + q * 4);
-      const vf4 a1 = *reinterpret_cast<const vf4*>(X + (32 + i) * FP + Q * 32 + h * 16 + q * 4);
+      vf4 a[TI];
+#pragma unroll
+      for (int ti = 0; ti < TI; ++ti)
+        a[ti] = *reinterpret_cast<const vf4*>(X + (ti * 32 + i) * FP + Q * 32 + h * 16 + q * 4);
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[c], b[0][q][c], acc[0][0], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[c], b[0][q][c], acc[1][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[c], b[1][q][c], acc[0][1], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[c], b[1][q][c], acc[1][1], 0, 0, 0);
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+          for (int ti = 0; ti < TI; ++ti)
+            acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ti][c], b[tj][q][c], acc[ti][tj], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
   }
 }
 
-template <bool SAVE>
+template <int TI>
+__device__ inline void zero_acc2(v16f (&acc)[TI][2]) {
+#pragma unroll
+  for (int a = 0; a < TI; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+}
+
+// TI = row tiles per workgroup (64 points for TI = 2; 32 points for TI = 1, used for small batches so that
+// every CU still gets a workgroup).
+template <int TI, bool SAVE>
 __global__ __launch_bounds__(256, 2) void fused_forward_kernel(FusedFwdArgs g) {
+  constexpr int FT = 32 * TI;
   __shared__ __attribute__((aligned(16))) float lds[FT * FP + FT * FEP];
   float* X = lds;
   float* E = lds + FT * FP;
@@ -93,7 +113,8 @@ __global__ __launch_bounds__(256, 2) void fused_forward_kernel(FusedFwdArgs g) {
 
   // ---- positional encoding of the tile: X[:, 0:Ep] = [x, sin(2^k x), cos(2^k x)], zero padded -------
   {
-    const int p = tid & 63, part = tid >> 6;
+    constexpr int PARTS = 256 / FT;
+    const int p = tid % FT, part = tid / FT;
     const int64_t row = row0 + p;
     float x[3] = {0.f, 0.f, 0.f};
     if (row < g.M) {
@@ -111,7 +132,7 @@ __global__ __launch_bounds__(256, 2) void fused_forward_kernel(FusedFwdArgs g) {
         g.x4[row * 4] = x[0]; g.x4[row * 4 + 1] = x[1]; g.x4[row * 4 + 2] = x[2]; g.x4[row * 4 + 3] = 0.f;
       }
     }
-    for (int k = part; k < g.multires; k += 4) {
+    for (int k = part; k < g.multires; k += PARTS) {
       const float f = (float)(1 << k);
 #pragma unroll
       for (int d = 0; d < 3; ++d) {
@@ -124,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void fused_forward_kernel(FusedFwdArgs g) {
     }
   }
   __syncthreads();
-  if (SAVE) {   // e is an operand of the backward (dW of layer 0) and of the R sweep: 64 x Ep floats
+  if (SAVE) {   // e is an operand of the backward (dW of layer 0) and of the R sweep: FT x Ep floats
     for (int idx = tid; idx < FT * g.Ep; idx += 256) {
       const int r = idx / g.Ep, c = idx - r * g.Ep;
       g.e[(row0 + r) * g.Ep + c] = X[r * FP + c];
@@ -132,12 +153,15 @@ __global__ __launch_bounds__(256, 2) void fused_forward_kernel(FusedFwdArgs g) {
   }
 
   const int h = lane >> 5, cl = lane & 31;
-  v16f acc[2][2];
+  v16f acc[TI][2];
   for (int l = 0; l < g.nh; ++l) {
-    zero_acc<2>(acc);
-    layer_mma_nt(X, g.packed + g.w_off[l], g.Kp[l], n0, lane, acc);
-    __syncthreads();   // every wave has finished reading the input activations
+    zero_acc2<TI>(acc);
+    layer_mma_nt<TI>(X, g.packed + g.w_off[l], g.Kp[l], n0, lane, acc);
+    lds_barrier();   // every wave has finished reading the input activations
     const float* bias = g.packed + g.b_off[l];
+    float* __restrict__ pa = SAVE ? g.a[l] + (size_t)row0 * FH : nullptr;
+    float* __restrict__ pD = SAVE ? g.D[l] + (size_t)row0 * FH : nullptr;
+    float* __restrict__ pg = (SAVE && g.gz_last) ? g.gz_last + (size_t)row0 * FH : nullptr;
     const int n_real = g.n_real[l];
     const bool pe_tail = (l + 1 == g.skip);
     const bool last = (l + 1 == g.nh);
@@ -148,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void fused_forward_kernel(FusedFwdArgs g) {
       const float ws = (SAVE && last && g.gz_last) ? g.packed[g.wsdf_off + col] : 0.f;
       const bool tile_full = n0 + tj * 32 + 32 <= n_real;   // wave-uniform: no per-element column checks
 #pragma unroll
-      for (int ti = 0; ti < 2; ++ti) {
+      for (int ti = 0; ti < TI; ++ti) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -160,15 +184,15 @@ __global__ __launch_bounds__(256, 2) void fused_forward_kernel(FusedFwdArgs g) {
           }
           X[row * FP + col] = a;
           if (SAVE) {
-            const size_t o = (size_t)(row0 + row) * FH + col;
-            g.a[l][o] = a;
-            g.D[l][o] = D;
-            if (last && g.gz_last) g.gz_last[o] = ws * D;
+            const int o = row * FH + col;   // 32-bit offset from the tile's (wave-uniform) base pointer
+            pa[o] = a;
+            pD[o] = D;
+            if (last && g.gz_last) pg[o] = ws * D;
           }
         }
       }
     }
-    __syncthreads();   // the new activations are visible to every wave
+    lds_barrier();   // the new activations are visible to every wave
   }
 
   // ---- sdf head: row 0 of the output layer (models/fields.py:104, :106-108) -----------------------------
@@ -178,8 +202,8 @@ __global__ __launch_bounds__(256, 2) void fused_forward_kernel(FusedFwdArgs g) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) w[u] = ws[lane + 64 * u];
     const float bs = g.packed[g.bsdf_off];
-    for (int rr = 0; rr < 16; ++rr) {
-      const int row = wave * 16 + rr;
+    for (int rr = 0; rr < FT / 4; ++rr) {
+      const int row = wave * (FT / 4) + rr;
       float s = 0.f;
 #pragma unroll
       for (int u = 0; u < 4; ++u) s = fmaf(X[row * FP + lane + 64 * u], w[u], s);
@@ -190,20 +214,21 @@ __global__ __launch_bounds__(256, 2) void fused_forward_kernel(FusedFwdArgs g) {
   }
   // ---- feature head: rows 1.. of the output layer, written into the albedo network's input ------------
   if (g.with_feat) {
-    zero_acc<2>(acc);
-    layer_mma_nt(X, g.packed + g.wf_off, FH, n0, lane, acc);
+    zero_acc2<TI>(acc);
+    layer_mma_nt<TI>(X, g.packed + g.wf_off, FH, n0, lane, acc);
     const float* bias = g.packed + g.bf_off;
+    float* __restrict__ pc = g.cin + (size_t)row0 * g.Cinp;
 #pragma unroll
     for (int tj = 0; tj < 2; ++tj) {
       const int col = n0 + tj * 32 + cl;
       if (col < g.F) {
         const float bc = bias[col];
 #pragma unroll
-        for (int ti = 0; ti < 2; ++ti) {
+        for (int ti = 0; ti < TI; ++ti) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int row = ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            g.cin[(size_t)(row0 + row) * g.Cinp + col] = acc[ti][tj][r] + bc;
+            pc[row * g.Cinp + col] = acc[ti][tj][r] + bc;
           }
         }
       }
@@ -255,15 +280,23 @@ int fused_forward(const Layout& L, const float* packed, const float* pts, int64_
   g.x4 = pb.x;
   g.e = pb.e;
   g.gz_last = need_gz_last ? pb.gz[L.nh - 1] : nullptr;
-  const unsigned blocks = (unsigned)(pb.Mp / FT);
   // algorithmic FLOPs of the sweep (real layer shapes), for the optional event instrumentation
   double fl = 0;
   for (int l = 0; l < L.nh; ++l) fl += 2.0 * (double)M * L.hid[l].N * L.hid[l].K;
   fl += 2.0 * (double)M * L.H;
   if (need_feat) fl += 2.0 * (double)M * L.F * L.H;
   ProfScope prof(fl, s);
-  if (save) hipLaunchKernelGGL(fused_forward_kernel<true>, dim3(blocks), dim3(256), 0, s, g);
-  else hipLaunchKernelGGL(fused_forward_kernel<false>, dim3(blocks), dim3(256), 0, s, g);
+  // 64-point tiles when that still gives every CU >= 2 workgroups, 32-point tiles for small batches
+  const bool small = pb.Mp / 64 < 512;
+  if (small) {
+    const unsigned blocks = (unsigned)(pb.Mp / 32);
+    if (save) hipLaunchKernelGGL((fused_forward_kernel<1, true>), dim3(blocks), dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((fused_forward_kernel<1, false>), dim3(blocks), dim3(256), 0, s, g);
+  } else {
+    const unsigned blocks = (unsigned)(pb.Mp / 64);
+    if (save) hipLaunchKernelGGL((fused_forward_kernel<2, true>), dim3(blocks), dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((fused_forward_kernel<2, false>), dim3(blocks), dim3(256), 0, s, g);
+  }
   RNB_CHECK_LAUNCH();
   return RNB_OK;
 }
