@@ -42,6 +42,16 @@ struct FusedFwdArgs {
 // i.e. it would wait for the fire-and-forget global stores of the previous epilogue to reach memory.
 __device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// Raw buffer access to one tile of a row-major matrix: resource = tile base + byte size, per-lane 32-bit
+// byte offset in a VGPR, wave-uniform byte offset in the scalar operand.
+typedef __amdgpu_buffer_rsrc_t BufRsrc;
+__device__ inline BufRsrc tile_rsrc(const float* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, p ? bytes : 0, 0x00020000);
+}
+__device__ inline void bstore(BufRsrc r, unsigned voff, unsigned soff, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+}
+
 // One (32*TI) x 64 output block per wave: C[rows][n0..n0+63] = X[rows][K] * W[n][K]^T, K a multiple of 32.
 // k-permutation inside each 32-k block: lane half h takes k = 32Q + 16h + 4q + c, so every lane streams 64
 // contiguous bytes of its weight row per block.
@@ -159,9 +169,12 @@ __global__ __launch_bounds__(256, 2) void fused_forward_kernel(FusedFwdArgs g) {
     layer_mma_nt<TI>(X, g.packed + g.w_off[l], g.Kp[l], n0, lane, acc);
     lds_barrier();   // every wave has finished reading the input activations
     const float* bias = g.packed + g.b_off[l];
-    float* __restrict__ pa = SAVE ? g.a[l] + (size_t)row0 * FH : nullptr;
-    float* __restrict__ pD = SAVE ? g.D[l] + (size_t)row0 * FH : nullptr;
-    float* __restrict__ pg = (SAVE && g.gz_last) ? g.gz_last + (size_t)row0 * FH : nullptr;
+    // saved state goes out through buffer stores: one 32-bit lane offset per column tile plus a
+    // compile-time row offset in the scalar operand (plain pointer stores cost a 64-bit VGPR address
+    // pair per element, i.e. 128 extra registers and spills)
+    const BufRsrc ra = tile_rsrc(SAVE ? g.a[l] + (size_t)row0 * FH : nullptr, FT * FH * 4);
+    const BufRsrc rD = tile_rsrc(SAVE ? g.D[l] + (size_t)row0 * FH : nullptr, FT * FH * 4);
+    const BufRsrc rg = tile_rsrc((SAVE && g.gz_last) ? g.gz_last + (size_t)row0 * FH : nullptr, FT * FH * 4);
     const int n_real = g.n_real[l];
     const bool pe_tail = (l + 1 == g.skip);
     const bool last = (l + 1 == g.nh);
@@ -171,11 +184,13 @@ __global__ __launch_bounds__(256, 2) void fused_forward_kernel(FusedFwdArgs g) {
       const float bc = bias[col];
       const float ws = (SAVE && last && g.gz_last) ? g.packed[g.wsdf_off + col] : 0.f;
       const bool tile_full = n0 + tj * 32 + 32 <= n_real;   // wave-uniform: no per-element column checks
+      const unsigned voff = (unsigned)(4 * h * FH + col) * 4u;
 #pragma unroll
       for (int ti = 0; ti < TI; ++ti) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int row = ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const int rowc = ti * 32 + (r & 3) + 8 * (r >> 2);   // compile-time part of the row
+          const int row = rowc + 4 * h;
           float a, D;
           softplus_aD(acc[ti][tj][r] + bc, a, D);
           if (!tile_full && col >= n_real) {   // only the tile straddling the skip connection's PE columns
@@ -184,10 +199,9 @@ __global__ __launch_bounds__(256, 2) void fused_forward_kernel(FusedFwdArgs g) {
           }
           X[row * FP + col] = a;
           if (SAVE) {
-            const int o = row * FH + col;   // 32-bit offset from the tile's (wave-uniform) base pointer
-            pa[o] = a;
-            pD[o] = D;
-            if (last && g.gz_last) pg[o] = ws * D;
+            bstore(ra, voff, rowc * FH * 4, a);
+            bstore(rD, voff, rowc * FH * 4, D);
+            if (last && g.gz_last) bstore(rg, voff, rowc * FH * 4, ws * D);
           }
         }
       }
@@ -217,18 +231,20 @@ __global__ __launch_bounds__(256, 2) void fused_forward_kernel(FusedFwdArgs g) {
     zero_acc2<TI>(acc);
     layer_mma_nt<TI>(X, g.packed + g.wf_off, FH, n0, lane, acc);
     const float* bias = g.packed + g.bf_off;
-    float* __restrict__ pc = g.cin + (size_t)row0 * g.Cinp;
+    const BufRsrc rc = tile_rsrc(g.cin + (size_t)row0 * g.Cinp, FT * g.Cinp * 4);
+    const unsigned rowb = (unsigned)g.Cinp * 4u;   // bytes per row of the albedo-net input
 #pragma unroll
     for (int tj = 0; tj < 2; ++tj) {
       const int col = n0 + tj * 32 + cl;
       if (col < g.F) {
         const float bc = bias[col];
+        const unsigned voff = (unsigned)(4 * h) * rowb + (unsigned)col * 4u;
 #pragma unroll
         for (int ti = 0; ti < TI; ++ti) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const int row = ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            pc[row * g.Cinp + col] = acc[ti][tj][r] + bc;
+            const int rowc = ti * 32 + (r & 3) + 8 * (r >> 2);
+            bstore(rc, voff, rowc * rowb, acc[ti][tj][r] + bc);
           }
         }
       }
