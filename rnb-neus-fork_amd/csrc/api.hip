@@ -81,6 +81,12 @@ static int forward_points(const Layout& L, const float* packed, const float* pts
   return sweep_forward(L, packed, pb, need_feat, need_gz_last, feat_dense, s);
 }
 
+// reverse-mode normal: fused sweep (seeds itself from D_last) or the generic chain (seeded by the forward)
+static int reverse_points(const Layout& L, const float* packed, PointBufs& pb, hipStream_t s) {
+  if (use_fused(L)) return fused_reverse(L, packed, pb, s);
+  return sweep_reverse(L, packed, pb, s);
+}
+
 RNB_API int rnb_sdf_forward(const rnb_model_desc* desc, const float* packed, const float* pts, int64_t n,
                             float* sdf_out, float* feat_out, void* ws, size_t ws_bytes, rnb_stream_t stream) {
   RNB_REQUIRE(packed, "packed");
@@ -106,8 +112,8 @@ RNB_API int rnb_sdf_gradient(const rnb_model_desc* desc, const float* packed, co
   Layout L;
   PointBufs pb;
   RNB_TRY(points_setup(desc, n, ws, ws_bytes, &L, &pb));
-  RNB_TRY(forward_points(L, packed, pts, n, pb, true, false, true, nullptr, s));
-  RNB_TRY(sweep_reverse(L, packed, pb, s));
+  RNB_TRY(forward_points(L, packed, pts, n, pb, true, false, !use_fused(L), nullptr, s));
+  RNB_TRY(reverse_points(L, packed, pb, s));
   RNB_TRY(launch_copy_cols(pb.nrm, 4, 3, n, grad_out, s));
   if (sdf_out) RNB_CHECK_HIP(hipMemcpyAsync(sdf_out, pb.sdf, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, s));
   return RNB_OK;
@@ -368,8 +374,8 @@ RNB_API int rnb_render_fwd(const rnb_model_desc* desc, const float* packed, cons
   const bool use_color = (mode & PM_WITH_COLOR) != 0;
   RNB_TRY(launch_fine_points(a->rays_o, a->rays_d, a->z_vals, a->B, a->S, 2.0f / (float)desc->n_samples, rb.pts,
                              rb.dists, s));
-  RNB_TRY(forward_points(L, packed, rb.pts, a->B * a->S, rb.pb, true, use_color, true, nullptr, s));
-  RNB_TRY(sweep_reverse(L, packed, rb.pb, s));
+  RNB_TRY(forward_points(L, packed, rb.pts, a->B * a->S, rb.pb, true, use_color, !use_fused(L), nullptr, s));
+  RNB_TRY(reverse_points(L, packed, rb.pb, s));
   if (use_color) RNB_TRY(sweep_color(L, packed, rb.pb, rb.pts, rb.pb.nrm, 4, s));
   CompArgs c = comp_args_of(L, a, rb);
   RNB_TRY(launch_composite_fwd(c, a->gradient_error, rb.gerr_den, s));
@@ -409,7 +415,7 @@ RNB_API int rnb_render_bwd(const rnb_model_desc* desc, const float* packed, cons
   g.invs_part = rb.invs_part;
   RNB_TRY(launch_composite_bwd(g, variance_grad, s));
   RNB_CHECK_HIP(hipMemsetAsync(packed_grad, 0, (size_t)L.total * sizeof(float), s));
-  RNB_TRY(sweep_backward(L, packed, rb.pb, use_color, packed_grad, s));
+  RNB_TRY(sweep_backward(L, packed, rb.pb, use_color, packed_grad, use_fused(L), s));
   return RNB_OK;
 }
 

@@ -1,0 +1,309 @@
+// Fused reverse-shaped sweeps of the 256-wide SDF network (same skeleton as fused_forward_kernel: a 64-point
+// tile per workgroup stays in LDS across all layers, weights stream from L2, saved state leaves through
+// fire-and-forget buffer stores, per-element operands of the epilogues come in through buffer loads).
+//
+//   fused_reverse_kernel  R : gz_l = g_l * D_l, g_{l-1} = gz_l W_l, normal = J_pe^T g_e   (fields.py:114-127)
+//   fused_ra_kernel       RA: adjoint of R (second-order terms zR_l and the u_l operands of dW)
+//   fused_fb_kernel       FB: backward of the forward sweep, zb_{l-1} = (zb_l W_l) * D_{l-1} + zR_{l-1}
+// Mathematical statement: oracle/explicit.py.  The reverse-shaped products use the transposed weight
+// copies W^T that rnb_weightnorm_fwd emits, so every sweep streams weight rows the same way.
+#include "fused_common.hip.h"
+
+namespace rnb {
+
+constexpr int FT = 64;
+
+struct FusedBwdArgs {
+  const float* packed;
+  int nh, skip, pe, multires, Ep;
+  float inv_scale;
+  int n_real[RNB_MAX_LIN];   // real output width of hidden layer l
+  int Kp[RNB_MAX_LIN];       // padded input width of hidden layer l
+  long long w_off[RNB_MAX_LIN], wT_off[RNB_MAX_LIN];
+  long long wsdf_off, wfT_off;
+  float* D[RNB_MAX_LIN];
+  float* gz[RNB_MAX_LIN];
+  float* u[RNB_MAX_LIN + 1];
+  float* zR[RNB_MAX_LIN];
+  float* zb[RNB_MAX_LIN];
+  const float* x4;      // [Mp,4]
+  float* nrm;           // [Mp,4]      (R)
+  const float* geb;     // [Mp,Ep]     (RA)
+  const float* sbar;    // [Mp]        (FB)
+  const float* fbar;    // [Mp,ld_fbar] first 256 columns, or nullptr (FB, no_albedo)
+  int ld_fbar;
+};
+
+// visits the wave's 64 x 64 accumulator block: f(tj, ti, r, col, rowc, row) with rowc the lane-independent
+// part of the row (compile-time after unrolling) and row = rowc + 4*(lane>>5)
+template <class F>
+__device__ inline void for_each_acc(int n0, int lane, F f) {
+  const int h = lane >> 5, cl = lane & 31;
+#pragma unroll
+  for (int tj = 0; tj < 2; ++tj) {
+    const int col = n0 + tj * 32 + cl;
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rowc = ti * 32 + (r & 3) + 8 * (r >> 2);
+        f(tj, ti, r, col, rowc, rowc + 4 * h);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// R sweep
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void fused_reverse_kernel(FusedBwdArgs g) {
+  __shared__ __attribute__((aligned(16))) float lds[FT * FP + FT * FEP];
+  float* X = lds;
+  float* GE = lds + FT * FP;   // d sdf / d e of the tile
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = wave_id();
+  const int64_t row0 = (int64_t)blockIdx.x * FT;
+  const int n0 = wave * 64;
+  const int h = lane >> 5;
+
+  // seed: gz_{nh-1} = w_sdf * D_{nh-1}  (row 0 of the output layer is d sdf / d a_last)
+  {
+    const float* Dl = g.D[g.nh - 1] + (size_t)row0 * FH;
+    float* gzl = g.gz[g.nh - 1] + (size_t)row0 * FH;
+    const float* ws = g.packed + g.wsdf_off;
+    for (int idx = tid; idx < FT * FH / 4; idx += 256) {
+      const int r = idx >> 6, c4 = idx & 63;
+      const vf4 d = *reinterpret_cast<const vf4*>(Dl + r * FH + c4 * 4);
+      const vf4 w = *reinterpret_cast<const vf4*>(ws + c4 * 4);
+      const vf4 v = d * w;
+      *reinterpret_cast<vf4*>(X + r * FP + c4 * 4) = v;
+      *reinterpret_cast<vf4*>(gzl + r * FH + c4 * 4) = v;
+    }
+    for (int idx = tid; idx < FT * FEP; idx += 256) GE[idx] = 0.f;
+  }
+  __syncthreads();
+
+  v16f acc[2][2];
+  for (int l = g.nh - 1; l >= 1; --l) {
+    zero_acc2<2>(acc);
+    layer_mma_nt<2>(X, g.packed + g.wT_off[l], FH, n0, lane, acc);   // g = gz_l W_l  (columns = inputs of layer l)
+    lds_barrier();
+    const bool is_skip = (l == g.skip);
+    const int ksplit = is_skip ? FH - g.pe : FH;   // columns that belong to layer l-1's output
+    const BufRsrc rD = tile_rsrc(g.D[l - 1] + (size_t)row0 * FH, FT * FH * 4);
+    const BufRsrc rg = tile_rsrc(g.gz[l - 1] + (size_t)row0 * FH, FT * FH * 4);
+    for_each_acc(n0, lane, [&](int tj, int ti, int r, int col, int rowc, int row) {
+      const unsigned voff = (unsigned)(4 * h * FH + col) * 4u;
+      const float v = acc[ti][tj][r];
+      float gzv;
+      if (col < ksplit) {
+        gzv = v * bload(rD, voff, rowc * FH * 4);
+      } else {
+        if (col < ksplit + g.pe) GE[row * FEP + (col - ksplit)] = v;   // skip connection: straight to g_e
+        gzv = 0.f;
+      }
+      X[row * FP + col] = gzv;
+      bstore(rg, voff, rowc * FH * 4, gzv);
+    });
+    lds_barrier();
+  }
+  // layer 0: g_e += gz_0 W_0 (Ep = 64 columns: wave 0 only)
+  if (wave == 0) {
+    zero_acc2<2>(acc);
+    layer_mma_nt<2>(X, g.packed + g.wT_off[0], FH, 0, lane, acc);
+    for_each_acc(0, lane, [&](int tj, int ti, int r, int col, int rowc, int row) {
+      if (col < g.pe) GE[row * FEP + col] += acc[ti][tj][r];
+    });
+  }
+  __syncthreads();
+  // normal = J_pe(x)^T g_e
+  if (tid < FT) {
+    const int64_t row = row0 + tid;
+    const float* ge = GE + tid * FEP;
+    float n[3] = {ge[0], ge[1], ge[2]};
+    float f = 1.f;
+    int c = 3;
+    for (int k = 0; k < g.multires; ++k) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        float s, co;
+        sincosf(g.x4[row * 4 + d] * f, &s, &co);
+        n[d] += f * (ge[c + d] * co - ge[c + 3 + d] * s);
+      }
+      c += 6;
+      f *= 2.f;
+    }
+    g.nrm[row * 4] = n[0]; g.nrm[row * 4 + 1] = n[1]; g.nrm[row * 4 + 2] = n[2]; g.nrm[row * 4 + 3] = 0.f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// RA sweep
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void fused_ra_kernel(FusedBwdArgs g) {
+  __shared__ __attribute__((aligned(16))) float lds[FT * FP + FT * FEP];
+  float* X = lds;
+  float* E = lds + FT * FP;   // adjoint of g_e of the tile (re-enters at the skip connection)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = wave_id();
+  const int64_t row0 = (int64_t)blockIdx.x * FT;
+  const int n0 = wave * 64;
+  const int h = lane >> 5;
+
+  for (int idx = tid; idx < FT * g.Ep; idx += 256) {
+    const int r = idx / g.Ep, c = idx - r * g.Ep;
+    const float v = g.geb[(row0 + r) * g.Ep + c];
+    X[r * FP + c] = v;
+    if (c < FEP) E[r * FEP + c] = v;
+  }
+  __syncthreads();
+
+  v16f acc[2][2];
+  for (int l = 0; l < g.nh; ++l) {
+    zero_acc2<2>(acc);
+    layer_mma_nt<2>(X, g.packed + g.w_off[l], g.Kp[l], n0, lane, acc);   // gzb = u_l W_l^T
+    lds_barrier();
+    const int n_real = g.n_real[l];
+    const bool pe_tail = (l + 1 == g.skip);
+    const BufRsrc rD = tile_rsrc(g.D[l] + (size_t)row0 * FH, FT * FH * 4);
+    const BufRsrc rgz = tile_rsrc(g.gz[l] + (size_t)row0 * FH, FT * FH * 4);
+    const BufRsrc rzR = tile_rsrc(g.zR[l] + (size_t)row0 * FH, FT * FH * 4);
+    const BufRsrc ru = tile_rsrc(g.u[l + 1] + (size_t)row0 * FH, FT * FH * 4);
+    for_each_acc(n0, lane, [&](int tj, int ti, int r, int col, int rowc, int row) {
+      const unsigned voff = (unsigned)(4 * h * FH + col) * 4u;
+      const unsigned soff = rowc * FH * 4;
+      const float v = acc[ti][tj][r];
+      float zr, un;
+      if (col < n_real) {
+        const float D = bload(rD, voff, soff);
+        const float gzv = bload(rgz, voff, soff);
+        zr = 100.f * v * gzv * (1.f - D);
+        un = v * D;
+      } else {
+        zr = 0.f;
+        un = (pe_tail && col < n_real + g.pe) ? E[row * FEP + (col - n_real)] : 0.f;
+      }
+      X[row * FP + col] = un;
+      bstore(rzR, voff, soff, zr);
+      bstore(ru, voff, soff, un);
+    });
+    lds_barrier();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// FB sweep
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void fused_fb_kernel(FusedBwdArgs g) {
+  __shared__ __attribute__((aligned(16))) float lds[FT * FP];
+  float* X = lds;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = wave_id();
+  const int64_t row0 = (int64_t)blockIdx.x * FT;
+  const int n0 = wave * 64;
+  const int h = lane >> 5;
+
+  v16f acc[2][2];
+  zero_acc2<2>(acc);
+  if (g.fbar != nullptr) {   // ab_{nh-1} = fbar W_feat (+ the sdf-head term below)
+    const float* fb = g.fbar + (size_t)row0 * g.ld_fbar;
+    for (int idx = tid; idx < FT * FH / 4; idx += 256) {
+      const int r = idx >> 6, c4 = idx & 63;
+      *reinterpret_cast<vf4*>(X + r * FP + c4 * 4) = *reinterpret_cast<const vf4*>(fb + (size_t)r * g.ld_fbar + c4 * 4);
+    }
+    __syncthreads();
+    layer_mma_nt<2>(X, g.packed + g.wfT_off, FH, n0, lane, acc);
+    lds_barrier();
+  }
+  for (int l = g.nh - 1; l >= 0; --l) {
+    // epilogue of the product that produced ab_l: zb_l = ab_l * D_l + zR_l
+    const int n_real = g.n_real[l];
+    const bool head = (l == g.nh - 1);
+    const BufRsrc rD = tile_rsrc(g.D[l] + (size_t)row0 * FH, FT * FH * 4);
+    const BufRsrc rzR = tile_rsrc(g.zR[l] + (size_t)row0 * FH, FT * FH * 4);
+    const BufRsrc rzb = tile_rsrc(g.zb[l] + (size_t)row0 * FH, FT * FH * 4);
+    for_each_acc(n0, lane, [&](int tj, int ti, int r, int col, int rowc, int row) {
+      const unsigned voff = (unsigned)(4 * h * FH + col) * 4u;
+      const unsigned soff = rowc * FH * 4;
+      float v = acc[ti][tj][r];
+      float zb = 0.f;
+      if (col < n_real) {
+        if (head) v = fmaf(g.sbar[row0 + row] * g.inv_scale, g.packed[g.wsdf_off + col], v);
+        zb = fmaf(v, bload(rD, voff, soff), bload(rzR, voff, soff));
+      }
+      X[row * FP + col] = zb;
+      bstore(rzb, voff, soff, zb);
+    });
+    lds_barrier();
+    if (l == 0) break;
+    zero_acc2<2>(acc);
+    layer_mma_nt<2>(X, g.packed + g.wT_off[l], FH, n0, lane, acc);   // ab_{l-1} = zb_l W_l
+    lds_barrier();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+static void fill_args(const Layout& L, const float* packed, PointBufs& pb, FusedBwdArgs& g) {
+  memset(&g, 0, sizeof(g));
+  g.packed = packed;
+  g.nh = L.nh;
+  g.skip = L.skip;
+  g.pe = L.pe;
+  g.multires = L.multires;
+  g.Ep = L.Ep;
+  g.inv_scale = 1.f / L.sdf_scale;
+  for (int l = 0; l < L.nh; ++l) {
+    g.n_real[l] = L.hid[l].N;
+    g.Kp[l] = L.hid[l].Kp;
+    g.w_off[l] = L.hid[l].w_off;
+    g.wT_off[l] = L.hid[l].wT_off;
+    g.D[l] = pb.D[l];
+    g.gz[l] = pb.gz[l];
+    g.zR[l] = pb.zR[l];
+    g.zb[l] = pb.zb[l];
+  }
+  for (int l = 1; l <= L.nh; ++l) g.u[l] = pb.u[l];
+  g.wsdf_off = L.wsdf_off;
+  g.wfT_off = L.feat.wT_off;
+  g.x4 = pb.x;
+  g.nrm = pb.nrm;
+  g.geb = pb.geb;
+  g.sbar = pb.sbar;
+}
+
+static double hidden_flops(const Layout& L, int64_t M, int first) {
+  double fl = 0;
+  for (int l = first; l < L.nh; ++l) fl += 2.0 * (double)M * L.hid[l].N * L.hid[l].K;
+  return fl;
+}
+
+int fused_reverse(const Layout& L, const float* packed, PointBufs& pb, hipStream_t s) {
+  FusedBwdArgs g;
+  fill_args(L, packed, pb, g);
+  ProfScope prof(hidden_flops(L, pb.M, 0), s);
+  hipLaunchKernelGGL(fused_reverse_kernel, dim3((unsigned)(pb.Mp / FT)), dim3(256), 0, s, g);
+  RNB_CHECK_LAUNCH();
+  return RNB_OK;
+}
+
+int fused_ra(const Layout& L, const float* packed, PointBufs& pb, hipStream_t s) {
+  FusedBwdArgs g;
+  fill_args(L, packed, pb, g);
+  ProfScope prof(hidden_flops(L, pb.M, 0), s);
+  hipLaunchKernelGGL(fused_ra_kernel, dim3((unsigned)(pb.Mp / FT)), dim3(256), 0, s, g);
+  RNB_CHECK_LAUNCH();
+  return RNB_OK;
+}
+
+int fused_fb(const Layout& L, const float* packed, PointBufs& pb, bool with_color, hipStream_t s) {
+  FusedBwdArgs g;
+  fill_args(L, packed, pb, g);
+  g.fbar = with_color ? pb.cinb : nullptr;
+  g.ld_fbar = L.Cinp;
+  ProfScope prof(hidden_flops(L, pb.M, 1) + (with_color ? 2.0 * (double)pb.M * L.F * L.H : 0.0), s);
+  hipLaunchKernelGGL(fused_fb_kernel, dim3((unsigned)(pb.Mp / FT)), dim3(256), 0, s, g);
+  RNB_CHECK_LAUNCH();
+  return RNB_OK;
+}
+
+}  // namespace rnb

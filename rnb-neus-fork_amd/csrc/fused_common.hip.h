@@ -1,0 +1,87 @@
+// Shared device helpers of the fused SDF-network sweeps (fused.hip, fused_bwd.hip).
+#pragma once
+#include "gemm.hip.h"
+#include "rnb_internal.h"
+
+namespace rnb {
+
+constexpr int FH = 256;       // hidden width of the fused path
+constexpr int FP = FH + 4;    // LDS pitch of the activation tile
+constexpr int FEP = 40;       // LDS pitch of the positional-encoding copy kept for the skip connection
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory counter,
+// i.e. it would wait for the fire-and-forget global stores of the previous epilogue to reach memory.
+__device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Raw buffer access to one tile of a row-major matrix: resource = tile base + byte size, per-lane 32-bit
+// byte offset in a VGPR, wave-uniform byte offset in the scalar operand.
+typedef __amdgpu_buffer_rsrc_t BufRsrc;
+__device__ inline BufRsrc tile_rsrc(const float* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, p ? bytes : 0, 0x00020000);
+}
+__device__ inline void bstore(BufRsrc r, unsigned voff, unsigned soff, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+}
+
+// One (32*TI) x 64 output block per wave: C[rows][n0..n0+63] = X[rows][K] * W[n][K]^T, K a multiple of 32.
+// k-permutation inside each 32-k block: lane half h takes k = 32Q + 16h + 4q + c, so every lane streams 64
+// contiguous bytes of its weight row per block.
+__device__ inline void load_b_block(const float* __restrict__ W, int K, int n0, int Q, int lane, vf4 (&b)[2][4]) {
+  const int j = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int tj = 0; tj < 2; ++tj) {
+    const float* p = W + (size_t)(n0 + tj * 32 + j) * K + Q * 32 + h * 16;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) b[tj][q] = *reinterpret_cast<const vf4*>(p + q * 4);
+  }
+}
+
+template <int TI>
+__device__ inline void layer_mma_nt(const float* __restrict__ X, const float* __restrict__ W, int K, int n0, int lane,
+                                    v16f (&acc)[TI][2]) {
+  const int i = lane & 31, h = lane >> 5;
+  const int nQ = K / 32;
+  vf4 bn[2][4];
+  load_b_block(W, K, n0, 0, lane, bn);
+  for (int Q = 0; Q < nQ; ++Q) {
+    vf4 b[2][4];
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) b[tj][q] = bn[tj][q];
+    if (Q + 1 < nQ) load_b_block(W, K, n0, Q + 1, lane, bn);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      vf4 a[TI];
+#pragma unroll
+      for (int ti = 0; ti < TI; ++ti)
+        a[ti] = *reinterpret_cast<const vf4*>(X + (ti * 32 + i) * FP + Q * 32 + h * 16 + q * 4);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+          for (int ti = 0; ti < TI; ++ti)
+            acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ti][c], b[tj][q][c], acc[ti][tj], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+template <int TI>
+__device__ inline void zero_acc2(v16f (&acc)[TI][2]) {
+#pragma unroll
+  for (int a = 0; a < TI; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+}
+
+
+__device__ inline float bload(BufRsrc r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+
+}  // namespace rnb

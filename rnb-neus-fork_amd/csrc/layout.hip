@@ -25,6 +25,13 @@ static void place(Lin& l, int N, int K, float scale, int64_t& off) {
   off += (int64_t)l.Np * l.Kp;
   l.b_off = off;
   off += l.Np;
+  l.wT_off = -1;
+}
+// transposed copy W^T [Kp x Np]: lets the reverse-shaped sweeps (R, FB) stream weight rows exactly like
+// the forward-shaped ones
+static void place_transpose(Lin& l, int64_t& off) {
+  l.wT_off = off;
+  off += (int64_t)l.Kp * l.Np;
 }
 
 int make_layout(const rnb_model_desc* d, Layout* L) {
@@ -62,11 +69,13 @@ int make_layout(const rnb_model_desc* d, Layout* L) {
     off += (int64_t)L->Hp * L->hid[l].Kp;
     L->hid[l].b_off = off;
     off += L->Hp;
+    place_transpose(L->hid[l], off);
   }
   L->F = d->sdf_d_out - 1;
   L->Fp = pad32(L->F > 0 ? L->F : 1);
   place(L->feat, L->F > 0 ? L->F : 0, L->H, 1.f, off);
   if (L->F <= 0) { L->feat.Np = 0; }
+  else place_transpose(L->feat, off);
   L->wsdf_off = off;
   off += L->Hp;
   L->bsdf_off = off;

@@ -588,7 +588,7 @@ int sweep_color(const Layout& L, const float* packed, PointBufs& pb, const float
 // Backward of everything above given pb.sbar, pb.nbar, pb.albbar (from the composite backward).
 // packed_grad (same layout as `packed`) must be zero on entry; it receives dW_eff / db of every layer.
 int sweep_backward(const Layout& L, const float* packed, PointBufs& pb, bool with_color, float* packed_grad,
-                   hipStream_t s) {
+                   bool fused, hipStream_t s) {
   const int64_t M = pb.M, Mp = pb.Mp;
   // ---- C': albedo network backward ---------------------------------------------------------------
   if (with_color) {
@@ -617,12 +617,16 @@ int sweep_backward(const Layout& L, const float* packed, PointBufs& pb, bool wit
                      L.Cinp, L.F + L.pev, L.multires_view, with_color ? 1 : 0, L.multires, L.Ep, M, Mp, pb.geb);
   RNB_CHECK_LAUNCH();
   // ---- RA: adjoint of the reverse sweep, forward layer order -----------------------------------------
-  for (int l = 0; l < L.nh; ++l) {
-    const Lin& ln = L.hid[l];
-    const float* in = l == 0 ? pb.geb : pb.u[l];
-    const int lda = l == 0 ? L.Ep : L.Hp;
-    EpiRA epi{pb.D[l], pb.gz[l], pb.zR[l], pb.u[l + 1], L.Hp, ln.N, (l + 1 == L.skip) ? pb.geb : nullptr, L.Ep, L.pe};
-    RNB_TRY((launch_rows<false, EpiRA>(in, lda, packed + ln.w_off, ln.Kp, Mp, ln.Np, ln.Kp, epi, mm_flops(M, ln), s)));
+  if (fused) {
+    RNB_TRY(fused_ra(L, packed, pb, s));
+  } else {
+    for (int l = 0; l < L.nh; ++l) {
+      const Lin& ln = L.hid[l];
+      const float* in = l == 0 ? pb.geb : pb.u[l];
+      const int lda = l == 0 ? L.Ep : L.Hp;
+      EpiRA epi{pb.D[l], pb.gz[l], pb.zR[l], pb.u[l + 1], L.Hp, ln.N, (l + 1 == L.skip) ? pb.geb : nullptr, L.Ep, L.pe};
+      RNB_TRY((launch_rows<false, EpiRA>(in, lda, packed + ln.w_off, ln.Kp, Mp, ln.Np, ln.Kp, epi, mm_flops(M, ln), s)));
+    }
   }
   // ---- sdf-head row gradient ---------------------------------------------------------------------
   {
@@ -633,12 +637,15 @@ int sweep_backward(const Layout& L, const float* packed, PointBufs& pb, bool wit
     RNB_CHECK_LAUNCH();
   }
   // ---- FB head: zb_{nh-1} = (fbar Wf + sbar/scale w_sdf) * D + zR ----------------------------------
+  if (fused) RNB_TRY(fused_fb(L, packed, pb, with_color, s));   // all zb_l in one launch
   {
-    EpiFB epi{pb.D[L.nh - 1], pb.zR[L.nh - 1], pb.zb[L.nh - 1], L.Hp, L.hid[L.nh - 1].N, pb.sbar,
-              packed + L.wsdf_off, 1.f / L.sdf_scale};
-    const int K = with_color ? L.feat.Np : 0;   // no_albedo: fbar == 0, the GEMM degenerates to its epilogue
-    RNB_TRY((launch_rows<true, EpiFB>(pb.cinb, L.Cinp, packed + L.feat.w_off, L.feat.Kp, Mp, L.feat.Kp, K, epi,
-                                      with_color ? mm_flops(M, L.feat) : 0.0, s)));
+    if (!fused) {
+      EpiFB epi{pb.D[L.nh - 1], pb.zR[L.nh - 1], pb.zb[L.nh - 1], L.Hp, L.hid[L.nh - 1].N, pb.sbar,
+                packed + L.wsdf_off, 1.f / L.sdf_scale};
+      const int K = with_color ? L.feat.Np : 0;   // no_albedo: fbar == 0, the GEMM degenerates to its epilogue
+      RNB_TRY((launch_rows<true, EpiFB>(pb.cinb, L.Cinp, packed + L.feat.w_off, L.feat.Kp, Mp, L.feat.Kp, K, epi,
+                                        with_color ? mm_flops(M, L.feat) : 0.0, s)));
+    }
     if (with_color) {
       DwPair p{pb.cinb, L.Cinp, pb.a[L.nh - 1], L.Hp};
       RNB_TRY(launch_dw(p, p, 1, M, L.feat.Np, L.feat.Kp, packed_grad + L.feat.w_off, L.feat.Kp,
@@ -655,7 +662,7 @@ int sweep_backward(const Layout& L, const float* packed, PointBufs& pb, bool wit
     DwPair p2{pb.zb[l], L.Hp, in, ldin};
     RNB_TRY(launch_dw(p1, p2, 2, M, ln.Np, ln.Kp, packed_grad + ln.w_off, ln.Kp, packed_grad + ln.b_off, 1,
                       2.0 * mm_flops(M, ln), s));
-    if (l > 0) {
+    if (l > 0 && !fused) {
       const Lin& lp = L.hid[l - 1];
       EpiFB epi{pb.D[l - 1], pb.zR[l - 1], pb.zb[l - 1], L.Hp, lp.N, nullptr, nullptr, 1.f};
       RNB_TRY((launch_rows<true, EpiFB>(pb.zb[l], L.Hp, packed + ln.w_off, ln.Kp, Mp, ln.Kp, ln.Np, epi, mm_flops(M, ln), s)));

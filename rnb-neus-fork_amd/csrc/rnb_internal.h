@@ -37,6 +37,7 @@ struct Lin {
   int N, K;        // real out / in widths
   int Np, Kp;      // padded
   int64_t w_off;   // float offset of W in the packed buffer
+  int64_t wT_off;  // float offset of the transposed copy W^T [Kp x Np] (reverse-shaped sweeps), or -1
   int64_t b_off;   // float offset of b
   float scale;     // factor folded into W (1/sqrt2 for the skip layer)
 };
@@ -128,7 +129,10 @@ int sweep_color(const Layout& L, const float* packed, PointBufs& pb, const float
 int launch_copy_cols(const float* src, int ld, int ncols, int64_t M, float* out, hipStream_t s);
 int launch_fill_cols(const float* src, int ncols, int64_t M, int64_t Mp, int ld, float* dst, hipStream_t s);
 int sweep_backward(const Layout& L, const float* packed, PointBufs& pb, bool with_color, float* packed_grad,
-                   hipStream_t s);
+                   bool fused, hipStream_t s);
+int fused_reverse(const Layout& L, const float* packed, PointBufs& pb, hipStream_t s);
+int fused_ra(const Layout& L, const float* packed, PointBufs& pb, hipStream_t s);
+int fused_fb(const Layout& L, const float* packed, PointBufs& pb, bool with_color, hipStream_t s);
 
 // ---- fused sweeps for hidden width 256 (fused.hip) ---------------------------------------------------
 bool fused_supported(const Layout& L);

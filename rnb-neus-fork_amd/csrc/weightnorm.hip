@@ -19,6 +19,7 @@ struct WnEntry {
   int cmap_f;       // >0: albedo layer 0 column permutation, value = F
   int cmap_2pev;
   long long w_off, b_off;
+  long long wT_off;  // transposed copy [Kp x Nrows] or -1
   float scale;
 };
 constexpr int kMaxEntries = 2 * RNB_MAX_LIN + 2;
@@ -52,8 +53,12 @@ __global__ __launch_bounds__(256) void wn_fwd_kernel(WnTable tab, float* __restr
   const WnEntry& en = tab.e[ei];
   const int r = blockIdx.x - en.row_begin;
   float* wrow = packed + en.w_off + (long long)r * en.Kp;
+  float* wT = en.wT_off >= 0 ? packed + en.wT_off + r : nullptr;   // column r of W^T, stride Nrows
   if (r >= en.N) {
-    for (int c = threadIdx.x; c < en.Kp; c += blockDim.x) wrow[c] = 0.f;
+    for (int c = threadIdx.x; c < en.Kp; c += blockDim.x) {
+      wrow[c] = 0.f;
+      if (wT) wT[(long long)c * en.Nrows] = 0.f;
+    }
     if (threadIdx.x == 0) packed[en.b_off + r] = 0.f;
     return;
   }
@@ -66,8 +71,16 @@ __global__ __launch_bounds__(256) void wn_fwd_kernel(WnTable tab, float* __restr
     ss = block_sum(ss, red);
     mult = en.scale * (en.g[src] / sqrtf(ss));
   }
-  for (int i = threadIdx.x; i < en.K; i += blockDim.x) wrow[cmap(en, i)] = vrow[i] * mult;
-  for (int c = en.K + threadIdx.x; c < en.Kp; c += blockDim.x) wrow[c] = 0.f;
+  for (int i = threadIdx.x; i < en.K; i += blockDim.x) {
+    const int c = cmap(en, i);
+    const float w = vrow[i] * mult;
+    wrow[c] = w;
+    if (wT) wT[(long long)c * en.Nrows] = w;
+  }
+  for (int c = en.K + threadIdx.x; c < en.Kp; c += blockDim.x) {
+    wrow[c] = 0.f;
+    if (wT) wT[(long long)c * en.Nrows] = 0.f;
+  }
   if (threadIdx.x == 0) packed[en.b_off + r] = en.b[src];
 }
 
@@ -105,7 +118,7 @@ __global__ __launch_bounds__(256) void wn_bwd_kernel(WnTable tab, const float* _
 
 static void add_entry(WnTable& t, const rnb_mlp_params* p, const rnb_mlp_grads* g, int lin, bool wn, int src_row0,
                       int N, int Nrows, int K, int Kp, long long w_off, long long b_off, float scale, int cmap_f,
-                      int cmap_2pev) {
+                      int cmap_2pev, long long wT_off = -1) {
   WnEntry& e = t.e[t.n];
   e.g = wn ? p->g[lin] : nullptr;
   e.v = p->v[lin];
@@ -122,6 +135,7 @@ static void add_entry(WnTable& t, const rnb_mlp_params* p, const rnb_mlp_grads* 
   e.cmap_f = cmap_f;
   e.cmap_2pev = cmap_2pev;
   e.w_off = w_off;
+  e.wT_off = wT_off;
   e.b_off = b_off;
   e.scale = scale;
   t.total_rows += Nrows;
@@ -140,12 +154,13 @@ static int build_table(const rnb_model_desc* d, const Layout& L, const rnb_mlp_p
       if (!sdf->v[l] || !sdf->b[l] || (wn && !sdf->g[l])) RNB_FAIL(RNB_E_NULL, "sdf lin%d has a NULL leaf", l);
     for (int l = 0; l < L.nh; ++l) {
       const Lin& ln = L.hid[l];
-      add_entry(t, sdf, gs, l, wn, 0, ln.N, ln.Np, ln.K, ln.Kp, ln.w_off, ln.b_off, ln.scale, 0, 0);
+      add_entry(t, sdf, gs, l, wn, 0, ln.N, ln.Np, ln.K, ln.Kp, ln.w_off, ln.b_off, ln.scale, 0, 0, ln.wT_off);
     }
     // output layer: row 0 -> sdf head, rows 1.. -> feature head
     add_entry(t, sdf, gs, L.nh, wn, 0, 1, 1, L.H, L.Hp, L.wsdf_off, L.bsdf_off, 1.f, 0, 0);
     if (L.F > 0)
-      add_entry(t, sdf, gs, L.nh, wn, 1, L.F, L.feat.Np, L.H, L.feat.Kp, L.feat.w_off, L.feat.b_off, 1.f, 0, 0);
+      add_entry(t, sdf, gs, L.nh, wn, 1, L.F, L.feat.Np, L.H, L.feat.Kp, L.feat.w_off, L.feat.b_off, 1.f, 0, 0,
+                L.feat.wT_off);
   }
   if (color) {
     if (L.F <= 0) RNB_FAIL(RNB_E_INVALID, "albedo network needs a feature head");

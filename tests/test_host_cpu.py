@@ -46,8 +46,9 @@ def test_packed_layout_size_and_workspace_queries():
     d = _desc()
     n = C.c_int64()
     R.native.check(lib.rnb_packed_floats(C.byref(d), C.byref(n)))
-    # 8 hidden layers + feature head + sdf row + albedo net, all padded to multiples of 32
-    expect = (256 * 64 + 256) + 7 * (256 * 256 + 256) + (256 * 256 + 256) + 256 + 32 \
+    # 8 hidden layers + feature head (each with a transposed copy for the reverse-shaped sweeps) + sdf row
+    # + albedo net, all padded to multiples of 32
+    expect = (2 * 256 * 64 + 256) + 7 * (2 * 256 * 256 + 256) + (2 * 256 * 256 + 256) + 256 + 32 \
         + (256 * 320 + 256) + (256 * 256 + 256) + (32 * 256 + 32)
     assert n.value == expect
     b = C.c_int64()
