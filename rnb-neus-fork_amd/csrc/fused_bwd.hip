@@ -1,6 +1,9 @@
-// Fused reverse-shaped sweeps of the 256-wide SDF network (same skeleton as fused_forward_kernel: a 64-point
-// tile per workgroup stays in LDS across all layers, weights stream from L2, saved state leaves through
-// fire-and-forget buffer stores, per-element operands of the epilogues come in through buffer loads).
+// Fused reverse-shaped sweeps of the 256-wide SDF network (same skeleton as fused_forward_kernel: a tile of
+// points per workgroup stays in LDS across all layers, weights stream from L2, saved state leaves through
+// fire-and-forget buffer stores).  The per-element operands of the epilogues (D_l, gz_l, zR_l) are
+// prefetched into registers with buffer loads issued BEFORE the layer's matrix loop, so they land while the
+// matrix cores run; 32-point tiles keep that prefetch (2 x 32 registers) inside the register budget and put
+// three workgroups on a CU.
 //
 //   fused_reverse_kernel  R : gz_l = g_l * D_l, g_{l-1} = gz_l W_l, normal = J_pe^T g_e   (fields.py:114-127)
 //   fused_ra_kernel       RA: adjoint of R (second-order terms zR_l and the u_l operands of dW)
@@ -11,7 +14,8 @@
 
 namespace rnb {
 
-constexpr int FT = 64;
+constexpr int BTI = 1;          // row tiles per workgroup
+constexpr int BT = 32 * BTI;    // points per workgroup
 
 struct FusedBwdArgs {
   const float* packed;
@@ -34,7 +38,9 @@ struct FusedBwdArgs {
   int ld_fbar;
 };
 
-// visits the wave's 64 x 64 accumulator block: f(tj, ti, r, col, rowc, row) with rowc the lane-independent
+typedef float AuxTile[BTI][2][16];   // one value per accumulator element of the wave's BT x 64 block
+
+// visits the wave's BT x 64 accumulator block: f(tj, ti, r, col, rowc, row) with rowc the lane-independent
 // part of the row (compile-time after unrolling) and row = rowc + 4*(lane>>5)
 template <class F>
 __device__ inline void for_each_acc(int n0, int lane, F f) {
@@ -43,7 +49,7 @@ __device__ inline void for_each_acc(int n0, int lane, F f) {
   for (int tj = 0; tj < 2; ++tj) {
     const int col = n0 + tj * 32 + cl;
 #pragma unroll
-    for (int ti = 0; ti < 2; ++ti) {
+    for (int ti = 0; ti < BTI; ++ti) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int rowc = ti * 32 + (r & 3) + 8 * (r >> 2);
@@ -53,16 +59,25 @@ __device__ inline void for_each_acc(int n0, int lane, F f) {
   }
 }
 
+// issues the buffer loads of one [BT x 256] tile in accumulator layout (no wait: consumed after the MFMA loop)
+__device__ inline void prefetch_tile(const float* base, int64_t row0, int n0, int lane, AuxTile& t) {
+  const BufRsrc rs = tile_rsrc(base + (size_t)row0 * FH, BT * FH * 4);
+  const int h = lane >> 5;
+  for_each_acc(n0, lane, [&](int tj, int ti, int r, int col, int rowc, int row) {
+    t[ti][tj][r] = bload(rs, (unsigned)(4 * h * FH + col) * 4u, rowc * FH * 4);
+  });
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // R sweep
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void fused_reverse_kernel(FusedBwdArgs g) {
-  __shared__ __attribute__((aligned(16))) float lds[FT * FP + FT * FEP];
+  __shared__ __attribute__((aligned(16))) float lds[BT * FP + BT * FEP];
   float* X = lds;
-  float* GE = lds + FT * FP;   // d sdf / d e of the tile
+  float* GE = lds + BT * FP;   // d sdf / d e of the tile
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = wave_id();
-  const int64_t row0 = (int64_t)blockIdx.x * FT;
+  const int64_t row0 = (int64_t)blockIdx.x * BT;
   const int n0 = wave * 64;
   const int h = lane >> 5;
 
@@ -71,7 +86,7 @@ __global__ __launch_bounds__(256, 2) void fused_reverse_kernel(FusedBwdArgs g) {
     const float* Dl = g.D[g.nh - 1] + (size_t)row0 * FH;
     float* gzl = g.gz[g.nh - 1] + (size_t)row0 * FH;
     const float* ws = g.packed + g.wsdf_off;
-    for (int idx = tid; idx < FT * FH / 4; idx += 256) {
+    for (int idx = tid; idx < BT * FH / 4; idx += 256) {
       const int r = idx >> 6, c4 = idx & 63;
       const vf4 d = *reinterpret_cast<const vf4*>(Dl + r * FH + c4 * 4);
       const vf4 w = *reinterpret_cast<const vf4*>(ws + c4 * 4);
@@ -79,25 +94,26 @@ __global__ __launch_bounds__(256, 2) void fused_reverse_kernel(FusedBwdArgs g) {
       *reinterpret_cast<vf4*>(X + r * FP + c4 * 4) = v;
       *reinterpret_cast<vf4*>(gzl + r * FH + c4 * 4) = v;
     }
-    for (int idx = tid; idx < FT * FEP; idx += 256) GE[idx] = 0.f;
+    for (int idx = tid; idx < BT * FEP; idx += 256) GE[idx] = 0.f;
   }
   __syncthreads();
 
-  v16f acc[2][2];
+  v16f acc[BTI][2];
+  AuxTile aD;
   for (int l = g.nh - 1; l >= 1; --l) {
-    zero_acc2<2>(acc);
-    layer_mma_nt<2>(X, g.packed + g.wT_off[l], FH, n0, lane, acc);   // g = gz_l W_l  (columns = inputs of layer l)
+    zero_acc2<BTI>(acc);
+    layer_mma_nt<BTI>(X, g.packed + g.wT_off[l], FH, n0, lane, acc,   // g = gz_l W_l  (columns = inputs of layer l)
+                      [&]() { prefetch_tile(g.D[l - 1], row0, n0, lane, aD); });
     lds_barrier();
     const bool is_skip = (l == g.skip);
     const int ksplit = is_skip ? FH - g.pe : FH;   // columns that belong to layer l-1's output
-    const BufRsrc rD = tile_rsrc(g.D[l - 1] + (size_t)row0 * FH, FT * FH * 4);
-    const BufRsrc rg = tile_rsrc(g.gz[l - 1] + (size_t)row0 * FH, FT * FH * 4);
+    const BufRsrc rg = tile_rsrc(g.gz[l - 1] + (size_t)row0 * FH, BT * FH * 4);
     for_each_acc(n0, lane, [&](int tj, int ti, int r, int col, int rowc, int row) {
       const unsigned voff = (unsigned)(4 * h * FH + col) * 4u;
       const float v = acc[ti][tj][r];
       float gzv;
       if (col < ksplit) {
-        gzv = v * bload(rD, voff, rowc * FH * 4);
+        gzv = v * aD[ti][tj][r];
       } else {
         if (col < ksplit + g.pe) GE[row * FEP + (col - ksplit)] = v;   // skip connection: straight to g_e
         gzv = 0.f;
@@ -109,15 +125,15 @@ __global__ __launch_bounds__(256, 2) void fused_reverse_kernel(FusedBwdArgs g) {
   }
   // layer 0: g_e += gz_0 W_0 (Ep = 64 columns: wave 0 only)
   if (wave == 0) {
-    zero_acc2<2>(acc);
-    layer_mma_nt<2>(X, g.packed + g.wT_off[0], FH, 0, lane, acc);
+    zero_acc2<BTI>(acc);
+    layer_mma_nt<BTI>(X, g.packed + g.wT_off[0], FH, 0, lane, acc);
     for_each_acc(0, lane, [&](int tj, int ti, int r, int col, int rowc, int row) {
       if (col < g.pe) GE[row * FEP + col] += acc[ti][tj][r];
     });
   }
   __syncthreads();
   // normal = J_pe(x)^T g_e
-  if (tid < FT) {
+  if (tid < BT) {
     const int64_t row = row0 + tid;
     const float* ge = GE + tid * FEP;
     float n[3] = {ge[0], ge[1], ge[2]};
@@ -141,16 +157,16 @@ __global__ __launch_bounds__(256, 2) void fused_reverse_kernel(FusedBwdArgs g) {
 // RA sweep
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void fused_ra_kernel(FusedBwdArgs g) {
-  __shared__ __attribute__((aligned(16))) float lds[FT * FP + FT * FEP];
+  __shared__ __attribute__((aligned(16))) float lds[BT * FP + BT * FEP];
   float* X = lds;
-  float* E = lds + FT * FP;   // adjoint of g_e of the tile (re-enters at the skip connection)
+  float* E = lds + BT * FP;   // adjoint of g_e of the tile (re-enters at the skip connection)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = wave_id();
-  const int64_t row0 = (int64_t)blockIdx.x * FT;
+  const int64_t row0 = (int64_t)blockIdx.x * BT;
   const int n0 = wave * 64;
   const int h = lane >> 5;
 
-  for (int idx = tid; idx < FT * g.Ep; idx += 256) {
+  for (int idx = tid; idx < BT * g.Ep; idx += 256) {
     const int r = idx / g.Ep, c = idx - r * g.Ep;
     const float v = g.geb[(row0 + r) * g.Ep + c];
     X[r * FP + c] = v;
@@ -158,26 +174,28 @@ __global__ __launch_bounds__(256, 2) void fused_ra_kernel(FusedBwdArgs g) {
   }
   __syncthreads();
 
-  v16f acc[2][2];
+  v16f acc[BTI][2];
+  AuxTile aD, aG;
   for (int l = 0; l < g.nh; ++l) {
-    zero_acc2<2>(acc);
-    layer_mma_nt<2>(X, g.packed + g.w_off[l], g.Kp[l], n0, lane, acc);   // gzb = u_l W_l^T
+    zero_acc2<BTI>(acc);
+    layer_mma_nt<BTI>(X, g.packed + g.w_off[l], g.Kp[l], n0, lane, acc,   // gzb = u_l W_l^T
+                      [&]() {
+                        prefetch_tile(g.D[l], row0, n0, lane, aD);
+                        prefetch_tile(g.gz[l], row0, n0, lane, aG);
+                      });
     lds_barrier();
     const int n_real = g.n_real[l];
     const bool pe_tail = (l + 1 == g.skip);
-    const BufRsrc rD = tile_rsrc(g.D[l] + (size_t)row0 * FH, FT * FH * 4);
-    const BufRsrc rgz = tile_rsrc(g.gz[l] + (size_t)row0 * FH, FT * FH * 4);
-    const BufRsrc rzR = tile_rsrc(g.zR[l] + (size_t)row0 * FH, FT * FH * 4);
-    const BufRsrc ru = tile_rsrc(g.u[l + 1] + (size_t)row0 * FH, FT * FH * 4);
+    const BufRsrc rzR = tile_rsrc(g.zR[l] + (size_t)row0 * FH, BT * FH * 4);
+    const BufRsrc ru = tile_rsrc(g.u[l + 1] + (size_t)row0 * FH, BT * FH * 4);
     for_each_acc(n0, lane, [&](int tj, int ti, int r, int col, int rowc, int row) {
       const unsigned voff = (unsigned)(4 * h * FH + col) * 4u;
       const unsigned soff = rowc * FH * 4;
       const float v = acc[ti][tj][r];
       float zr, un;
       if (col < n_real) {
-        const float D = bload(rD, voff, soff);
-        const float gzv = bload(rgz, voff, soff);
-        zr = 100.f * v * gzv * (1.f - D);
+        const float D = aD[ti][tj][r];
+        zr = 100.f * v * aG[ti][tj][r] * (1.f - D);
         un = v * D;
       } else {
         zr = 0.f;
@@ -195,33 +213,34 @@ __global__ __launch_bounds__(256, 2) void fused_ra_kernel(FusedBwdArgs g) {
 // FB sweep
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void fused_fb_kernel(FusedBwdArgs g) {
-  __shared__ __attribute__((aligned(16))) float lds[FT * FP];
+  __shared__ __attribute__((aligned(16))) float lds[BT * FP];
   float* X = lds;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = wave_id();
-  const int64_t row0 = (int64_t)blockIdx.x * FT;
+  const int64_t row0 = (int64_t)blockIdx.x * BT;
   const int n0 = wave * 64;
   const int h = lane >> 5;
 
-  v16f acc[2][2];
-  zero_acc2<2>(acc);
+  v16f acc[BTI][2];
+  AuxTile aD, aZ;
+  prefetch_tile(g.D[g.nh - 1], row0, n0, lane, aD);
+  prefetch_tile(g.zR[g.nh - 1], row0, n0, lane, aZ);
+  zero_acc2<BTI>(acc);
   if (g.fbar != nullptr) {   // ab_{nh-1} = fbar W_feat (+ the sdf-head term below)
     const float* fb = g.fbar + (size_t)row0 * g.ld_fbar;
-    for (int idx = tid; idx < FT * FH / 4; idx += 256) {
+    for (int idx = tid; idx < BT * FH / 4; idx += 256) {
       const int r = idx >> 6, c4 = idx & 63;
       *reinterpret_cast<vf4*>(X + r * FP + c4 * 4) = *reinterpret_cast<const vf4*>(fb + (size_t)r * g.ld_fbar + c4 * 4);
     }
     __syncthreads();
-    layer_mma_nt<2>(X, g.packed + g.wfT_off, FH, n0, lane, acc);
+    layer_mma_nt<BTI>(X, g.packed + g.wfT_off, FH, n0, lane, acc);
     lds_barrier();
   }
   for (int l = g.nh - 1; l >= 0; --l) {
     // epilogue of the product that produced ab_l: zb_l = ab_l * D_l + zR_l
     const int n_real = g.n_real[l];
     const bool head = (l == g.nh - 1);
-    const BufRsrc rD = tile_rsrc(g.D[l] + (size_t)row0 * FH, FT * FH * 4);
-    const BufRsrc rzR = tile_rsrc(g.zR[l] + (size_t)row0 * FH, FT * FH * 4);
-    const BufRsrc rzb = tile_rsrc(g.zb[l] + (size_t)row0 * FH, FT * FH * 4);
+    const BufRsrc rzb = tile_rsrc(g.zb[l] + (size_t)row0 * FH, BT * FH * 4);
     for_each_acc(n0, lane, [&](int tj, int ti, int r, int col, int rowc, int row) {
       const unsigned voff = (unsigned)(4 * h * FH + col) * 4u;
       const unsigned soff = rowc * FH * 4;
@@ -229,15 +248,19 @@ __global__ __launch_bounds__(256, 2) void fused_fb_kernel(FusedBwdArgs g) {
       float zb = 0.f;
       if (col < n_real) {
         if (head) v = fmaf(g.sbar[row0 + row] * g.inv_scale, g.packed[g.wsdf_off + col], v);
-        zb = fmaf(v, bload(rD, voff, soff), bload(rzR, voff, soff));
+        zb = fmaf(v, aD[ti][tj][r], aZ[ti][tj][r]);
       }
       X[row * FP + col] = zb;
       bstore(rzb, voff, soff, zb);
     });
     lds_barrier();
     if (l == 0) break;
-    zero_acc2<2>(acc);
-    layer_mma_nt<2>(X, g.packed + g.wT_off[l], FH, n0, lane, acc);   // ab_{l-1} = zb_l W_l
+    zero_acc2<BTI>(acc);
+    layer_mma_nt<BTI>(X, g.packed + g.wT_off[l], FH, n0, lane, acc,   // ab_{l-1} = zb_l W_l
+                      [&]() {
+                        prefetch_tile(g.D[l - 1], row0, n0, lane, aD);
+                        prefetch_tile(g.zR[l - 1], row0, n0, lane, aZ);
+                      });
     lds_barrier();
   }
 }
@@ -281,7 +304,7 @@ int fused_reverse(const Layout& L, const float* packed, PointBufs& pb, hipStream
   FusedBwdArgs g;
   fill_args(L, packed, pb, g);
   ProfScope prof(hidden_flops(L, pb.M, 0), s);
-  hipLaunchKernelGGL(fused_reverse_kernel, dim3((unsigned)(pb.Mp / FT)), dim3(256), 0, s, g);
+  hipLaunchKernelGGL(fused_reverse_kernel, dim3((unsigned)(pb.Mp / BT)), dim3(256), 0, s, g);
   RNB_CHECK_LAUNCH();
   return RNB_OK;
 }
@@ -290,7 +313,7 @@ int fused_ra(const Layout& L, const float* packed, PointBufs& pb, hipStream_t s)
   FusedBwdArgs g;
   fill_args(L, packed, pb, g);
   ProfScope prof(hidden_flops(L, pb.M, 0), s);
-  hipLaunchKernelGGL(fused_ra_kernel, dim3((unsigned)(pb.Mp / FT)), dim3(256), 0, s, g);
+  hipLaunchKernelGGL(fused_ra_kernel, dim3((unsigned)(pb.Mp / BT)), dim3(256), 0, s, g);
   RNB_CHECK_LAUNCH();
   return RNB_OK;
 }
@@ -301,7 +324,7 @@ int fused_fb(const Layout& L, const float* packed, PointBufs& pb, bool with_colo
   g.fbar = with_color ? pb.cinb : nullptr;
   g.ld_fbar = L.Cinp;
   ProfScope prof(hidden_flops(L, pb.M, 1) + (with_color ? 2.0 * (double)pb.M * L.F * L.H : 0.0), s);
-  hipLaunchKernelGGL(fused_fb_kernel, dim3((unsigned)(pb.Mp / FT)), dim3(256), 0, s, g);
+  hipLaunchKernelGGL(fused_fb_kernel, dim3((unsigned)(pb.Mp / BT)), dim3(256), 0, s, g);
   RNB_CHECK_LAUNCH();
   return RNB_OK;
 }

@@ -36,11 +36,19 @@ __device__ inline void load_b_block(const float* __restrict__ W, int K, int n0, 
   }
 }
 
-template <int TI>
+struct NoHook {
+  __device__ void operator()() const {}
+};
+// `hook` runs once inside the loop (second 32-k block, after that block's weight prefetch has been issued):
+// the place to issue the epilogue's operand loads.  The vector-memory counter retires in order, so loads
+// issued before the first weight block would have to land before the first MFMA; issued here they have one
+// and a half blocks of matrix work to land.
+template <int TI, class Hook = NoHook>
 __device__ inline void layer_mma_nt(const float* __restrict__ X, const float* __restrict__ W, int K, int n0, int lane,
-                                    v16f (&acc)[TI][2]) {
+                                    v16f (&acc)[TI][2], Hook hook = Hook()) {
   const int i = lane & 31, h = lane >> 5;
   const int nQ = K / 32;
+  const int hookQ = nQ > 2 ? 1 : 0;
   vf4 bn[2][4];
   load_b_block(W, K, n0, 0, lane, bn);
   for (int Q = 0; Q < nQ; ++Q) {
@@ -50,6 +58,7 @@ __device__ inline void layer_mma_nt(const float* __restrict__ X, const float* __
 #pragma unroll
       for (int q = 0; q < 4; ++q) b[tj][q] = bn[tj][q];
     if (Q + 1 < nQ) load_b_block(W, K, n0, Q + 1, lane, bn);
+    if (Q == hookQ) hook();
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       vf4 a[TI];
