@@ -228,7 +228,8 @@ int fused_forward(const Layout& L, const float* packed, const float* pts, int64_
   if (need_feat) fl += 2.0 * (double)M * L.F * L.H;
   ProfScope prof(fl, s);
   // 64-point tiles when that still gives every CU >= 2 workgroups, 32-point tiles for small batches
-  const bool small = pb.Mp / 64 < 512;
+  static const char* force_ti = getenv("RNB_FWD_TI");   // tuning knob: "1" or "2" forces the tile height
+  const bool small = force_ti ? (force_ti[0] == '1') : (pb.Mp / 64 < 512);
   if (small) {
     const unsigned blocks = (unsigned)(pb.Mp / 32);
     if (save) hipLaunchKernelGGL((fused_forward_kernel<1, true>), dim3(blocks), dim3(256), 0, s, g);

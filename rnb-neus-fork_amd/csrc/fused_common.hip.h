@@ -1,5 +1,7 @@
 // Shared device helpers of the fused SDF-network sweeps (fused.hip, fused_bwd.hip).
 #pragma once
+#include <stdlib.h>
+
 #include "gemm.hip.h"
 #include "rnb_internal.h"
 
