@@ -36,6 +36,7 @@ struct FusedBwdArgs {
   const float* sbar;    // [Mp]        (FB)
   const float* fbar;    // [Mp,ld_fbar] first 256 columns, or nullptr (FB, no_albedo)
   int ld_fbar;
+  int hook_late, stagger;   // tuning knobs (RNB_HOOK_LATE, RNB_STAGGER)
 };
 
 typedef float AuxTile[BTI][2][16];   // one value per accumulator element of the wave's BT x 64 block
@@ -80,6 +81,7 @@ __global__ __launch_bounds__(256, 2) void fused_reverse_kernel(FusedBwdArgs g) {
   const int64_t row0 = (int64_t)blockIdx.x * BT;
   const int n0 = wave * 64;
   const int h = lane >> 5;
+  stagger_start(g.stagger);
 
   // seed: gz_{nh-1} = w_sdf * D_{nh-1}  (row 0 of the output layer is d sdf / d a_last)
   {
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(256, 2) void fused_reverse_kernel(FusedBwdArgs g) {
   for (int l = g.nh - 1; l >= 1; --l) {
     zero_acc2<BTI>(acc);
     layer_mma_nt<BTI>(X, g.packed + g.wT_off[l], FH, n0, lane, acc,   // g = gz_l W_l  (columns = inputs of layer l)
-                      [&]() { prefetch_tile(g.D[l - 1], row0, n0, lane, aD); });
+                      [&]() { prefetch_tile(g.D[l - 1], row0, n0, lane, aD); }, g.hook_late);
     lds_barrier();
     const bool is_skip = (l == g.skip);
     const int ksplit = is_skip ? FH - g.pe : FH;   // columns that belong to layer l-1's output
@@ -165,6 +167,7 @@ __global__ __launch_bounds__(256, 2) void fused_ra_kernel(FusedBwdArgs g) {
   const int64_t row0 = (int64_t)blockIdx.x * BT;
   const int n0 = wave * 64;
   const int h = lane >> 5;
+  stagger_start(g.stagger);
 
   for (int idx = tid; idx < BT * g.Ep; idx += 256) {
     const int r = idx / g.Ep, c = idx - r * g.Ep;
@@ -182,7 +185,7 @@ __global__ __launch_bounds__(256, 2) void fused_ra_kernel(FusedBwdArgs g) {
                       [&]() {
                         prefetch_tile(g.D[l], row0, n0, lane, aD);
                         prefetch_tile(g.gz[l], row0, n0, lane, aG);
-                      });
+                      }, g.hook_late);
     lds_barrier();
     const int n_real = g.n_real[l];
     const bool pe_tail = (l + 1 == g.skip);
@@ -220,6 +223,7 @@ __global__ __launch_bounds__(256, 2) void fused_fb_kernel(FusedBwdArgs g) {
   const int64_t row0 = (int64_t)blockIdx.x * BT;
   const int n0 = wave * 64;
   const int h = lane >> 5;
+  stagger_start(g.stagger);
 
   v16f acc[BTI][2];
   AuxTile aD, aZ;
@@ -260,7 +264,7 @@ __global__ __launch_bounds__(256, 2) void fused_fb_kernel(FusedBwdArgs g) {
                       [&]() {
                         prefetch_tile(g.D[l - 1], row0, n0, lane, aD);
                         prefetch_tile(g.zR[l - 1], row0, n0, lane, aZ);
-                      });
+                      }, g.hook_late);
     lds_barrier();
   }
 }
@@ -292,6 +296,10 @@ static void fill_args(const Layout& L, const float* packed, PointBufs& pb, Fused
   g.nrm = pb.nrm;
   g.geb = pb.geb;
   g.sbar = pb.sbar;
+  static const char* hl = getenv("RNB_HOOK_LATE");
+  static const char* sg = getenv("RNB_STAGGER");
+  g.hook_late = hl ? atoi(hl) : 0;
+  g.stagger = sg ? atoi(sg) : 0;
 }
 
 static double hidden_flops(const Layout& L, int64_t M, int first) {

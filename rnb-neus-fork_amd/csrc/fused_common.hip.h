@@ -47,10 +47,13 @@ struct NoHook {
 // and a half blocks of matrix work to land.
 template <int TI, class Hook = NoHook>
 __device__ inline void layer_mma_nt(const float* __restrict__ X, const float* __restrict__ W, int K, int n0, int lane,
-                                    v16f (&acc)[TI][2], Hook hook = Hook()) {
+                                    v16f (&acc)[TI][2], Hook hook = Hook(), int hook_late = 0) {
   const int i = lane & 31, h = lane >> 5;
   const int nQ = K / 32;
-  const int hookQ = nQ > 2 ? 1 : 0;
+  // early: second block (the loads must land before the weight block issued after them is consumed, i.e.
+  // within ~1.5 blocks); late: second-to-last block (no younger weight load exists, the wait moves into
+  // the epilogue and only the last block's matrix work overlaps the latency)
+  const int hookQ = hook_late ? (nQ >= 2 ? nQ - 2 : 0) : (nQ > 2 ? 1 : 0);
   vf4 bn[2][4];
   load_b_block(W, K, n0, 0, lane, bn);
   for (int Q = 0; Q < nQ; ++Q) {
@@ -90,6 +93,14 @@ __device__ inline void zero_acc2(v16f (&acc)[TI][2]) {
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 }
 
+
+// optional start-up stagger: every other group of 8 workgroups sleeps `units` x 64 cycles so that the
+// workgroups sharing a CU do not run their matrix phases and epilogues in lockstep (tuning knob)
+__device__ inline void stagger_start(int units) {
+  if (units > 0 && ((blockIdx.x >> 3) & 1)) {
+    for (int i = 0; i < units; i += 64) __builtin_amdgcn_s_sleep(64);
+  }
+}
 
 __device__ inline float bload(BufRsrc r, unsigned voff, unsigned soff) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
