@@ -39,9 +39,14 @@ struct FusedFwdArgs {
 template <int TI, bool SAVE>
 __global__ __launch_bounds__(256, 2) void fused_forward_kernel(FusedFwdArgs g) {
   constexpr int FT = 32 * TI;
-  __shared__ __attribute__((aligned(16))) float lds[FT * FP + FT * FEP];
+  // TI == 1: two activation tiles (a layer reads one, writes the other: one barrier per layer);
+  // TI == 2: one tile updated in place behind a second barrier (two tiles would not leave room for two
+  // workgroups per CU)
+  constexpr int NBUF = TI == 1 ? 2 : 1;
+  __shared__ __attribute__((aligned(16))) float lds[NBUF * FT * FP + FT * FEP];
   float* X = lds;
-  float* E = lds + FT * FP;
+  float* Y = lds + (NBUF - 1) * FT * FP;
+  float* E = lds + NBUF * FT * FP;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = wave_id();
   const int64_t row0 = (int64_t)blockIdx.x * FT;
@@ -94,7 +99,7 @@ __global__ __launch_bounds__(256, 2) void fused_forward_kernel(FusedFwdArgs g) {
   for (int l = 0; l < g.nh; ++l) {
     zero_acc2<TI>(acc);
     layer_mma_nt<TI>(X, g.packed + g.w_off[l], g.Kp[l], n0, lane, acc);
-    lds_barrier();   // every wave has finished reading the input activations
+    if constexpr (NBUF == 1) lds_barrier();   // every wave has finished reading the input activations
     const float* bias = g.packed + g.b_off[l];
     // saved state goes out through buffer stores: one 32-bit lane offset per column tile plus a
     // compile-time row offset in the scalar operand (plain pointer stores cost a 64-bit VGPR address
@@ -124,7 +129,7 @@ __global__ __launch_bounds__(256, 2) void fused_forward_kernel(FusedFwdArgs g) {
             a = (pe_tail && col < n_real + g.pe) ? E[row * FEP + (col - n_real)] : 0.f;
             D = 0.f;
           }
-          X[row * FP + col] = a;
+          Y[row * FP + col] = a;
           if (SAVE) {
             bstore(ra, voff, rowc * FH * 4, a);
             bstore(rD, voff, rowc * FH * 4, D);
@@ -134,6 +139,7 @@ __global__ __launch_bounds__(256, 2) void fused_forward_kernel(FusedFwdArgs g) {
       }
     }
     lds_barrier();   // the new activations are visible to every wave
+    if constexpr (NBUF == 2) { float* t = X; X = Y; Y = t; }
   }
 
   // ---- sdf head: row 0 of the output layer (models/fields.py:104, :106-108) -----------------------------

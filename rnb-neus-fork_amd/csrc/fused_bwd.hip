@@ -73,9 +73,11 @@ __device__ inline void prefetch_tile(const float* base, int64_t row0, int n0, in
 // R sweep
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void fused_reverse_kernel(FusedBwdArgs g) {
-  __shared__ __attribute__((aligned(16))) float lds[BT * FP + BT * FEP];
-  float* X = lds;
-  float* GE = lds + BT * FP;   // d sdf / d e of the tile
+  // two activation tiles (ping-pong): a layer reads one and writes the other, so one barrier per layer
+  __shared__ __attribute__((aligned(16))) float lds[2 * BT * FP + BT * FEP];
+  float* X = lds;              // input of the current layer
+  float* Y = lds + BT * FP;    // output of the current layer
+  float* GE = lds + 2 * BT * FP;   // d sdf / d e of the tile
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = wave_id();
   const int64_t row0 = (int64_t)blockIdx.x * BT;
@@ -106,7 +108,6 @@ __global__ __launch_bounds__(256, 2) void fused_reverse_kernel(FusedBwdArgs g) {
     zero_acc2<BTI>(acc);
     layer_mma_nt<BTI>(X, g.packed + g.wT_off[l], FH, n0, lane, acc,   // g = gz_l W_l  (columns = inputs of layer l)
                       [&]() { prefetch_tile(g.D[l - 1], row0, n0, lane, aD); }, g.hook_late);
-    lds_barrier();
     const bool is_skip = (l == g.skip);
     const int ksplit = is_skip ? FH - g.pe : FH;   // columns that belong to layer l-1's output
     const BufRsrc rg = tile_rsrc(g.gz[l - 1] + (size_t)row0 * FH, BT * FH * 4);
@@ -120,10 +121,11 @@ __global__ __launch_bounds__(256, 2) void fused_reverse_kernel(FusedBwdArgs g) {
         if (col < ksplit + g.pe) GE[row * FEP + (col - ksplit)] = v;   // skip connection: straight to g_e
         gzv = 0.f;
       }
-      X[row * FP + col] = gzv;
+      Y[row * FP + col] = gzv;
       bstore(rg, voff, rowc * FH * 4, gzv);
     });
     lds_barrier();
+    { float* t = X; X = Y; Y = t; }
   }
   // layer 0: g_e += gz_0 W_0 (Ep = 64 columns: wave 0 only)
   if (wave == 0) {
@@ -159,9 +161,10 @@ __global__ __launch_bounds__(256, 2) void fused_reverse_kernel(FusedBwdArgs g) {
 // RA sweep
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void fused_ra_kernel(FusedBwdArgs g) {
-  __shared__ __attribute__((aligned(16))) float lds[BT * FP + BT * FEP];
-  float* X = lds;
-  float* E = lds + BT * FP;   // adjoint of g_e of the tile (re-enters at the skip connection)
+  __shared__ __attribute__((aligned(16))) float lds[2 * BT * FP + BT * FEP];
+  float* X = lds;              // ping-pong activation tiles (one barrier per layer)
+  float* Y = lds + BT * FP;
+  float* E = lds + 2 * BT * FP;   // adjoint of g_e of the tile (re-enters at the skip connection)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = wave_id();
   const int64_t row0 = (int64_t)blockIdx.x * BT;
@@ -186,7 +189,6 @@ __global__ __launch_bounds__(256, 2) void fused_ra_kernel(FusedBwdArgs g) {
                         prefetch_tile(g.D[l], row0, n0, lane, aD);
                         prefetch_tile(g.gz[l], row0, n0, lane, aG);
                       }, g.hook_late);
-    lds_barrier();
     const int n_real = g.n_real[l];
     const bool pe_tail = (l + 1 == g.skip);
     const BufRsrc rzR = tile_rsrc(g.zR[l] + (size_t)row0 * FH, BT * FH * 4);
@@ -204,11 +206,12 @@ __global__ __launch_bounds__(256, 2) void fused_ra_kernel(FusedBwdArgs g) {
         zr = 0.f;
         un = (pe_tail && col < n_real + g.pe) ? E[row * FEP + (col - n_real)] : 0.f;
       }
-      X[row * FP + col] = un;
+      Y[row * FP + col] = un;
       bstore(rzR, voff, soff, zr);
       bstore(ru, voff, soff, un);
     });
     lds_barrier();
+    { float* t = X; X = Y; Y = t; }
   }
 }
 
@@ -216,8 +219,9 @@ __global__ __launch_bounds__(256, 2) void fused_ra_kernel(FusedBwdArgs g) {
 // FB sweep
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void fused_fb_kernel(FusedBwdArgs g) {
-  __shared__ __attribute__((aligned(16))) float lds[BT * FP];
-  float* X = lds;
+  __shared__ __attribute__((aligned(16))) float lds[2 * BT * FP];
+  float* X = lds;              // ping-pong activation tiles (one barrier per layer)
+  float* Y = lds + BT * FP;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = wave_id();
   const int64_t row0 = (int64_t)blockIdx.x * BT;
@@ -238,7 +242,6 @@ __global__ __launch_bounds__(256, 2) void fused_fb_kernel(FusedBwdArgs g) {
     }
     __syncthreads();
     layer_mma_nt<BTI>(X, g.packed + g.wfT_off, FH, n0, lane, acc);
-    lds_barrier();
   }
   for (int l = g.nh - 1; l >= 0; --l) {
     // epilogue of the product that produced ab_l: zb_l = ab_l * D_l + zR_l
@@ -254,18 +257,18 @@ __global__ __launch_bounds__(256, 2) void fused_fb_kernel(FusedBwdArgs g) {
         if (head) v = fmaf(g.sbar[row0 + row] * g.inv_scale, g.packed[g.wsdf_off + col], v);
         zb = fmaf(v, aD[ti][tj][r], aZ[ti][tj][r]);
       }
-      X[row * FP + col] = zb;
+      Y[row * FP + col] = zb;
       bstore(rzb, voff, soff, zb);
     });
-    lds_barrier();
     if (l == 0) break;
+    lds_barrier();
+    { float* t = X; X = Y; Y = t; }
     zero_acc2<BTI>(acc);
     layer_mma_nt<BTI>(X, g.packed + g.wT_off[l], FH, n0, lane, acc,   // ab_{l-1} = zb_l W_l
                       [&]() {
                         prefetch_tile(g.D[l - 1], row0, n0, lane, aD);
                         prefetch_tile(g.zR[l - 1], row0, n0, lane, aZ);
                       }, g.hook_late);
-    lds_barrier();
   }
 }
 

@@ -78,6 +78,8 @@ __device__ inline void layer_mma_nt(const float* __restrict__ X, const float* __
           for (int ti = 0; ti < TI; ++ti)
             acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ti][c], b[tj][q][c], acc[ti][tj], 0, 0, 0);
       }
+      // TI = 2 runs at the register cap: keep each k-group's fragment reads behind the previous group's
+      // MFMAs.  TI = 1 has room, so the scheduler may hoist the next groups' LDS reads over the MFMAs.
       __builtin_amdgcn_sched_barrier(0);
     }
   }
