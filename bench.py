@@ -94,10 +94,18 @@ def main():
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     assert torch.cuda.is_available(), "bench.py needs a GPU (the renderer has no CPU path)"
+    # one process per GPU; RNB_SHARE_GPU=1 (functional rehearsal of the N>1 path on a one-GPU box, with
+    # RNB_DIST_BACKEND=gloo) puts every rank on device 0
+    if os.environ.get("RNB_SHARE_GPU"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("RNB_DIST_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     n_gpus = world
     if args.gpus != n_gpus and rank == 0:
         print(f"[bench] --gpus {args.gpus} but WORLD_SIZE {world}: using {world}", file=sys.stderr)
@@ -115,7 +123,12 @@ def main():
     params = list(sdf.parameters()) + list(devnet.parameters())
     if not args.no_albedo:
         params += list(col.parameters())
-    opt = torch.optim.Adam(params, lr=5e-4)   # exp_runner.py:115
+    # exp_runner.py:115 (same optimizer and hyper-parameters; `fused=True` only selects PyTorch's
+    # multi-tensor single-kernel implementation of the identical update)
+    try:
+        opt = torch.optim.Adam(params, lr=5e-4, fused=True)
+    except Exception:   # pragma: no cover
+        opt = torch.optim.Adam(params, lr=5e-4)
 
     B = args.rays
     n_batches = 8
