@@ -297,8 +297,25 @@ __global__ __launch_bounds__(256, 3) void gemm_dw_kernel(DwPair p1, DwPair p2, i
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = wave_id();
   const int wm = wave >> 1, wn = wave & 1;
-  const int n_blk = blockIdx.x * 128, k_blk = blockIdx.y * 128;
-  const int m_begin = blockIdx.z * rows_per_split;
+  // 1-D grid of tiles_n * tiles_k * splits blocks.  Workgroups are dealt round-robin over the 8 XCDs
+  // (blocks b and b+8 share an L2), so the tiles of one point-split are placed on ONE XCD in consecutive
+  // dispatch slots: the X / Y chunks they share are then served by that XCD's L2 instead of being fetched
+  // once per tile.  Pure placement heuristic: any mapping is correct.
+  const int tiles_n = (N + 127) / 128, tiles_k = (K + 127) / 128;
+  const int nt = tiles_n * tiles_k;
+  const int splits = gridDim.x / nt;
+  int tile, split;
+  if (splits % 8 == 0) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    tile = j % nt;
+    split = (j / nt) * 8 + xcd;
+  } else {
+    tile = blockIdx.x % nt;
+    split = blockIdx.x / nt;
+  }
+  const int tile_n = tile % tiles_n, tile_k = tile / tiles_n;
+  const int n_blk = tile_n * 128, k_blk = tile_k * 128;
+  const int m_begin = split * rows_per_split;
   const int m_end = min(M, m_begin + rows_per_split);
   unsigned mask = 0;
 #pragma unroll
@@ -308,7 +325,7 @@ __global__ __launch_bounds__(256, 3) void gemm_dw_kernel(DwPair p1, DwPair p2, i
   v16f acc[2][2];
   zero_acc<2>(acc);
   double bsum = 0.0;   // bias gradients are long signed sums: keep the per-block partial in fp64
-  const bool bias_blk = (db != nullptr) && blockIdx.y == 0 && tid < 128 && (n_blk + tid < N);
+  const bool bias_blk = (db != nullptr) && tile_k == 0 && tid < 128 && (n_blk + tid < N);
 
   if (m_begin < m_end) {
     for (int pi = 0; pi < npairs; ++pi) {

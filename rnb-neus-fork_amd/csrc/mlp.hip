@@ -486,10 +486,12 @@ static int launch_dw(DwPair p1, DwPair p2, int npairs, int64_t M, int N, int K, 
   const int max_splits = (1024 + tiles - 1) / tiles;  // ~1024 blocks in flight
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
+  if (splits >= 8) splits = splits / 8 * 8;   // multiple of 8: enables the XCD-aware placement in the kernel
   int rows = (int)((M + splits - 1) / splits);
   rows = (rows + BK - 1) / BK * BK;
-  splits = (int)((M + rows - 1) / rows);
-  dim3 grid((unsigned)((N + 127) / 128), (unsigned)((K + 127) / 128), (unsigned)splits);
+  // (the kernel tolerates empty splits, so the grid keeps the multiple-of-8 split count)
+  if ((int64_t)rows * splits < M) splits = (int)((M + rows - 1) / rows);
+  dim3 grid((unsigned)(tiles * splits));
   ProfScope prof(flops, s);
   if (N % 128 == 0 && K % 128 == 0 && M % BK == 0)
     hipLaunchKernelGGL(gemm_dw_kernel<false>, grid, dim3(256), 0, s, p1, p2, npairs, (int)M, N, K, rows, dW, lddw,

@@ -191,7 +191,7 @@ int main(int argc, char** argv) {
     DwPair p1{X1, N, A, K}, p2{X2, N, A, K};
     const int splits = 256, rows = M / splits;
     report("dW 2 pairs (atomics)", time_it([&] {
-             hipLaunchKernelGGL(gemm_dw_kernel<false>, dim3(2, 2, splits), dim3(256), 0, 0, p1, p2, 2, M, N, K, rows, dW, K, (float*)nullptr, 1);
+             hipLaunchKernelGGL(gemm_dw_kernel<false>, dim3(4 * splits), dim3(256), 0, 0, p1, p2, 2, M, N, K, rows, dW, K, (float*)nullptr, 1);
            }, iters), 2 * flops);
   }
   // correctness spot check of the NT kernel against a host dot product
