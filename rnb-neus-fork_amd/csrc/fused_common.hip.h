@@ -41,47 +41,53 @@ __device__ inline void load_b_block(const float* __restrict__ W, int K, int n0, 
 struct NoHook {
   __device__ void operator()() const {}
 };
-// `hook` runs once inside the loop (second 32-k block, after that block's weight prefetch has been issued):
-// the place to issue the epilogue's operand loads.  The vector-memory counter retires in order, so loads
-// issued before the first weight block would have to land before the first MFMA; issued here they have one
-// and a half blocks of matrix work to land.
+
+// the 4 k-groups (x 4 MFMA k-steps) of one 32-k block with the block's weight fragments in `b`
+template <int TI>
+__device__ inline void mma_block(const float* __restrict__ X, int Q, int i, int h, const vf4 (&b)[2][4],
+                                 v16f (&acc)[TI][2]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    vf4 a[TI];
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti)
+      a[ti] = *reinterpret_cast<const vf4*>(X + (ti * 32 + i) * FP + Q * 32 + h * 16 + q * 4);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti)
+          acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ti][c], b[tj][q][c], acc[ti][tj], 0, 0, 0);
+    }
+    // keep each k-group's fragment reads behind the previous group's MFMAs (hoisting them all costs
+    // registers and, measured, 15 % of the matrix-pipe utilisation)
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// C[rows][n0..n0+63] += X[rows][K] * W[n][K]^T for one wave; K a multiple of 64.  Weight fragments are
+// prefetched one 32-k block ahead into two alternating register sets (no copies: on gfx950 the fp32 MFMA
+// shares the SIMD's issue bandwidth with ordinary vector instructions, so every v_mov in this loop is
+// matrix time lost).  `hook` runs once inside the loop, after a block's weight prefetch has been issued:
+// the place to issue the epilogue's operand loads (the vector-memory counter retires in order, so loads
+// issued before the first weight block would have to land before the first MFMA).  hook_late: run it in
+// the second-to-last block instead of the second.
 template <int TI, class Hook = NoHook>
 __device__ inline void layer_mma_nt(const float* __restrict__ X, const float* __restrict__ W, int K, int n0, int lane,
                                     v16f (&acc)[TI][2], Hook hook = Hook(), int hook_late = 0) {
   const int i = lane & 31, h = lane >> 5;
-  const int nQ = K / 32;
-  // early: second block (the loads must land before the weight block issued after them is consumed, i.e.
-  // within ~1.5 blocks); late: second-to-last block (no younger weight load exists, the wait moves into
-  // the epilogue and only the last block's matrix work overlaps the latency)
+  const int nQ = K / 32;   // even
   const int hookQ = hook_late ? (nQ >= 2 ? nQ - 2 : 0) : (nQ > 2 ? 1 : 0);
-  vf4 bn[2][4];
-  load_b_block(W, K, n0, 0, lane, bn);
-  for (int Q = 0; Q < nQ; ++Q) {
-    vf4 b[2][4];
-#pragma unroll
-    for (int tj = 0; tj < 2; ++tj)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) b[tj][q] = bn[tj][q];
-    if (Q + 1 < nQ) load_b_block(W, K, n0, Q + 1, lane, bn);
+  vf4 b0[2][4], b1[2][4];
+  load_b_block(W, K, n0, 0, lane, b0);
+  for (int Q = 0; Q < nQ; Q += 2) {
+    load_b_block(W, K, n0, Q + 1, lane, b1);
     if (Q == hookQ) hook();
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      vf4 a[TI];
-#pragma unroll
-      for (int ti = 0; ti < TI; ++ti)
-        a[ti] = *reinterpret_cast<const vf4*>(X + (ti * 32 + i) * FP + Q * 32 + h * 16 + q * 4);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-#pragma unroll
-        for (int tj = 0; tj < 2; ++tj)
-#pragma unroll
-          for (int ti = 0; ti < TI; ++ti)
-            acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ti][c], b[tj][q][c], acc[ti][tj], 0, 0, 0);
-      }
-      // TI = 2 runs at the register cap: keep each k-group's fragment reads behind the previous group's
-      // MFMAs.  TI = 1 has room, so the scheduler may hoist the next groups' LDS reads over the MFMAs.
-      __builtin_amdgcn_sched_barrier(0);
-    }
+    mma_block<TI>(X, Q, i, h, b0, acc);
+    if (Q + 2 < nQ) load_b_block(W, K, n0, Q + 2, lane, b0);
+    if (Q + 1 == hookQ) hook();
+    mma_block<TI>(X, Q + 1, i, h, b1, acc);
   }
 }
 
@@ -99,7 +105,9 @@ __device__ inline void zero_acc2(v16f (&acc)[TI][2]) {
 // optional start-up stagger: every other group of 8 workgroups sleeps `units` x 64 cycles so that the
 // workgroups sharing a CU do not run their matrix phases and epilogues in lockstep (tuning knob)
 __device__ inline void stagger_start(int units) {
-  if (units > 0 && ((blockIdx.x >> 3) & 1)) {
+  // the two workgroups that share a CU at start-up are either dispatch neighbours on one XCD (b, b+8) or a
+  // first-round / second-round pair (b, b+256): flip the parity for both patterns
+  if (units > 0 && (((blockIdx.x >> 3) ^ (blockIdx.x >> 8)) & 1)) {
     for (int i = 0; i < units; i += 64) __builtin_amdgcn_s_sleep(64);
   }
 }
