@@ -1,0 +1,74 @@
+"""Data-parallel path on the device: two ranks (sharing the one GPU of the test box, gloo transport) render
+their shards of one ray batch with `set_data_parallel()`; the gradients every rank ends up with must equal
+the mean of the two ranks' local (non-DP) gradients.  On the 8-GPU node the same code runs one rank per GPU
+over RCCL (bench.py)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import rnb_neus_fork_amd as R
+    from rnb_neus_fork_amd import parallel as P
+    from oracle import rnb_oracle as O
+    dev = torch.device("cuda:0")
+    mc = O.ModelConf(sdf=O.SDFConf(d_out=65, d_hidden=64), color=O.ColorConf(d_feature=64, d_hidden=64),
+                     render=O.RenderConf(n_samples=16, n_importance=16))
+    torch.manual_seed(0)
+    p = O.init_params(mc)
+    sdf, devn, col, ren = R.build_from_named_params(mc, p, dev)
+    P.broadcast_parameters([sdf, devn, col])
+    batch = O.synthetic_batch(16, seed=9, step=2, warmup=False)
+    mine = {k: v.to(dev) for k, v in P.shard_batch(batch, rank, world).items()}
+    leaves = list(sdf.parameters()) + list(devn.parameters()) + list(col.parameters())
+
+    def grads(dp):
+        ren.set_data_parallel(enabled=dp)
+        for x in leaves:
+            x.grad = None
+        out = ren.render_rnb(mine["rays_o"], mine["rays_d"], mine["near"], mine["far"], mine["lights_dir"],
+                             cos_anneal_ratio=1.0, t_rand=mine["t_rand"])
+        O.rnb_loss(out, mine["true_rgb"], mine["mask"])[0].backward()
+        torch.cuda.synchronize()
+        return torch.cat([x.grad.reshape(-1) for x in leaves]).clone()
+
+    g_local = grads(False)
+    g_dp = grads(True)
+    gathered = [torch.empty_like(g_local) for _ in range(world)]
+    dist.all_gather(gathered, g_local)
+    expect = sum(gathered) / world
+    rel = float((g_dp - expect).norm() / expect.norm())
+    differs = float((gathered[0] - gathered[1]).norm() / expect.norm())
+    q.put((rank, rel, differs))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradients_are_the_mean_of_local_gradients():
+    assert torch.cuda.is_available()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    for rank, rel, differs in res:
+        assert rel < 1e-5, f"rank {rank}: DP gradient differs from the mean of local gradients by {rel:.2e}"
+        assert differs > 1e-3, "the two shards should produce different local gradients"
