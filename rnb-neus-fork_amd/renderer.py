@@ -87,6 +87,9 @@ class _FinePass(torch.autograd.Function):
         ctx.renderer, ctx.call, ctx.args, ctx.keep, ctx.ws, ctx.out = renderer, call, args, keep, ws, out
         ctx.n_leaves = len(leaves)
         ctx.mark_non_differentiable(out["inside_sphere"])
+        # outputs the loss does not touch arrive as None in backward (no zero tensors are materialised;
+        # the native backward treats a NULL cotangent as zero)
+        ctx.set_materialize_grads(False)
         renderer.last_extras = extras
         return tuple(out[k] for k in _OUT_KEYS)
 

@@ -17,7 +17,7 @@ typedef float vf4 __attribute__((ext_vector_type(4)));
 
 constexpr int FP = 260;
 
-template <bool A_LDS, bool B_GLB, bool BAR, bool SCHED, int TI, bool PIPE = false>
+template <bool A_LDS, bool B_GLB, bool BAR, bool SCHED, int TI, bool PIPE = false, int EPI = 0>
 __global__ __launch_bounds__(256, 2) void probe_kernel(const float* __restrict__ W, float* __restrict__ out, int layers) {
   __shared__ __attribute__((aligned(16))) float X[32 * TI * FP];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -79,8 +79,35 @@ __global__ __launch_bounds__(256, 2) void probe_kernel(const float* __restrict__
     }
     if (BAR) {
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      // light epilogue: touch one LDS element per lane so the barrier pair has something to order
-      X[(lane & 31) * FP + n0 + (lane >> 5)] = acc[0][0][0];
+      if (EPI == 0) {
+        // light epilogue: touch one LDS element per lane so the barrier pair has something to order
+        X[(lane & 31) * FP + n0 + (lane >> 5)] = acc[0][0][0];
+      } else {
+        // heavy epilogue: ~EPI-flavoured VALU work per accumulator element + LDS write (+ global stores)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+          for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int row = ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+              const int col = n0 + tj * 32 + i;
+              float v = acc[ti][tj][r] * 1e-6f;
+              float t = fminf(fmaxf(v * 100.f, -87.f), 20.f);
+              float e = __builtin_amdgcn_exp2f(t * 1.44269504f);
+              float u = 1.f + e;
+              float lg = __builtin_amdgcn_logf(u) * 0.69314718f;
+              float a = (t > 19.f) ? v : lg * 0.01f * (e * __builtin_amdgcn_rcpf(u == 1.f ? 1.f : u - 1.f));
+              float D = e * __builtin_amdgcn_rcpf(u);
+              X[row * FP + col] = a;
+              if (EPI == 2) {
+                out[((size_t)blockIdx.x * 32 * TI + row) * 256 + col] = a;
+                out[((size_t)(gridDim.x + blockIdx.x) * 32 * TI + row) * 256 + col] = D;
+              } else {
+                acc[ti][tj][r] = D;   // keep D live
+              }
+            }
+      }
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
   }
@@ -103,10 +130,10 @@ static float time_it(F f, int iters) {
   return ms * 1e3f / iters;
 }
 
-template <bool A, bool B, bool BAR, bool S, int TI, bool PIPE = false>
+template <bool A, bool B, bool BAR, bool S, int TI, bool PIPE = false, int EPI = 0>
 static void run(const char* name, const float* W, float* out, int wgs) {
   const int layers = 8;
-  float us = time_it([&] { hipLaunchKernelGGL((probe_kernel<A, B, BAR, S, TI, PIPE>), dim3(wgs), dim3(256), 0, 0, W, out, layers); }, 10);
+  float us = time_it([&] { hipLaunchKernelGGL((probe_kernel<A, B, BAR, S, TI, PIPE, EPI>), dim3(wgs), dim3(256), 0, 0, W, out, layers); }, 10);
   const double fl = (double)wgs * layers * 2.0 * (32 * TI) * 256 * 256;
   printf("%-44s TI=%d wgs=%5d %9.1f us %7.1f TFLOP/s (%.1f%%)\n", name, TI, wgs, us, fl / us * 1e-6, fl / us * 1e-6 / 157.3 * 100);
 }
@@ -114,9 +141,9 @@ static void run(const char* name, const float* W, float* out, int wgs) {
 int main() {
   float *W, *out;
   CK(hipMalloc(&W, (size_t)8 * 256 * 256 * 4));
-  CK(hipMalloc(&out, (size_t)4096 * 256 * 4));
+  CK(hipMalloc(&out, (size_t)2 * 2048 * 64 * 256 * 4));
   CK(hipMemset(W, 0, (size_t)8 * 256 * 256 * 4));
-  for (int wgs : {512, 1024}) {
+  for (int wgs : {1024}) {
     run<false, false, false, false, 2>("regs only", W, out, wgs);
     run<true, false, false, false, 2>("A from LDS", W, out, wgs);
     run<true, false, false, true, 2>("A from LDS + sched_barrier", W, out, wgs);
@@ -125,8 +152,9 @@ int main() {
     run<true, true, true, true, 2>("A LDS + B global + sched + barriers", W, out, wgs);
     run<true, true, true, false, 2>("A LDS + B global + barriers (no sched)", W, out, wgs);
     run<true, true, true, true, 1>("A LDS + B global + sched + barriers", W, out, wgs * 2);
-    run<true, true, true, true, 1, true>("same, A fragments prefetched one group ahead", W, out, wgs * 2);
-    run<true, true, true, true, 2, true>("same, A fragments prefetched one group ahead", W, out, wgs);
+    run<true, true, true, true, 2, false, 1>("full loop + softplus-like epilogue (no stores)", W, out, wgs);
+    run<true, true, true, true, 2, false, 2>("full loop + softplus-like epilogue + 2 stores", W, out, wgs);
+    run<true, true, true, true, 1, false, 1>("full loop + softplus-like epilogue (no stores)", W, out, wgs * 2);
   }
   return 0;
 }
