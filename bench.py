@@ -29,6 +29,22 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+
+
+def measured_traffic(n_gpus, rays):
+    """HBM bytes per MFMA-family launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
+    see profiles/README.md).  PMC collection needs its own rocprofv3 runs, so bench.py reports the stored
+    measurement of the same workload (N=1, 512 rays) and null for any other shape."""
+    try:
+        with open(TRAFFIC_JSON) as f:
+            t = json.load(f)
+        if n_gpus == 1 and rays == t.get("rays", 512):
+            return {"hbm_bytes_per_launch": round(t["hbm_bytes_per_launch"]),
+                    "hbm_bytes_per_step": round(t["hbm_bytes_per_step"]), "source": "profiles/hbm_traffic.json"}
+    except Exception:
+        pass
+    return None
 
 
 def parse():
@@ -191,7 +207,7 @@ def main():
         if use_events and gemm_n.value > 0:
             ach = gemm_fl.value / (gemm_ms.value * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": measured_traffic(world, B),
                     "kernel": "fp32-MFMA layer GEMMs (gemm_rows_kernel<*>, gemm_dw_kernel)",
                     "launches_per_step": gemm_n.value / args.steps,
                     "avg_launch_us": round(1e3 * gemm_ms.value / gemm_n.value, 2),
