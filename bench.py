@@ -40,11 +40,12 @@ def measured_traffic(n_gpus, rays):
         with open(TRAFFIC_JSON) as f:
             t = json.load(f)
         if n_gpus == 1 and rays == t.get("rays", 512):
-            return {"hbm_bytes_per_launch": round(t["hbm_bytes_per_launch"]),
-                    "hbm_bytes_per_step": round(t["hbm_bytes_per_step"]), "source": "profiles/hbm_traffic.json"}
+            return round(t["hbm_bytes_per_launch"]), {"hbm_bytes_per_step": round(t["hbm_bytes_per_step"]),
+                                                       "launches_per_step": t["launches_per_step"],
+                                                       "source": "profiles/hbm_traffic.json"}
     except Exception:
         pass
-    return None
+    return None, None
 
 
 def parse():
@@ -204,11 +205,13 @@ def main():
         ms_per_step = 1e3 * elapsed / args.steps
         value = B * world * args.steps / elapsed
         roof = None
+        traffic, traffic_detail = measured_traffic(world, B)
         if use_events and gemm_n.value > 0:
             ach = gemm_fl.value / (gemm_ms.value * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": measured_traffic(world, B),
-                    "kernel": "fp32-MFMA layer GEMMs (gemm_rows_kernel<*>, gemm_dw_kernel)",
+                    "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch",
+                    "traffic_detail": traffic_detail,
+                    "kernel": "fp32-MFMA family: fused_forward/reverse/ra/fb_kernel, gemm_dw_kernel, gemm_rows_kernel<*>",
                     "launches_per_step": gemm_n.value / args.steps,
                     "avg_launch_us": round(1e3 * gemm_ms.value / gemm_n.value, 2),
                     "flop_per_launch": round(gemm_fl.value / gemm_n.value, 1),
