@@ -32,7 +32,6 @@ struct FusedFwdArgs {
   float* D[RNB_MAX_LIN];
   float* gz_last;       // [Mp,256] seed of the reverse sweep: w_sdf * D_last (optional)
   int stagger;          // tuning knob (RNB_STAGGER)
-  int dbg_nostore;      // timing experiment only (RNB_DEBUG_NOSTORE): skip the saved-state stores
 };
 
 // TI = row tiles per workgroup (64 points for TI = 2; 32 points for TI = 1, used for small batches so that
@@ -131,7 +130,7 @@ __global__ __launch_bounds__(256, 2) void fused_forward_kernel(FusedFwdArgs g) {
             D = 0.f;
           }
           Y[row * FP + col] = a;
-          if (SAVE && !g.dbg_nostore) {
+          if (SAVE) {
             bstore(ra, voff, rowc * FH * 4, a);
             bstore(rD, voff, rowc * FH * 4, D);
             if (last && g.gz_last) bstore(rg, voff, rowc * FH * 4, ws * D);
@@ -232,8 +231,6 @@ int fused_forward(const Layout& L, const float* packed, const float* pts, int64_
   g.gz_last = need_gz_last ? pb.gz[L.nh - 1] : nullptr;
   static const char* sg = getenv("RNB_STAGGER");
   g.stagger = sg ? atoi(sg) : 0;
-  static const char* ns = getenv("RNB_DEBUG_NOSTORE");
-  g.dbg_nostore = ns ? atoi(ns) : 0;
   // algorithmic FLOPs of the sweep (real layer shapes), for the optional event instrumentation
   double fl = 0;
   for (int l = 0; l < L.nh; ++l) fl += 2.0 * (double)M * L.hid[l].N * L.hid[l].K;

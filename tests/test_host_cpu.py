@@ -129,3 +129,34 @@ def test_embedder_matches_oracle():
     x = torch.randn(10, 3)
     assert dim == 39
     assert torch.equal(fn(x), O.embed(x, 6))
+
+
+def test_checkpoint_layout_round_trip(tmp_path):
+    """Reference checkpoint layout (exp_runner.py:373-386): same keys, parameter names and Adam state order."""
+    from rnb_neus_fork_amd import checkpoint as CK
+    torch.manual_seed(0)
+    nerf = R.NeRF(D=8, d_in=4, d_in_view=3, W=256, multires=10, multires_view=4, output_ch=4, skips=[4],
+                  use_viewdirs=True)
+    sdf = R.SDFNetwork(d_in=3, d_out=65, d_hidden=64, n_layers=8, skip_in=[4], multires=6)
+    dev = R.SingleVarianceNetwork(0.3)
+    col = R.RenderingNetwork(d_feature=64, mode="no_view_dir", d_in=6, d_out=3, d_hidden=64, n_layers=2,
+                             multires_view=4)
+    params = list(nerf.parameters()) + list(sdf.parameters()) + list(dev.parameters()) + list(col.parameters())
+    opt = torch.optim.Adam(params, lr=5e-4)
+    for p in list(sdf.parameters())[:3]:
+        p.grad = torch.ones_like(p)
+    opt.step()
+    path = CK.save_checkpoint(str(tmp_path / "checkpoints" / "ckpt_000123.pth"), nerf, sdf, dev, col, opt, 123)
+    raw = torch.load(path, weights_only=True)
+    assert tuple(raw.keys()) == CK.KEYS
+    assert list(raw["sdf_network_fine"].keys())[:3] == ["lin0.bias", "lin0.weight_g", "lin0.weight_v"]
+    assert list(raw["variance_network_fine"].keys()) == ["variance"]
+    sdf2 = R.SDFNetwork(d_in=3, d_out=65, d_hidden=64, n_layers=8, skip_in=[4], multires=6)
+    dev2 = R.SingleVarianceNetwork(0.1)
+    col2 = R.RenderingNetwork(d_feature=64, mode="no_view_dir", d_in=6, d_out=3, d_hidden=64, n_layers=2,
+                              multires_view=4)
+    it = CK.load_checkpoint(path, None, sdf2, dev2, col2)
+    assert it == 123 and float(dev2.variance) == pytest.approx(0.3)
+    assert all(torch.equal(a, b) for a, b in zip(sdf.parameters(), sdf2.parameters()))
+    assert CK.latest_checkpoint(str(tmp_path / "checkpoints")) == path
+    assert CK.latest_checkpoint(str(tmp_path / "checkpoints"), end_iter=100) is None
