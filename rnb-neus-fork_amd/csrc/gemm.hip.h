@@ -249,11 +249,11 @@ __global__ __launch_bounds__(256, BN == 256 ? 2 : 3) void gemm_rows_kernel(const
                         epi);
 }
 
-// ---- dW[N x K] += X1^T Y1 (+ X2^T Y2), reduction over the M points, split over blockIdx.z ---------
-//   X* [M x N] (ldx), Y* [M x K] (ldy); rows >= M are masked.  grid = (ceil(N/128), ceil(K/128), splits).
+// ---- dW[N x K] += X1^T Y1 (+ X2^T Y2), reduction over the M points, split-K over workgroups ---------
+//   X* [M x N] (ldx), Y* [M x K] (ldy); rows >= M are masked.  1-D grid over (job, tile, split).
 //   Partial tiles are accumulated into dW with float atomics (dW zero-initialised by the caller);
 //   colsum(X) of pair `bias_pair` over the same rows is added to db when db != nullptr (by the
-//   blockIdx.y == 0 blocks).
+//   tile_k == 0 blocks).
 struct DwPair {
   const float* X;
   int ldx;
@@ -286,37 +286,59 @@ __device__ inline void dw_main_loop(const DwPair& p, int m_begin, int m_end, int
   }
 }
 
-// GUARD (host: N % 128 || K % 128 || M % 32) as for gemm_rows_kernel.
+// One dW job = one weight matrix; a launch carries a group of jobs so that the atomic tail of one matrix
+// overlaps the main loop of the next (a single 256x256 job is ONE resident wave of workgroups: all of them
+// would reach their atomics together).  block_end = exclusive prefix sum of the jobs' block counts, each a
+// multiple of 8 when splits is (keeps the XCD decode below valid inside the group).
+struct DwJob {
+  DwPair p1, p2;
+  float* dW;
+  float* db;
+  int npairs, N, K, lddw, bias_pair, splits, rows_per_split, block_end;
+};
+constexpr int kMaxDwJobs = 12;
+struct DwGroup {
+  DwJob job[kMaxDwJobs];
+  int njobs, M;
+};
+
+// GUARD (host: N % 128 || K % 128 || M % 32) as for gemm_rows_kernel: all jobs of a group share it.
 template <bool GUARD>
-__global__ __launch_bounds__(256, 3) void gemm_dw_kernel(DwPair p1, DwPair p2, int npairs, int M, int N, int K,
-                                                         int rows_per_split, float* __restrict__ dW, int lddw,
-                                                         float* __restrict__ db, int bias_pair) {
+__global__ __launch_bounds__(256, 3) void gemm_dw_kernel(const DwGroup g) {
   __shared__ __attribute__((aligned(16))) float smem[2 * BK * 128];
   float* Xs = smem;
   float* Ys = smem + BK * 128;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = wave_id();
   const int wm = wave >> 1, wn = wave & 1;
-  // 1-D grid of tiles_n * tiles_k * splits blocks.  Workgroups are dealt round-robin over the 8 XCDs
+  int ji = 0, begin = 0;
+  for (int i = 0; i + 1 < g.njobs; ++i)
+    if ((int)blockIdx.x >= g.job[i].block_end) { ji = i + 1; begin = g.job[i].block_end; }
+  const DwJob& J = g.job[ji];
+  const int blk = (int)blockIdx.x - begin;
+  const int M = g.M, N = J.N, K = J.K, splits = J.splits;
+  float* __restrict__ dW = J.dW;
+  float* __restrict__ db = J.db;
+  // Blocks of a job: tiles_n * tiles_k * splits.  Workgroups are dealt round-robin over the 8 XCDs
   // (blocks b and b+8 share an L2), so the tiles of one point-split are placed on ONE XCD in consecutive
   // dispatch slots: the X / Y chunks they share are then served by that XCD's L2 instead of being fetched
   // once per tile.  Pure placement heuristic: any mapping is correct.
   const int tiles_n = (N + 127) / 128, tiles_k = (K + 127) / 128;
   const int nt = tiles_n * tiles_k;
-  const int splits = gridDim.x / nt;
+  if (blk >= nt * splits) return;   // padding blocks that align the next job to 8
   int tile, split;
   if (splits % 8 == 0) {
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int xcd = blk & 7, j = blk >> 3;
     tile = j % nt;
     split = (j / nt) * 8 + xcd;
   } else {
-    tile = blockIdx.x % nt;
-    split = blockIdx.x / nt;
+    tile = blk % nt;
+    split = blk / nt;
   }
   const int tile_n = tile % tiles_n, tile_k = tile / tiles_n;
   const int n_blk = tile_n * 128, k_blk = tile_k * 128;
-  const int m_begin = split * rows_per_split;
-  const int m_end = min(M, m_begin + rows_per_split);
+  const int m_begin = split * J.rows_per_split;
+  const int m_end = min(M, m_begin + J.rows_per_split);
   unsigned mask = 0;
 #pragma unroll
   for (int tj = 0; tj < 2; ++tj)
@@ -328,13 +350,14 @@ __global__ __launch_bounds__(256, 3) void gemm_dw_kernel(DwPair p1, DwPair p2, i
   const bool bias_blk = (db != nullptr) && tile_k == 0 && tid < 128 && (n_blk + tid < N);
 
   if (m_begin < m_end) {
-    for (int pi = 0; pi < npairs; ++pi) {
-      const DwPair p = pi == 0 ? p1 : p2;
-      const bool do_bias = bias_blk && pi == bias_pair;
+    for (int pi = 0; pi < J.npairs; ++pi) {
+      const DwPair p = pi == 0 ? J.p1 : J.p2;
+      const bool do_bias = bias_blk && pi == J.bias_pair;
       dw_main_loop<GUARD>(p, m_begin, m_end, N, K, n_blk, k_blk, wm, wn, mask, do_bias, bsum, Xs, Ys, acc);
     }
   }
   // atomics: each register of a 32x32 accumulator is two 128-byte row segments per wave instruction
+  const int lddw = J.lddw;
 #pragma unroll
   for (int tj = 0; tj < 2; ++tj) {
     if (!((mask >> tj) & 1u)) continue;

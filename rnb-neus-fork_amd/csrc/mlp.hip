@@ -479,29 +479,61 @@ static int launch_rows(const float* A, int lda, const float* W, int ldw, int64_t
   return RNB_OK;
 }
 
-static int launch_dw(DwPair p1, DwPair p2, int npairs, int64_t M, int N, int K, float* dW, int lddw, float* db,
-                     int bias_pair, double flops, hipStream_t s) {
-  const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
-  int splits = (int)((M + 511) / 512);              // >= 512 points per block
-  const int max_splits = (1024 + tiles - 1) / tiles;  // ~1024 blocks in flight
-  if (splits > max_splits) splits = max_splits;
-  if (splits < 1) splits = 1;
-  if (splits >= 8) splits = splits / 8 * 8;   // multiple of 8: enables the XCD-aware placement in the kernel
-  int rows = (int)((M + splits - 1) / splits);
-  rows = (rows + BK - 1) / BK * BK;
-  // (the kernel tolerates empty splits, so the grid keeps the multiple-of-8 split count)
-  if ((int64_t)rows * splits < M) splits = (int)((M + rows - 1) / rows);
-  dim3 grid((unsigned)(tiles * splits));
-  ProfScope prof(flops, s);
-  if (N % 128 == 0 && K % 128 == 0 && M % BK == 0)
-    hipLaunchKernelGGL(gemm_dw_kernel<false>, grid, dim3(256), 0, s, p1, p2, npairs, (int)M, N, K, rows, dW, lddw,
-                       db, bias_pair);
-  else
-    hipLaunchKernelGGL(gemm_dw_kernel<true>, grid, dim3(256), 0, s, p1, p2, npairs, (int)M, N, K, rows, dW, lddw,
-                       db, bias_pair);
-  RNB_CHECK_LAUNCH();
-  return RNB_OK;
-}
+// Collects the dW jobs of one backward pass and launches them as (at most) two grouped GEMMs, one per GUARD
+// variant.  Every job reads buffers that stay untouched until the end of sweep_backward, so deferring the
+// launch is safe.
+struct DwBatch {
+  DwGroup grp[2];     // [0] exact shapes, [1] guarded
+  double flops[2];
+  int64_t M;
+  hipStream_t s;
+  DwBatch(int64_t M_, hipStream_t s_) : M(M_), s(s_) {
+    for (int v = 0; v < 2; ++v) { grp[v].njobs = 0; grp[v].M = (int)M_; flops[v] = 0.0; }
+  }
+  int flush(int v) {
+    DwGroup& g = grp[v];
+    if (g.njobs == 0) return RNB_OK;
+    const dim3 grid((unsigned)g.job[g.njobs - 1].block_end);
+    {
+      ProfScope prof(flops[v], s);
+      if (v == 0) hipLaunchKernelGGL(gemm_dw_kernel<false>, grid, dim3(256), 0, s, g);
+      else hipLaunchKernelGGL(gemm_dw_kernel<true>, grid, dim3(256), 0, s, g);
+    }
+    g.njobs = 0;
+    flops[v] = 0.0;
+    RNB_CHECK_LAUNCH();
+    return RNB_OK;
+  }
+  int add(DwPair p1, DwPair p2, int npairs, int N, int K, float* dW, int lddw, float* db, int bias_pair, double fl) {
+    const int v = (N % 128 == 0 && K % 128 == 0 && M % BK == 0) ? 0 : 1;
+    if (grp[v].njobs == kMaxDwJobs) RNB_TRY(flush(v));
+    const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
+    int splits = (int)((M + 511) / 512);              // >= 512 points per block
+    const int max_splits = (1024 + tiles - 1) / tiles;  // ~1024 blocks per job
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    if (splits >= 8) splits = splits / 8 * 8;   // multiple of 8: enables the XCD-aware placement in the kernel
+    int rows = (int)((M + splits - 1) / splits);
+    rows = (rows + BK - 1) / BK * BK;
+    // (the kernel tolerates empty splits, so the job keeps the multiple-of-8 split count)
+    if ((int64_t)rows * splits < M) splits = (int)((M + rows - 1) / rows);
+    DwGroup& g = grp[v];
+    DwJob& j = g.job[g.njobs];
+    j.p1 = p1; j.p2 = p2; j.dW = dW; j.db = db;
+    j.npairs = npairs; j.N = N; j.K = K; j.lddw = lddw; j.bias_pair = bias_pair;
+    j.splits = splits; j.rows_per_split = rows;
+    // jobs start on a multiple of 8 blocks so that (block & 7) is the XCD inside every job
+    const int begin = g.njobs ? g.job[g.njobs - 1].block_end : 0;
+    j.block_end = begin + (tiles * splits + 7) / 8 * 8;
+    ++g.njobs;
+    flops[v] += fl;
+    return RNB_OK;
+  }
+  int flush_all() {
+    RNB_TRY(flush(0));
+    return flush(1);
+  }
+};
 
 static inline unsigned blocks_for(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
 
@@ -592,6 +624,7 @@ int sweep_color(const Layout& L, const float* packed, PointBufs& pb, const float
 int sweep_backward(const Layout& L, const float* packed, PointBufs& pb, bool with_color, float* packed_grad,
                    bool fused, hipStream_t s) {
   const int64_t M = pb.M, Mp = pb.Mp;
+  DwBatch dw(M, s);
   // ---- C': albedo network backward ---------------------------------------------------------------
   if (with_color) {
     const int rows_per_blk = 64;
@@ -604,7 +637,7 @@ int sweep_backward(const Layout& L, const float* packed, PointBufs& pb, bool wit
       const float* in = l == 0 ? pb.cin : pb.ac[l - 1];
       const int ldin = l == 0 ? L.Cinp : L.Hcp;
       DwPair p{pb.zc[l], L.Hcp, in, ldin};
-      RNB_TRY(launch_dw(p, p, 1, M, ln.Np, ln.Kp, packed_grad + ln.w_off, ln.Kp, packed_grad + ln.b_off, 0, mm_flops(M, ln), s));
+      RNB_TRY(dw.add(p, p, 1, ln.Np, ln.Kp, packed_grad + ln.w_off, ln.Kp, packed_grad + ln.b_off, 0, mm_flops(M, ln)));
       if (l > 0) {
         EpiReluMask epi{pb.ac[l - 1], pb.zc[l - 1], L.Hcp, L.col[l - 1].N};
         RNB_TRY((launch_rows<true, EpiReluMask>(pb.zc[l], L.Hcp, packed + ln.w_off, ln.Kp, Mp, ln.Kp, ln.Np, epi, mm_flops(M, ln), s)));
@@ -650,8 +683,8 @@ int sweep_backward(const Layout& L, const float* packed, PointBufs& pb, bool wit
     }
     if (with_color) {
       DwPair p{pb.cinb, L.Cinp, pb.a[L.nh - 1], L.Hp};
-      RNB_TRY(launch_dw(p, p, 1, M, L.feat.Np, L.feat.Kp, packed_grad + L.feat.w_off, L.feat.Kp,
-                        packed_grad + L.feat.b_off, 0, mm_flops(M, L.feat), s));
+      RNB_TRY(dw.add(p, p, 1, L.feat.Np, L.feat.Kp, packed_grad + L.feat.w_off, L.feat.Kp,
+                     packed_grad + L.feat.b_off, 0, mm_flops(M, L.feat)));
     }
   }
   // ---- FB + dW, layers nh-1 .. 0 -------------------------------------------------------------------
@@ -662,15 +695,15 @@ int sweep_backward(const Layout& L, const float* packed, PointBufs& pb, bool wit
     const float* uin = l == 0 ? pb.geb : pb.u[l];
     DwPair p1{pb.gz[l], L.Hp, uin, ldin};
     DwPair p2{pb.zb[l], L.Hp, in, ldin};
-    RNB_TRY(launch_dw(p1, p2, 2, M, ln.Np, ln.Kp, packed_grad + ln.w_off, ln.Kp, packed_grad + ln.b_off, 1,
-                      2.0 * mm_flops(M, ln), s));
+    RNB_TRY(dw.add(p1, p2, 2, ln.Np, ln.Kp, packed_grad + ln.w_off, ln.Kp, packed_grad + ln.b_off, 1,
+                   2.0 * mm_flops(M, ln)));
     if (l > 0 && !fused) {
       const Lin& lp = L.hid[l - 1];
       EpiFB epi{pb.D[l - 1], pb.zR[l - 1], pb.zb[l - 1], L.Hp, lp.N, nullptr, nullptr, 1.f};
       RNB_TRY((launch_rows<true, EpiFB>(pb.zb[l], L.Hp, packed + ln.w_off, ln.Kp, Mp, ln.Kp, ln.Np, epi, mm_flops(M, ln), s)));
     }
   }
-  return RNB_OK;
+  return dw.flush_all();
 }
 
 }  // namespace rnb

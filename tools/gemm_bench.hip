@@ -189,10 +189,25 @@ int main(int argc, char** argv) {
   }
   {
     DwPair p1{X1, N, A, K}, p2{X2, N, A, K};
-    const int splits = 256, rows = M / splits;
-    report("dW 2 pairs (atomics)", time_it([&] {
-             hipLaunchKernelGGL(gemm_dw_kernel<false>, dim3(4 * splits), dim3(256), 0, 0, p1, p2, 2, M, N, K, rows, dW, K, (float*)nullptr, 1);
-           }, iters), 2 * flops);
+    for (int njobs : {1, 8}) {
+      for (int splits : {128, 256}) {
+        DwGroup g;
+        g.njobs = njobs;
+        g.M = M;
+        for (int j = 0; j < njobs; ++j) {
+          DwJob& J = g.job[j];
+          J.p1 = p1; J.p2 = p2; J.dW = dW; J.db = nullptr;
+          J.npairs = 2; J.N = N; J.K = K; J.lddw = K; J.bias_pair = 1;
+          J.splits = splits; J.rows_per_split = M / splits;
+          J.block_end = (j + 1) * 4 * splits;
+        }
+        char name[96];
+        snprintf(name, sizeof name, "dW 2 pairs (atomics), %d job(s)/launch, %d splits", njobs, splits);
+        report(name, time_it([&] {
+                 hipLaunchKernelGGL(gemm_dw_kernel<false>, dim3(g.job[njobs - 1].block_end), dim3(256), 0, 0, g);
+               }, iters), 2 * flops * njobs);
+      }
+    }
   }
   // correctness spot check of the NT kernel against a host dot product
   {
