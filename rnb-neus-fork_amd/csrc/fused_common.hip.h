@@ -11,10 +11,6 @@ constexpr int FH = 256;       // hidden width of the fused path
 constexpr int FP = FH + 4;    // LDS pitch of the activation tile
 constexpr int FEP = 40;       // LDS pitch of the positional-encoding copy kept for the skip connection
 
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory counter,
-// i.e. it would wait for the fire-and-forget global stores of the previous epilogue to reach memory.
-__device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
 // Raw buffer access to one tile of a row-major matrix: resource = tile base + byte size, per-lane 32-bit
 // byte offset in a VGPR, wave-uniform byte offset in the scalar operand.
 typedef __amdgpu_buffer_rsrc_t BufRsrc;

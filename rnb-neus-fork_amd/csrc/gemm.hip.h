@@ -29,6 +29,10 @@ constexpr int BM = 128;
 constexpr int BK = 32;
 constexpr int LDK = BK + 4;   // pitch (floats) of a k-contiguous tile  [rows][36]
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory counter,
+// i.e. it would wait for prefetch loads and fire-and-forget global stores that are still in flight.
+__device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ inline int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
 // ---- global -> register staging ------------------------------------------------------------------
@@ -206,7 +210,7 @@ __device__ inline void rows_main_loop(const float* __restrict__ A, int lda, cons
     store_rows<BM>(As, tid, ra);
     if constexpr (!B_KMAJOR) store_rows<BN>(Bs, tid, rb);
     else store_kmajor<BN>(Bs, tid, rb);
-    __syncthreads();
+    lds_barrier();
     if (kt + 1 < nk) {
       const int k0 = (kt + 1) * BK;
       load_rows<BM, false>(A, lda, m_blk, k0, 0, tid, ra);
@@ -214,7 +218,7 @@ __device__ inline void rows_main_loop(const float* __restrict__ A, int lda, cons
       else load_kmajor<BN, GUARD>(W, ldw, k0, n_blk, K, N, tid, rb);
     }
     mma_step<false, LDK, B_KMAJOR, B_PITCH, TN, GUARD>(As, Bs, wm * 64, wn * (BN / 2), lane, mask, acc);
-    __syncthreads();
+    lds_barrier();
   }
 }
 
@@ -261,28 +265,28 @@ struct DwPair {
   int ldy;
 };
 
-template <bool GUARD>
+template <bool GUARD, int KT>
 __device__ inline void dw_main_loop(const DwPair& p, int m_begin, int m_end, int N, int K, int n_blk, int k_blk,
                                     int wm, int wn, unsigned mask, bool do_bias, double& bsum,
-                                    float* __restrict__ Xs, float* __restrict__ Ys, v16f (&acc)[2][2]) {
+                                    float* __restrict__ Xs, float* __restrict__ Ys, v16f (&acc)[2][KT / 64]) {
   const int tid = threadIdx.x, lane = tid & 63;
-  vf4 rx[4], ry[4];
+  vf4 rx[4], ry[KT / 32];
   load_kmajor<128, GUARD>(p.X, p.ldx, m_begin, n_blk, m_end, N, tid, rx);
-  load_kmajor<128, GUARD>(p.Y, p.ldy, m_begin, k_blk, m_end, K, tid, ry);
+  load_kmajor<KT, GUARD>(p.Y, p.ldy, m_begin, k_blk, m_end, K, tid, ry);
   for (int m0 = m_begin; m0 < m_end; m0 += BK) {
     store_kmajor<128>(Xs, tid, rx);
-    store_kmajor<128>(Ys, tid, ry);
-    __syncthreads();
+    store_kmajor<KT>(Ys, tid, ry);
+    lds_barrier();
     if (m0 + BK < m_end) {
       load_kmajor<128, GUARD>(p.X, p.ldx, m0 + BK, n_blk, m_end, N, tid, rx);
-      load_kmajor<128, GUARD>(p.Y, p.ldy, m0 + BK, k_blk, m_end, K, tid, ry);
+      load_kmajor<KT, GUARD>(p.Y, p.ldy, m0 + BK, k_blk, m_end, K, tid, ry);
     }
     if (do_bias) {
 #pragma unroll 8
       for (int kk = 0; kk < BK; ++kk) bsum += (double)Xs[kk * 128 + tid];
     }
-    mma_step<true, 128, true, 128, 2, GUARD>(Xs, Ys, wm * 64, wn * 64, lane, mask, acc);
-    __syncthreads();
+    mma_step<true, 128, true, KT, KT / 64, GUARD>(Xs, Ys, wm * 64, wn * (KT / 2), lane, mask, acc);
+    lds_barrier();
   }
 }
 
@@ -302,10 +306,13 @@ struct DwGroup {
   int njobs, M;
 };
 
-// GUARD (host: N % 128 || K % 128 || M % 32) as for gemm_rows_kernel: all jobs of a group share it.
-template <bool GUARD>
+// GUARD (host: N % 128 || K % KT || M % 32) as for gemm_rows_kernel, and the width KT (128 or 64) of the
+// output tile along K: all jobs of a group share both.  KT = 64 keeps all four waves busy on narrow or ragged
+// K (the PE-input layer has K = 64, the albedo net's first layer K = 320).
+template <bool GUARD, int KT>
 __global__ __launch_bounds__(256, 3) void gemm_dw_kernel(const DwGroup g) {
-  __shared__ __attribute__((aligned(16))) float smem[2 * BK * 128];
+  constexpr int TN = KT / 64;
+  __shared__ __attribute__((aligned(16))) float smem[BK * 128 + BK * KT];
   float* Xs = smem;
   float* Ys = smem + BK * 128;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -323,7 +330,7 @@ __global__ __launch_bounds__(256, 3) void gemm_dw_kernel(const DwGroup g) {
   // (blocks b and b+8 share an L2), so the tiles of one point-split are placed on ONE XCD in consecutive
   // dispatch slots: the X / Y chunks they share are then served by that XCD's L2 instead of being fetched
   // once per tile.  Pure placement heuristic: any mapping is correct.
-  const int tiles_n = (N + 127) / 128, tiles_k = (K + 127) / 128;
+  const int tiles_n = (N + 127) / 128, tiles_k = (K + KT - 1) / KT;
   const int nt = tiles_n * tiles_k;
   if (blk >= nt * splits) return;   // padding blocks that align the next job to 8
   int tile, split;
@@ -336,16 +343,16 @@ __global__ __launch_bounds__(256, 3) void gemm_dw_kernel(const DwGroup g) {
     split = blk / nt;
   }
   const int tile_n = tile % tiles_n, tile_k = tile / tiles_n;
-  const int n_blk = tile_n * 128, k_blk = tile_k * 128;
+  const int n_blk = tile_n * 128, k_blk = tile_k * KT;
   const int m_begin = split * J.rows_per_split;
   const int m_end = min(M, m_begin + J.rows_per_split);
   unsigned mask = 0;
 #pragma unroll
-  for (int tj = 0; tj < 2; ++tj)
-    if (k_blk + wn * 64 + tj * 32 < K) mask |= 1u << tj;
+  for (int tj = 0; tj < TN; ++tj)
+    if (k_blk + wn * (KT / 2) + tj * 32 < K) mask |= 1u << tj;
 
-  v16f acc[2][2];
-  zero_acc<2>(acc);
+  v16f acc[2][TN];
+  zero_acc<TN>(acc);
   double bsum = 0.0;   // bias gradients are long signed sums: keep the per-block partial in fp64
   const bool bias_blk = (db != nullptr) && tile_k == 0 && tid < 128 && (n_blk + tid < N);
 
@@ -353,15 +360,15 @@ __global__ __launch_bounds__(256, 3) void gemm_dw_kernel(const DwGroup g) {
     for (int pi = 0; pi < J.npairs; ++pi) {
       const DwPair p = pi == 0 ? J.p1 : J.p2;
       const bool do_bias = bias_blk && pi == J.bias_pair;
-      dw_main_loop<GUARD>(p, m_begin, m_end, N, K, n_blk, k_blk, wm, wn, mask, do_bias, bsum, Xs, Ys, acc);
+      dw_main_loop<GUARD, KT>(p, m_begin, m_end, N, K, n_blk, k_blk, wm, wn, mask, do_bias, bsum, Xs, Ys, acc);
     }
   }
   // atomics: each register of a 32x32 accumulator is two 128-byte row segments per wave instruction
   const int lddw = J.lddw;
 #pragma unroll
-  for (int tj = 0; tj < 2; ++tj) {
+  for (int tj = 0; tj < TN; ++tj) {
     if (!((mask >> tj) & 1u)) continue;
-    const int col = k_blk + wn * 64 + tj * 32 + (lane & 31);
+    const int col = k_blk + wn * (KT / 2) + tj * 32 + (lane & 31);
 #pragma unroll
     for (int ti = 0; ti < 2; ++ti) {
 #pragma unroll

@@ -479,16 +479,16 @@ static int launch_rows(const float* A, int lda, const float* W, int ldw, int64_t
   return RNB_OK;
 }
 
-// Collects the dW jobs of one backward pass and launches them as (at most) two grouped GEMMs, one per GUARD
-// variant.  Every job reads buffers that stay untouched until the end of sweep_backward, so deferring the
+// Collects the dW jobs of one backward pass and launches them as (at most) three grouped GEMMs, one per kernel
+// variant (K-tile 128 exact / K-tile 64 exact / K-tile 64 guarded).  Every job reads buffers that stay untouched until the end of sweep_backward, so deferring the
 // launch is safe.
 struct DwBatch {
-  DwGroup grp[2];     // [0] exact shapes, [1] guarded
-  double flops[2];
+  DwGroup grp[3];     // [0] K % 128 == 0, [1] K % 64 == 0, [2] anything (guarded)
+  double flops[3];
   int64_t M;
   hipStream_t s;
   DwBatch(int64_t M_, hipStream_t s_) : M(M_), s(s_) {
-    for (int v = 0; v < 2; ++v) { grp[v].njobs = 0; grp[v].M = (int)M_; flops[v] = 0.0; }
+    for (int v = 0; v < 3; ++v) { grp[v].njobs = 0; grp[v].M = (int)M_; flops[v] = 0.0; }
   }
   int flush(int v) {
     DwGroup& g = grp[v];
@@ -496,8 +496,9 @@ struct DwBatch {
     const dim3 grid((unsigned)g.job[g.njobs - 1].block_end);
     {
       ProfScope prof(flops[v], s);
-      if (v == 0) hipLaunchKernelGGL(gemm_dw_kernel<false>, grid, dim3(256), 0, s, g);
-      else hipLaunchKernelGGL(gemm_dw_kernel<true>, grid, dim3(256), 0, s, g);
+      if (v == 0) hipLaunchKernelGGL((gemm_dw_kernel<false, 128>), grid, dim3(256), 0, s, g);
+      else if (v == 1) hipLaunchKernelGGL((gemm_dw_kernel<false, 64>), grid, dim3(256), 0, s, g);
+      else hipLaunchKernelGGL((gemm_dw_kernel<true, 64>), grid, dim3(256), 0, s, g);
     }
     g.njobs = 0;
     flops[v] = 0.0;
@@ -505,10 +506,13 @@ struct DwBatch {
     return RNB_OK;
   }
   int add(DwPair p1, DwPair p2, int npairs, int N, int K, float* dW, int lddw, float* db, int bias_pair, double fl) {
-    const int v = (N % 128 == 0 && K % 128 == 0 && M % BK == 0) ? 0 : 1;
+    const bool exact = N % 128 == 0 && M % BK == 0;
+    const int v = (exact && K % 128 == 0) ? 0 : (exact && K % 64 == 0) ? 1 : 2;
     if (grp[v].njobs == kMaxDwJobs) RNB_TRY(flush(v));
-    const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
-    int splits = (int)((M + 511) / 512);              // >= 512 points per block
+    const int kt = v == 0 ? 128 : 64;                  // tile width along K of the variant (see kernel)
+    const int min_rows = v == 0 ? 512 : 256;           // points per block (half-size tiles: half the rows)
+    const int tiles = ((N + 127) / 128) * ((K + kt - 1) / kt);
+    int splits = (int)((M + min_rows - 1) / min_rows);
     const int max_splits = (1024 + tiles - 1) / tiles;  // ~1024 blocks per job
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
@@ -531,7 +535,8 @@ struct DwBatch {
   }
   int flush_all() {
     RNB_TRY(flush(0));
-    return flush(1);
+    RNB_TRY(flush(1));
+    return flush(2);
   }
 };
 

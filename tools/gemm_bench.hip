@@ -204,7 +204,7 @@ int main(int argc, char** argv) {
         char name[96];
         snprintf(name, sizeof name, "dW 2 pairs (atomics), %d job(s)/launch, %d splits", njobs, splits);
         report(name, time_it([&] {
-                 hipLaunchKernelGGL(gemm_dw_kernel<false>, dim3(g.job[njobs - 1].block_end), dim3(256), 0, 0, g);
+                 hipLaunchKernelGGL((gemm_dw_kernel<false, 128>), dim3(g.job[njobs - 1].block_end), dim3(256), 0, 0, g);
                }, iters), 2 * flops * njobs);
       }
     }
