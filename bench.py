@@ -59,7 +59,23 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--no-gemm-events", action="store_true")
+    ap.add_argument("--torch-train-ops", action="store_true",
+                    help="loss as the reference's chain of torch ops and torch.optim.Adam(fused=True) instead of "
+                         "the library's one-launch loss and flat Adam")
     return ap.parse_args()
+
+
+def torch_rnb_loss(render_out, true_rgb, mask, igr_weight=0.1, mask_weight=0.1):
+    """The loss exactly as exp_runner.py:229-258 writes it (torch ops on the renderer's outputs)."""
+    import torch.nn.functional as F
+    n_lights = true_rgb.shape[0]
+    mask = (mask > 0.5).float() if mask_weight > 0.0 else torch.ones_like(mask)
+    mask_sum = mask.sum() + 1e-5
+    err = ((render_out["color_fine"] - true_rgb) * mask[None, :, :]).reshape(-1, true_rgb.shape[-1])
+    color_loss = F.l1_loss(err, torch.zeros_like(err), reduction="sum") / (mask_sum * n_lights)
+    eik = render_out["gradient_error"]
+    mask_loss = F.binary_cross_entropy(render_out["weight_sum"].clip(1e-3, 1.0 - 1e-3), mask)
+    return color_loss + eik * igr_weight + mask_loss * mask_weight, {}
 
 
 def make_oracle_conf():
@@ -127,41 +143,53 @@ def main():
     if args.gpus != n_gpus and rank == 0:
         print(f"[bench] --gpus {args.gpus} but WORLD_SIZE {world}: using {world}", file=sys.stderr)
 
+    # the measured leg uses the product only (package + librnbneus_hip.so); oracle/ is touched by
+    # cpu_baseline() alone
     import rnb_neus_fork_amd as R
     from rnb_neus_fork_amd import parallel as P
-    O, mc = make_oracle_conf()   # configuration dataclasses + synthetic ray generator only
+    from rnb_neus_fork_amd.synthetic import synthetic_batch
     lib = R.native.load()
 
+    # confs/wmask_rnb.conf:53-90, constructed in the order of exp_runner.py:95-100 under seed 0
     torch.manual_seed(0)
-    sdf, devnet, col, ren = R.build_from_named_params(mc, None, dev)   # geometric init under seed 0 (R2i)
+    sdf = R.SDFNetwork(d_out=257, d_in=3, d_hidden=256, n_layers=8, skip_in=[4], multires=6, bias=0.5, scale=1.0,
+                       geometric_init=True, weight_norm=True).to(dev)
+    devnet = R.SingleVarianceNetwork(init_val=0.3).to(dev)
+    col = R.RenderingNetwork(d_feature=256, mode="no_view_dir", d_in=6, d_out=3, d_hidden=256, n_layers=2,
+                             weight_norm=True, multires_view=4, squeeze_out=True).to(dev)
+    ren = R.NeuSRenderer(None, sdf, devnet, col, n_samples=64, n_importance=64, n_outside=0, up_sample_steps=4,
+                         perturb=1.0)
     if world > 1:
         P.broadcast_parameters([sdf, devnet, col])
         ren.set_data_parallel()
     params = list(sdf.parameters()) + list(devnet.parameters())
     if not args.no_albedo:
         params += list(col.parameters())
-    # exp_runner.py:115 (same optimizer and hyper-parameters; `fused=True` only selects PyTorch's
-    # multi-tensor single-kernel implementation of the identical update)
-    try:
+    # exp_runner.py:115: Adam, lr 5e-4.  Default: the library's flat single-launch Adam (identical update rule,
+    # tests/test_gpu_parity.py); --torch-train-ops keeps torch.optim.Adam and the reference's chain of torch ops
+    # for the loss, i.e. exactly what exp_runner.py would run around the drop-in renderer.
+    if args.torch_train_ops:
         opt = torch.optim.Adam(params, lr=5e-4, fused=True)
-    except Exception:   # pragma: no cover
-        opt = torch.optim.Adam(params, lr=5e-4)
+    else:
+        opt = R.FlatAdam(params, lr=5e-4)
 
     B = args.rays
     n_batches = 8
     # inputs resident in HBM before the timed region: each rank owns its contiguous shard of a global batch
     batches = []
     for i in range(n_batches):
-        gb = O.synthetic_batch(B * world, seed=0, step=i, warmup=args.warmup_mode)
+        gb = synthetic_batch(B * world, seed=0, step=i, warmup=args.warmup_mode)
         mine = P.shard_batch(gb, rank, world, n_rays=B * world)
         batches.append({k: v.to(dev) for k, v in mine.items()})
+
+    loss_fn = torch_rnb_loss if args.torch_train_ops else R.rnb_loss
 
     def step(i):
         b = batches[i % n_batches]
         fn = ren.render_rnb_warmup if args.warmup_mode else ren.render_rnb
         out = fn(b["rays_o"], b["rays_d"], b["near"], b["far"], b["lights_dir"], cos_anneal_ratio=1.0,
                  no_albedo=args.no_albedo, t_rand=b["t_rand"])
-        loss, _ = O.rnb_loss(out, b["true_rgb"], b["mask"])
+        loss, _ = loss_fn(out, b["true_rgb"], b["mask"])
         opt.zero_grad(set_to_none=True)
         loss.backward()
         opt.step()
@@ -231,7 +259,9 @@ def main():
                                    f"({'render_rnb_warmup' if args.warmup_mode else 'render_rnb'}), "
                                    f"{B} rays x (64+64) samples per GPU, 3 lights, geometric init, Adam",
                        "rays_per_gpu": B, "samples_per_ray": 128, "n_lights": 3,
-                       "no_albedo": bool(args.no_albedo), "parallelism": f"dp{world}", "final_loss": final_loss},
+                       "no_albedo": bool(args.no_albedo), "parallelism": f"dp{world}", "final_loss": final_loss,
+                       "train_ops": ("torch ops loss + torch.optim.Adam(fused)" if args.torch_train_ops
+                                     else "rnb_loss_rnb + rnb_adam_step (one launch each)")},
             "roofline": roof,
             "cpu_baseline": cpu,
         }

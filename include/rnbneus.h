@@ -213,6 +213,24 @@ int rnb_render_bwd(const rnb_model_desc* desc, const float* packed, const rnb_re
 int rnb_algorithmic_flops(const rnb_model_desc* desc, int64_t B, int32_t flags, double* train_flops,
                           double* forward_flops);
 
+/* The loss of train_rnb (exp_runner.py:241-258) and its gradients with respect to the renderer outputs, one
+ * launch:  loss = sum|(color_fine - true_rgb) * mask| / ((sum(mask) + 1e-5) * n_lights)
+ *               + igr_weight * gradient_error
+ *               + mask_weight * mean BCE(clip(weight_sum, 1e-3, 1 - 1e-3), mask),   mask := (mask > 0.5)
+ * (mask := 1 when mask_weight == 0, exp_runner.py:233-236).  color_fine, true_rgb [n_lights, B, color_depth];
+ * mask, weight_sum [B]; gradient_error [1].  loss [1]; parts [3] = color_loss, eikonal_loss, mask_loss;
+ * d_color_fine / d_weight_sum / d_gradient_error = d loss / d input (same shapes as the inputs). */
+int rnb_loss_rnb(const float* color_fine, const float* true_rgb, const float* mask, const float* weight_sum,
+                 const float* gradient_error, int32_t n_lights, int64_t B, int32_t color_depth, float igr_weight,
+                 float mask_weight, float* loss, float* parts, float* d_color_fine, float* d_weight_sum,
+                 float* d_gradient_error, rnb_stream_t stream);
+
+/* torch.optim.Adam.step() of exp_runner.py:115/:262 (amsgrad off) over ONE flat buffer of n parameters:
+ * exp_avg / exp_avg_sq are the optimizer state, `step` the 1-based step count.  lr..weight_decay are host
+ * scalars (the learning-rate schedule of exp_runner.py:327-337 changes lr every step). */
+int rnb_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double lr,
+                  double beta1, double beta2, double eps, double weight_decay, int64_t step, rnb_stream_t stream);
+
 /* Measurement aid for bench.py (not part of the reference's interface): while enabled, every launch of
  * the fp32-MFMA layer-GEMM kernels (gemm_rows_kernel<...>, gemm_dw_kernel) is bracketed by HIP events on
  * its launch stream.  After the caller has synchronised, rnb_profile_collect returns the summed device

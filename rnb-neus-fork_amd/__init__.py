@@ -16,9 +16,11 @@ from . import native  # noqa: F401
 from .embedder import get_embedder  # noqa: F401
 from .fields import NeRF, RenderingNetwork, SDFNetwork, SingleVarianceNetwork, model_desc  # noqa: F401
 from .renderer import NeuSRenderer  # noqa: F401
+from .losses import rnb_loss  # noqa: F401
+from .optim import FlatAdam  # noqa: F401
 
 __all__ = ["NeuSRenderer", "SDFNetwork", "RenderingNetwork", "SingleVarianceNetwork", "NeRF", "get_embedder",
-           "native", "build_from_named_params"]
+           "native", "build_from_named_params", "rnb_loss", "FlatAdam"]
 
 
 def build_from_named_params(mc, params, device):

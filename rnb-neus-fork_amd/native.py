@@ -88,6 +88,11 @@ _SIGNATURES = {
     "rnb_render_bwd": (C.c_int, [_P(ModelDesc), C.c_void_p, _P(RenderArgs), _P(RenderGrads), C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "rnb_algorithmic_flops": (C.c_int, [_P(ModelDesc), C.c_int64, C.c_int32, _P(C.c_double), _P(C.c_double)]),
+    "rnb_loss_rnb": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64,
+                               C.c_int32, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                               C.c_void_p, C.c_void_p]),
+    "rnb_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double,
+                                C.c_double, C.c_double, C.c_double, C.c_int64, C.c_void_p]),
     "rnb_profile_enable": (C.c_int, [C.c_int]),
     "rnb_profile_collect": (C.c_int, [_P(C.c_double), _P(C.c_int64), _P(C.c_double)]),
 }

@@ -30,16 +30,25 @@ __global__ __launch_bounds__(256, 2) void probe_kernel(const float* __restrict__
   for (int a = 0; a < TI; ++a) for (int b = 0; b < 2; ++b) for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
   vf4 areg[TI];
   for (int a = 0; a < TI; ++a) areg[a] = vf4{0.01f * lane, 0.02f, 0.03f, 0.04f};
+  constexpr bool XPF = (EPI == 4 || EPI == 5);   // next layer's first weight block is loaded before the stores
+  constexpr bool WIDE = (EPI == 3 || EPI == 4);  // a / D leave through LDS as 16-byte-per-lane row stores
+  vf4 bn[2][4];
   for (int l = 0; l < layers; ++l) {
     const float* Wl = W + (size_t)l * 256 * 256;
-    vf4 bn[2][4], b[2][4];
+    vf4 b[2][4];
+    auto loadb_at = [&](const float* Wx, int Q, vf4 (&d)[2][4]) {
+      for (int tj = 0; tj < 2; ++tj) {
+        const float* p = Wx + (size_t)(n0 + tj * 32 + i) * 256 + Q * 32 + h * 16;
+        for (int q = 0; q < 4; ++q) d[tj][q] = *reinterpret_cast<const vf4*>(p + q * 4);
+      }
+    };
     auto loadb = [&](int Q, vf4 (&d)[2][4]) {
       for (int tj = 0; tj < 2; ++tj) {
         const float* p = Wl + (size_t)(n0 + tj * 32 + i) * 256 + Q * 32 + h * 16;
         for (int q = 0; q < 4; ++q) d[tj][q] = B_GLB ? *reinterpret_cast<const vf4*>(p + q * 4) : vf4{0.1f, 0.2f, 0.3f, 0.4f + 0.001f * Q};
       }
     };
-    loadb(0, bn);
+    if (!(XPF && l > 0)) loadb(0, bn);
     for (int Q = 0; Q < 8; ++Q) {
 #pragma unroll
       for (int tj = 0; tj < 2; ++tj)
@@ -83,6 +92,7 @@ __global__ __launch_bounds__(256, 2) void probe_kernel(const float* __restrict__
         // light epilogue: touch one LDS element per lane so the barrier pair has something to order
         X[(lane & 31) * FP + n0 + (lane >> 5)] = acc[0][0][0];
       } else {
+        if (EPI == 5) loadb_at(W + (size_t)((l + 1) % 8) * 256 * 256, 0, bn);
         // heavy epilogue: ~EPI-flavoured VALU work per accumulator element + LDS write (+ global stores)
 #pragma unroll
         for (int tj = 0; tj < 2; ++tj)
@@ -100,7 +110,7 @@ __global__ __launch_bounds__(256, 2) void probe_kernel(const float* __restrict__
               float a = (t > 19.f) ? v : lg * 0.01f * (e * __builtin_amdgcn_rcpf(u == 1.f ? 1.f : u - 1.f));
               float D = e * __builtin_amdgcn_rcpf(u);
               X[row * FP + col] = a;
-              if (EPI == 2) {
+              if (EPI == 2 || EPI == 5) {
                 out[((size_t)blockIdx.x * 32 * TI + row) * 256 + col] = a;
                 out[((size_t)(gridDim.x + blockIdx.x) * 32 * TI + row) * 256 + col] = D;
               } else {
@@ -109,6 +119,20 @@ __global__ __launch_bounds__(256, 2) void probe_kernel(const float* __restrict__
             }
       }
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (WIDE) {
+        if (EPI == 4) loadb_at(W + (size_t)((l + 1) % 8) * 256 * 256, 0, bn);
+        // the tile (a_l) is row-major in LDS: every lane moves 16 bytes, a wave one full 1 KB row
+        float* o0 = out + (size_t)blockIdx.x * 32 * TI * 256;
+        float* o1 = out + (size_t)(gridDim.x + blockIdx.x) * 32 * TI * 256;
+#pragma unroll
+        for (int it = 0; it < 8 * TI; ++it) {
+          const int idx = it * 256 + tid;
+          const int row = idx >> 6, c4 = idx & 63;
+          const vf4 v = *reinterpret_cast<const vf4*>(X + row * FP + c4 * 4);
+          *reinterpret_cast<vf4*>(o0 + (size_t)row * 256 + c4 * 4) = v;
+          *reinterpret_cast<vf4*>(o1 + (size_t)row * 256 + c4 * 4) = v;
+        }
+      }
     }
   }
   float s = 0.f;
@@ -154,7 +178,13 @@ int main() {
     run<true, true, true, true, 1>("A LDS + B global + sched + barriers", W, out, wgs * 2);
     run<true, true, true, true, 2, false, 1>("full loop + softplus-like epilogue (no stores)", W, out, wgs);
     run<true, true, true, true, 2, false, 2>("full loop + softplus-like epilogue + 2 stores", W, out, wgs);
+    run<true, true, true, true, 2, false, 5>("  ... dword stores + cross-layer B prefetch", W, out, wgs);
+    run<true, true, true, true, 2, false, 3>("  ... wide stores from LDS", W, out, wgs);
+    run<true, true, true, true, 2, false, 4>("  ... wide stores + cross-layer B prefetch", W, out, wgs);
     run<true, true, true, true, 1, false, 1>("full loop + softplus-like epilogue (no stores)", W, out, wgs * 2);
+    run<true, true, true, true, 1, false, 2>("full loop + softplus-like epilogue + 2 stores", W, out, wgs * 2);
+    run<true, true, true, true, 1, false, 3>("  ... wide stores from LDS", W, out, wgs * 2);
+    run<true, true, true, true, 1, false, 4>("  ... wide stores + cross-layer B prefetch", W, out, wgs * 2);
   }
   return 0;
 }
