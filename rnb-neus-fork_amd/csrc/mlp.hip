@@ -86,15 +86,42 @@ __global__ void normal_kernel(const float* __restrict__ x4, const float* __restr
   nrm[row * 4 + 0] = n[0]; nrm[row * 4 + 1] = n[1]; nrm[row * 4 + 2] = n[2]; nrm[row * 4 + 3] = 0.f;
 }
 
+// ---- 64-point row tiles through LDS ------------------------------------------------------------------
+// The per-point kernels below compute (or consume) W consecutive columns of one matrix row per lane.
+// Touching global memory in that shape makes every access instruction hit 64 different rows; instead one
+// wave stages its 64 rows x W columns in LDS (pitch W + 1: conflict-free both ways) and moves them with
+// 16 bytes per lane along the rows.  W % 4 == 0, col0 % 4 == 0, ld % 4 == 0; one wave per workgroup.
+__device__ inline void tile_store64(float* __restrict__ dst, int ld, int64_t r0, int col0, int W,
+                                    const float* __restrict__ tile, int lane) {
+  const int g = W >> 2;   // 16-byte groups per row
+  for (int idx = lane; idx < 64 * g; idx += 64) {
+    const int p = idx / g, c = (idx - p * g) * 4;
+    const float* t = tile + p * (W + 1) + c;
+    *reinterpret_cast<vf4*>(dst + (r0 + p) * ld + col0 + c) = make_vf4(t[0], t[1], t[2], t[3]);
+  }
+}
+__device__ inline void tile_load64(const float* __restrict__ src, int ld, int64_t r0, int col0, int W,
+                                   float* __restrict__ tile, int lane) {
+  const int g = W >> 2;
+  for (int idx = lane; idx < 64 * g; idx += 64) {
+    const int p = idx / g, c = (idx - p * g) * 4;
+    const vf4 v = *reinterpret_cast<const vf4*>(src + (r0 + p) * ld + col0 + c);
+    float* t = tile + p * (W + 1) + c;
+    t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+  }
+}
+
 // albedo-net input columns F.. : [pe_v(p) | pe_v(n) | 0]  (feature columns 0..F-1 are written by the
-// feature-head GEMM).  models/fields.py:179-191 in the packed column order.
-__global__ void color_input_kernel(const float* __restrict__ pts, const float* __restrict__ nrm, int nrm_ld,
-                                   int64_t M, int64_t Mp, int F, int multires, int Cinp,
-                                   float* __restrict__ cin) {
-  int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (row >= Mp) return;
-  float* cr = cin + row * Cinp;
-  int c = F;
+// feature-head GEMM).  models/fields.py:179-191 in the packed column order.  One wave = 64 points;
+// dynamic LDS = 64 * (Cinp - F + 1) floats.
+__global__ __launch_bounds__(64) void color_input_kernel(const float* __restrict__ pts, const float* __restrict__ nrm,
+                                                         int nrm_ld, int64_t M, int64_t Mp, int F, int multires,
+                                                         int Cinp, float* __restrict__ cin) {
+  extern __shared__ float tile[];
+  const int lane = threadIdx.x, W = Cinp - F;
+  const int64_t r0 = (int64_t)blockIdx.x * 64, row = r0 + lane;
+  float* cr = tile + lane * (W + 1);
+  int c = 0;
   for (int which = 0; which < 2; ++which) {
     float v[3] = {0.f, 0.f, 0.f};
     if (row < M) {
@@ -116,7 +143,9 @@ __global__ void color_input_kernel(const float* __restrict__ pts, const float* _
       f *= 2.f;
     }
   }
-  for (; c < Cinp; ++c) cr[c] = 0.f;
+  for (; c < W; ++c) cr[c] = 0.f;
+  __builtin_amdgcn_wave_barrier();
+  tile_store64(cin, Cinp, r0, F, W, tile, lane);
 }
 
 // albedo output layer (d_out rows) + sigmoid: 32 lanes per point.
@@ -149,58 +178,108 @@ __global__ void color_out_kernel(const float* __restrict__ ac, int Hcp, int Hc, 
 }
 
 // backward of the albedo output layer: zo = albbar * alb(1-alb); zc_last = (zo Wo) * relu'(ac);
-// dWo += zo^T ac ; dbo += sum zo.   One workgroup handles `rows_per_blk` points; 256 threads = columns.
-__global__ void color_out_bwd_kernel(const float* __restrict__ albbar, const float* __restrict__ alb,
-                                     const float* __restrict__ ac, int Hcp, int Hc,
-                                     const float* __restrict__ Wo, int ldwo, int Co, int squeeze, int64_t M,
-                                     int rows_per_blk, float* __restrict__ zc, float* __restrict__ dWo,
-                                     float* __restrict__ dbo) {
+// dWo += zo^T ac ; dbo += sum zo.   One workgroup (512 threads) handles `rows_per_blk` points: thread =
+// (4 columns, row phase of 8); every access is 16 bytes per lane along a row.  blockIdx.y = 256-column chunk;
+// Co <= 4.  Few, fat workgroups: every workgroup ends in atomics on the SAME 3 x 256 addresses, which the L2
+// serialises (~0.1 us each), so their number — not the streaming — bounds the kernel.
+__global__ __launch_bounds__(512) void color_out_bwd_kernel(const float* __restrict__ albbar,
+                                                            const float* __restrict__ alb,
+                                                            const float* __restrict__ ac, int Hcp, int Hc,
+                                                            const float* __restrict__ Wo, int ldwo, int Co,
+                                                            int squeeze, int64_t M, int rows_per_blk,
+                                                            float* __restrict__ zc, float* __restrict__ dWo,
+                                                            float* __restrict__ dbo) {
+  __shared__ float red[7][4][256];   // [phase 1..7][c][column]
+  __shared__ float redb[8][4];
+  const int tid = threadIdx.x, cg = tid & 63, ph = tid >> 6;
+  const int kl = cg * 4, k0 = blockIdx.y * 256 + kl;
+  const bool col_ok = k0 < Hcp;
+  const bool bias_blk = blockIdx.y == 0;
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_blk;
   const int64_t r1 = min(M, r0 + rows_per_blk);
-  for (int k = threadIdx.x; k < Hcp; k += blockDim.x) {
-    float w[4] = {0.f, 0.f, 0.f, 0.f}, dw[4] = {0.f, 0.f, 0.f, 0.f};
-    if (k < Hc)
-      for (int c = 0; c < Co; ++c) w[c] = Wo[c * ldwo + k];
-    for (int64_t row = r0; row < r1; ++row) {
-      float zo[4];
-      for (int c = 0; c < 4; ++c) {
-        const float a = alb[row * 4 + c];
-        zo[c] = c < Co ? albbar[row * 4 + c] * (squeeze ? a * (1.f - a) : 1.f) : 0.f;
+  float w[4][4], dw[4][4], db[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      w[c][j] = (col_ok && c < Co && k0 + j < Hc) ? Wo[c * ldwo + k0 + j] : 0.f;
+      dw[c][j] = 0.f;
+    }
+#pragma unroll 4
+  for (int64_t row = r0 + ph; row < r1; row += 8) {
+    const vf4 a4 = *reinterpret_cast<const vf4*>(alb + row * 4);
+    const vf4 g4 = *reinterpret_cast<const vf4*>(albbar + row * 4);
+    float zo[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) zo[c] = c < Co ? g4[c] * (squeeze ? a4[c] * (1.f - a4[c]) : 1.f) : 0.f;
+    if (cg == 0) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) db[c] += zo[c];
+    }
+    if (col_ok) {
+      const vf4 av = *reinterpret_cast<const vf4*>(ac + row * Hcp + k0);
+      vf4 z;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float t = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { t = fmaf(zo[c], w[c][j], t); dw[c][j] = fmaf(zo[c], av[j], dw[c][j]); }
+        z[j] = (k0 + j < Hc && av[j] > 0.f) ? t : 0.f;
       }
-      const float av = ac[row * Hcp + k];
-      float t = 0.f;
-      for (int c = 0; c < Co; ++c) { t = fmaf(zo[c], w[c], t); dw[c] = fmaf(zo[c], av, dw[c]); }
-      zc[row * Hcp + k] = (k < Hc && av > 0.f) ? t : 0.f;
+      *reinterpret_cast<vf4*>(zc + row * Hcp + k0) = z;
     }
-    if (k < Hc)
-      for (int c = 0; c < Co; ++c) atomicAdd(dWo + c * ldwo + k, dw[c]);
   }
-  if (threadIdx.x < Co) {
-    const int c = threadIdx.x;
-    float s = 0.f;
-    for (int64_t row = r0; row < r1; ++row) {
-      const float a = alb[row * 4 + c];
-      s += albbar[row * 4 + c] * (squeeze ? a * (1.f - a) : 1.f);
-    }
-    atomicAdd(dbo + c, s);
+  // combine the 8 row phases, then one atomic per (c, column) and workgroup
+  if (ph > 0) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) red[ph - 1][c][kl + j] = dw[c][j];
+  }
+  if (cg == 0) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) redb[ph][c] = db[c];
+  }
+  __syncthreads();
+  if (ph == 0 && col_ok) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float t = dw[c][j];
+#pragma unroll
+        for (int q = 0; q < 7; ++q) t += red[q][c][kl + j];
+        if (c < Co && k0 + j < Hc) atomicAdd(dWo + c * ldwo + k0 + j, t);
+      }
+  }
+  if (bias_blk && tid < Co) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) t += redb[q][tid];
+    atomicAdd(dbo + tid, t);
   }
 }
 
 // nbar_total = nbar + J_pe(n)^T cinb[pe(n) block] ;  geb = J_pe(x) nbar_total  (input of the RA sweep)
-__global__ void nbar_geb_kernel(const float* __restrict__ x4, const float* __restrict__ nrm,
-                                const float* __restrict__ nbar_in, const float* __restrict__ cinb, int Cinp,
-                                int pen_off, int multires_view, int with_color, int multires, int Ep,
-                                int64_t M, int64_t Mp, float* __restrict__ geb) {
-  int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (row >= Mp) return;
+// One wave = 64 points.  The [pe(p) | pe(n)] block of cinb (columns blk_off .. Cinp) comes in through an LDS
+// tile, the geb rows go out through one; dynamic LDS = 64 * (max(Cinp - blk_off, Ep) + 1) floats.
+__global__ __launch_bounds__(64) void nbar_geb_kernel(const float* __restrict__ x4, const float* __restrict__ nrm,
+                                                      const float* __restrict__ nbar_in,
+                                                      const float* __restrict__ cinb, int Cinp, int blk_off,
+                                                      int pen_off, int multires_view, int with_color, int multires,
+                                                      int Ep, int64_t M, int64_t Mp, float* __restrict__ geb) {
+  extern __shared__ float tile[];
+  const int lane = threadIdx.x;
+  const int64_t r0 = (int64_t)blockIdx.x * 64, row = r0 + lane;
   float nb[3] = {0.f, 0.f, 0.f};
-  if (row < M) {
+  if (with_color) {
+    const int Wc = Cinp - blk_off;
+    tile_load64(cinb, Cinp, r0, blk_off, Wc, tile, lane);
+    __builtin_amdgcn_wave_barrier();
+    if (row < M) {
+      const float* g = tile + lane * (Wc + 1) + (pen_off - blk_off);
 #pragma unroll
-    for (int d = 0; d < 3; ++d) nb[d] = nbar_in[row * 4 + d];
-    if (with_color) {
-      const float* g = cinb + row * Cinp + pen_off;
-#pragma unroll
-      for (int d = 0; d < 3; ++d) nb[d] += g[d];
+      for (int d = 0; d < 3; ++d) nb[d] = nbar_in[row * 4 + d] + g[d];
       float f = 1.f;
       int c = 3;
       for (int k = 0; k < multires_view; ++k) {
@@ -214,8 +293,12 @@ __global__ void nbar_geb_kernel(const float* __restrict__ x4, const float* __res
         f *= 2.f;
       }
     }
+    __builtin_amdgcn_wave_barrier();   // every lane is done with the input tile before it is overwritten
+  } else if (row < M) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) nb[d] = nbar_in[row * 4 + d];
   }
-  float* o = geb + row * Ep;
+  float* o = tile + lane * (Ep + 1);
   o[0] = nb[0]; o[1] = nb[1]; o[2] = nb[2];
   int c = 3;
   float f = 1.f;
@@ -231,24 +314,58 @@ __global__ void nbar_geb_kernel(const float* __restrict__ x4, const float* __res
     f *= 2.f;
   }
   for (; c < Ep; ++c) o[c] = 0.f;
+  __builtin_amdgcn_wave_barrier();
+  tile_store64(geb, Ep, r0, 0, Ep, tile, lane);
 }
 
 // gradient of the sdf-head row: dw_sdf[k] += sum_rows ( sbar/scale * a_last + u_last ), db_sdf += sum sbar/scale
-__global__ void sdf_head_bwd_kernel(const float* __restrict__ a, const float* __restrict__ ulast, int Hp, int H,
-                                    const float* __restrict__ sbar, float inv_scale, int64_t M, int rows_per_blk,
-                                    float* __restrict__ dwsdf, float* __restrict__ dbsdf) {
+// 512 threads: thread = (4 columns, row phase of 8), 16 bytes per lane along the rows; fp64 partial sums (long
+// signed sums).  blockIdx.y = 256-column chunk.  Few, fat workgroups (same-address atomics, see
+// color_out_bwd_kernel).
+__global__ __launch_bounds__(512) void sdf_head_bwd_kernel(const float* __restrict__ a, const float* __restrict__ ulast,
+                                                           int Hp, int H, const float* __restrict__ sbar,
+                                                           float inv_scale, int64_t M, int rows_per_blk,
+                                                           float* __restrict__ dwsdf, float* __restrict__ dbsdf) {
+  __shared__ double red[7][256];
+  __shared__ double redb[8];
+  const int tid = threadIdx.x, cg = tid & 63, ph = tid >> 6;
+  const int kl = cg * 4, k0 = blockIdx.y * 256 + kl;
+  const bool col_ok = k0 < Hp;
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_blk;
   const int64_t r1 = min(M, r0 + rows_per_blk);
-  for (int k = threadIdx.x; k < H; k += blockDim.x) {
-    double s = 0.0;
-    for (int64_t row = r0; row < r1; ++row)
-      s += (double)(sbar[row] * inv_scale * a[row * Hp + k] + ulast[row * Hp + k]);
-    atomicAdd(dwsdf + k, (float)s);
+  double s[4] = {0.0, 0.0, 0.0, 0.0}, sb = 0.0;
+#pragma unroll 4
+  for (int64_t row = r0 + ph; row < r1; row += 8) {
+    const float t = sbar[row] * inv_scale;
+    if (cg == 0) sb += (double)t;
+    if (col_ok) {
+      const vf4 av = *reinterpret_cast<const vf4*>(a + row * Hp + k0);
+      const vf4 uv = *reinterpret_cast<const vf4*>(ulast + row * Hp + k0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s[j] += (double)(t * av[j] + uv[j]);
+    }
   }
-  if (threadIdx.x == 0) {
-    double s = 0.0;
-    for (int64_t row = r0; row < r1; ++row) s += (double)(sbar[row] * inv_scale);
-    atomicAdd(dbsdf, (float)s);
+  if (ph > 0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[ph - 1][kl + j] = s[j];
+  }
+  if (cg == 0) redb[ph] = sb;
+  __syncthreads();
+  if (ph == 0 && col_ok) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (k0 + j < H) {
+        double t = s[j];
+#pragma unroll
+        for (int q = 0; q < 7; ++q) t += red[q][kl + j];
+        atomicAdd(dwsdf + k0 + j, (float)t);
+      }
+  }
+  if (tid == 0 && blockIdx.y == 0) {
+    double t = 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) t += redb[q];
+    atomicAdd(dbsdf, (float)t);
   }
 }
 
@@ -510,7 +627,7 @@ struct DwBatch {
     const int v = (exact && K % 128 == 0) ? 0 : (exact && K % 64 == 0) ? 1 : 2;
     if (grp[v].njobs == kMaxDwJobs) RNB_TRY(flush(v));
     const int kt = v == 0 ? 128 : 64;                  // tile width along K of the variant (see kernel)
-    const int min_rows = v == 0 ? 512 : 256;           // points per block (half-size tiles: half the rows)
+    const int min_rows = v == 0 ? 1024 : 512;          // points per block (half-size tiles: half the rows)
     const int tiles = ((N + 127) / 128) * ((K + kt - 1) / kt);
     int splits = (int)((M + min_rows - 1) / min_rows);
     const int max_splits = (1024 + tiles - 1) / tiles;  // ~1024 blocks per job
@@ -541,6 +658,12 @@ struct DwBatch {
 };
 
 static inline unsigned blocks_for(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
+// rows per workgroup of the column-sum kernels: ~256 workgroups (bounded same-address atomics), >= 64 rows
+static inline int reduce_rows_per_block(int64_t M) {
+  int64_t r = (M + 255) / 256;
+  r = (r + 7) / 8 * 8;
+  return (int)(r < 64 ? 64 : r);
+}
 
 int launch_copy_cols(const float* src, int ld, int ncols, int64_t M, float* out, hipStream_t s) {
   hipLaunchKernelGGL(copy_cols_kernel, dim3(blocks_for(M * ncols, 256)), dim3(256), 0, s, src, ld, ncols, M, out);
@@ -608,7 +731,8 @@ int sweep_reverse(const Layout& L, const float* packed, PointBufs& pb, hipStream
 // C: albedo network (models/fields.py:177-215, mode no_view_dir).  Needs the feature block of pb.cin and pb.nrm.
 int sweep_color(const Layout& L, const float* packed, PointBufs& pb, const float* pts, const float* nrm, int nrm_ld,
                 hipStream_t s) {
-  hipLaunchKernelGGL(color_input_kernel, dim3(blocks_for(pb.Mp, 256)), dim3(256), 0, s, pts, nrm, nrm_ld, pb.M, pb.Mp,
+  hipLaunchKernelGGL(color_input_kernel, dim3(blocks_for(pb.Mp, 64)), dim3(64),
+                     (size_t)64 * (L.Cinp - L.F + 1) * sizeof(float), s, pts, nrm, nrm_ld, pb.M, pb.Mp,
                      L.F, L.multires_view, L.Cinp, pb.cin);
   RNB_CHECK_LAUNCH();
   for (int l = 0; l < L.nc; ++l) {
@@ -632,8 +756,8 @@ int sweep_backward(const Layout& L, const float* packed, PointBufs& pb, bool wit
   DwBatch dw(M, s);
   // ---- C': albedo network backward ---------------------------------------------------------------
   if (with_color) {
-    const int rows_per_blk = 64;
-    hipLaunchKernelGGL(color_out_bwd_kernel, dim3(blocks_for(M, rows_per_blk)), dim3(256), 0, s, pb.albbar, pb.alb,
+    const int rows_per_blk = reduce_rows_per_block(M);
+    hipLaunchKernelGGL(color_out_bwd_kernel, dim3(blocks_for(M, rows_per_blk), (L.Hcp + 255) / 256), dim3(512), 0, s, pb.albbar, pb.alb,
                        pb.ac[L.nc - 1], L.Hcp, L.Hc, packed + L.colo.w_off, L.colo.Kp, L.Co, L.squeeze, M,
                        rows_per_blk, pb.zc[L.nc - 1], packed_grad + L.colo.w_off, packed_grad + L.colo.b_off);
     RNB_CHECK_LAUNCH();
@@ -653,8 +777,12 @@ int sweep_backward(const Layout& L, const float* packed, PointBufs& pb, bool wit
     }
   }
   // ---- nbar (+ albedo-net contribution) -> geb = u_0 -----------------------------------------------
-  hipLaunchKernelGGL(nbar_geb_kernel, dim3(blocks_for(Mp, 256)), dim3(256), 0, s, pb.x, pb.nrm, pb.nbar, pb.cinb,
-                     L.Cinp, L.F + L.pev, L.multires_view, with_color ? 1 : 0, L.multires, L.Ep, M, Mp, pb.geb);
+  {
+    const int wt = (with_color && L.Cinp - L.F > L.Ep) ? L.Cinp - L.F : L.Ep;
+    hipLaunchKernelGGL(nbar_geb_kernel, dim3(blocks_for(Mp, 64)), dim3(64), (size_t)64 * (wt + 1) * sizeof(float), s,
+                       pb.x, pb.nrm, pb.nbar, pb.cinb, L.Cinp, L.F, L.F + L.pev, L.multires_view, with_color ? 1 : 0,
+                       L.multires, L.Ep, M, Mp, pb.geb);
+  }
   RNB_CHECK_LAUNCH();
   // ---- RA: adjoint of the reverse sweep, forward layer order -----------------------------------------
   if (fused) {
@@ -670,8 +798,8 @@ int sweep_backward(const Layout& L, const float* packed, PointBufs& pb, bool wit
   }
   // ---- sdf-head row gradient ---------------------------------------------------------------------
   {
-    const int rows_per_blk = 128;
-    hipLaunchKernelGGL(sdf_head_bwd_kernel, dim3(blocks_for(M, rows_per_blk)), dim3(256), 0, s, pb.a[L.nh - 1],
+    const int rows_per_blk = reduce_rows_per_block(M);
+    hipLaunchKernelGGL(sdf_head_bwd_kernel, dim3(blocks_for(M, rows_per_blk), (L.Hp + 255) / 256), dim3(512), 0, s, pb.a[L.nh - 1],
                        pb.u[L.nh], L.Hp, L.H, pb.sbar, 1.f / L.sdf_scale, M, rows_per_blk,
                        packed_grad + L.wsdf_off, packed_grad + L.bsdf_off);
     RNB_CHECK_LAUNCH();

@@ -190,7 +190,7 @@ int main(int argc, char** argv) {
   {
     DwPair p1{X1, N, A, K}, p2{X2, N, A, K};
     for (int njobs : {1, 8}) {
-      for (int splits : {128, 256}) {
+      for (int splits : {32, 64, 128, 256}) {
         DwGroup g;
         g.njobs = njobs;
         g.M = M;
