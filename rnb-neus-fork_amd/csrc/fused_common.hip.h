@@ -11,16 +11,6 @@ constexpr int FH = 256;       // hidden width of the fused path
 constexpr int FP = FH + 4;    // LDS pitch of the activation tile
 constexpr int FEP = 40;       // LDS pitch of the positional-encoding copy kept for the skip connection
 
-// Raw buffer access to one tile of a row-major matrix: resource = tile base + byte size, per-lane 32-bit
-// byte offset in a VGPR, wave-uniform byte offset in the scalar operand.
-typedef __amdgpu_buffer_rsrc_t BufRsrc;
-__device__ inline BufRsrc tile_rsrc(const float* p, unsigned bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, p ? bytes : 0, 0x00020000);
-}
-__device__ inline void bstore(BufRsrc r, unsigned voff, unsigned soff, float v) {
-  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
-}
-
 // One (32*TI) x 64 output block per wave: C[rows][n0..n0+63] = X[rows][K] * W[n][K]^T, K a multiple of 32.
 // k-permutation inside each 32-k block: lane half h takes k = 32Q + 16h + 4q + c, so every lane streams 64
 // contiguous bytes of its weight row per block.
@@ -106,10 +96,6 @@ __device__ inline void stagger_start(int units) {
   if (units > 0 && (((blockIdx.x >> 3) ^ (blockIdx.x >> 8)) & 1)) {
     for (int i = 0; i < units; i += 64) __builtin_amdgcn_s_sleep(64);
   }
-}
-
-__device__ inline float bload(BufRsrc r, unsigned voff, unsigned soff) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
 
 }  // namespace rnb

@@ -35,6 +35,25 @@ __device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_b
 
 __device__ inline int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
+// Raw buffer access to one tile of a row-major matrix: resource = tile base + byte size, per-lane 32-bit
+// byte offset in a VGPR, wave-uniform byte offset in the scalar operand (no per-access vector address
+// arithmetic; out-of-range reads return 0, out-of-range writes are dropped).
+typedef __amdgpu_buffer_rsrc_t BufRsrc;
+typedef float vf2 __attribute__((ext_vector_type(2)));
+typedef unsigned vu2 __attribute__((ext_vector_type(2)));
+__device__ inline BufRsrc tile_rsrc(const float* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, p ? bytes : 0, 0x00020000);
+}
+__device__ inline void bstore(BufRsrc r, unsigned voff, unsigned soff, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+}
+__device__ inline float bload(BufRsrc r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ inline vf2 bload2(BufRsrc r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(vf2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+}
+
 // ---- global -> register staging ------------------------------------------------------------------
 // k-contiguous source: element (r, k) at src[r*ld + k]; tile = ROWS rows from r0, k0..k0+31.
 template <int ROWS, bool GUARD>
@@ -379,6 +398,134 @@ __global__ __launch_bounds__(256, 3) void gemm_dw_kernel(const DwGroup g) {
     }
   }
   if (bias_blk) atomicAdd(db + n_blk + tid, (float)bsum);
+}
+
+// ---- dW without LDS ----------------------------------------------------------------------------------
+// Both operands of dW = X^T Y are point-major in memory, and v_mfma_f32_32x32x2_f32 wants exactly that: lane
+// (i, h) supplies A[row i][k = h] and B[k = h][col i], i.e. for a pair of consecutive points the two lane
+// halves read the two rows X[m + h][...] — a coalesced global load IS the fragment.  No staging, no
+// barriers: the four waves of a workgroup (2 x 2 sub-tiles of 64 x KT/2) run independently and only share
+// L1/L2 lines.  X comes in as 8-byte loads (lane i holds columns 2i, 2i+1 -> the wave's two row tiles are
+// the even and the odd rows of its 64-row band), Y as 4-byte loads (columns i and 32 + i), so a pair of
+// points costs 1 + TN loads for 2 * TN MFMAs.  Loads run two 16-point chunks ahead in a 3-slot register
+// ring (<= 63 in flight per wave).  Exact shapes only: N % 128 == 0, K % KT == 0, point ranges % 16 == 0.
+template <int KT, int OCC>
+__global__ __launch_bounds__(256, OCC) void gemm_dw_direct_kernel(const DwGroup g) {
+  constexpr int TN = KT / 64;
+  constexpr int CH = 8;   // point pairs per chunk
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = wave_id();
+  const int wm = wave >> 1, wn = wave & 1;
+  int ji = 0, begin = 0;
+  for (int q = 0; q + 1 < g.njobs; ++q)
+    if ((int)blockIdx.x >= g.job[q].block_end) { ji = q + 1; begin = g.job[q].block_end; }
+  const DwJob& J = g.job[ji];
+  const int blk = (int)blockIdx.x - begin;
+  const int M = g.M, N = J.N, K = J.K, splits = J.splits;
+  const int tiles_n = N / 128, tiles_k = K / KT;
+  const int nt = tiles_n * tiles_k;
+  if (blk >= nt * splits) return;   // padding blocks that align the next job to 8
+  int tile, split;
+  if (splits % 8 == 0) {            // XCD-aware placement, see gemm_dw_kernel
+    const int xcd = blk & 7, j = blk >> 3;
+    tile = j % nt;
+    split = (j / nt) * 8 + xcd;
+  } else {
+    tile = blk % nt;
+    split = blk / nt;
+  }
+  const int tile_n = tile % tiles_n, tile_k = tile / tiles_n;
+  const int m_begin = split * J.rows_per_split;
+  const int m_end = min(M, m_begin + J.rows_per_split);
+  if (m_begin >= m_end) return;
+  const int i = lane & 31, h = lane >> 5;
+  const int n_w = tile_n * 128 + wm * 64;          // first row (of dW) of this wave
+  const int k_w = tile_k * KT + wn * (KT / 2);     // first column
+  const int nch = (m_end - m_begin) / (2 * CH);
+  const bool bias_wave = J.db != nullptr && tile_k == 0 && wn == 0;
+
+  v16f acc[2][TN];
+  zero_acc<TN>(acc);
+  double bs0 = 0.0, bs1 = 0.0;   // column sums of X (bias gradient), fp64 partials
+
+  for (int pi = 0; pi < J.npairs; ++pi) {
+    const DwPair p = pi == 0 ? J.p1 : J.p2;
+    const bool do_bias = bias_wave && pi == J.bias_pair;
+    const unsigned xrow = (unsigned)p.ldx * 4u, yrow = (unsigned)p.ldy * 4u;   // row pitch in bytes
+    const BufRsrc rx = tile_rsrc(p.X + (size_t)m_begin * p.ldx, (unsigned)(m_end - m_begin) * xrow);
+    const BufRsrc ry = tile_rsrc(p.Y + (size_t)m_begin * p.ldy, (unsigned)(m_end - m_begin) * yrow);
+    const unsigned vx = (unsigned)h * xrow + (unsigned)(n_w + 2 * i) * 4u;
+    const unsigned vy = (unsigned)h * yrow + (unsigned)(k_w + i) * 4u;
+    vf2 a[3][CH];
+    float b[3][CH][TN];
+#define RNB_DW_LOAD(slot, chunk)                                                     \
+    {                                                                                  \
+      const int c_ = min((chunk), nch - 1);                                            \
+      const unsigned sx = (unsigned)c_ * (2 * CH) * xrow, sy = (unsigned)c_ * (2 * CH) * yrow; \
+      _Pragma("unroll") for (int q = 0; q < CH; ++q) {                                 \
+        a[slot][q] = bload2(rx, vx, sx + (unsigned)(2 * q) * xrow);                    \
+        _Pragma("unroll") for (int tj = 0; tj < TN; ++tj)                              \
+          b[slot][q][tj] = bload(ry, vy + (unsigned)tj * 128u, sy + (unsigned)(2 * q) * yrow); \
+      }                                                                                \
+    }
+#define RNB_DW_MMA(slot)                                                               \
+    {                                                                                  \
+      _Pragma("unroll") for (int q = 0; q < CH; ++q) {                                 \
+        _Pragma("unroll") for (int tj = 0; tj < TN; ++tj) {                            \
+          acc[0][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[slot][q].x, b[slot][q][tj], acc[0][tj], 0, 0, 0); \
+          acc[1][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[slot][q].y, b[slot][q][tj], acc[1][tj], 0, 0, 0); \
+        }                                                                              \
+      }                                                                                \
+      if (do_bias) {   /* 16 points in fp32, then into the fp64 partial */                 \
+        float t0 = 0.f, t1 = 0.f;                                                      \
+        _Pragma("unroll") for (int q = 0; q < CH; ++q) { t0 += a[slot][q].x; t1 += a[slot][q].y; } \
+        bs0 += (double)t0;                                                             \
+        bs1 += (double)t1;                                                             \
+      }                                                                                \
+    }
+    RNB_DW_LOAD(0, 0)
+    RNB_DW_LOAD(1, 1)
+    for (int c = 0; c < nch; c += 3) {
+      RNB_DW_LOAD(2, c + 2)
+      __builtin_amdgcn_sched_barrier(0);
+      RNB_DW_MMA(0)
+      __builtin_amdgcn_sched_barrier(0);
+      RNB_DW_LOAD(0, c + 3)
+      __builtin_amdgcn_sched_barrier(0);
+      if (c + 1 < nch) RNB_DW_MMA(1)
+      __builtin_amdgcn_sched_barrier(0);
+      RNB_DW_LOAD(1, c + 4)
+      __builtin_amdgcn_sched_barrier(0);
+      if (c + 2 < nch) RNB_DW_MMA(2)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#undef RNB_DW_LOAD
+#undef RNB_DW_MMA
+  }
+  // atomics: accumulator (ti, tj, r) of lane (i, h) is dW[n_w + 2 * rho + ti][k_w + 32 * tj + i],
+  // rho = (r & 3) + 8 * (r >> 2) + 4 * h
+  float* __restrict__ dW = J.dW;
+  const int lddw = J.lddw;
+#pragma unroll
+  for (int tj = 0; tj < TN; ++tj) {
+    const int col = k_w + tj * 32 + i;
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = n_w + 2 * ((r & 3) + 8 * (r >> 2) + 4 * h) + ti;
+        atomicAdd(dW + (size_t)row * lddw + col, acc[ti][tj][r]);
+      }
+    }
+  }
+  if (bias_wave) {
+    bs0 += __shfl_xor(bs0, 32, 64);
+    bs1 += __shfl_xor(bs1, 32, 64);
+    if (h == 0) {
+      atomicAdd(J.db + n_w + 2 * i, (float)bs0);
+      atomicAdd(J.db + n_w + 2 * i + 1, (float)bs1);
+    }
+  }
 }
 
 // ---- activation helpers ----------------------------------------------------------------------------

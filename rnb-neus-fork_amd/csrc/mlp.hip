@@ -610,10 +610,31 @@ struct DwBatch {
   int flush(int v) {
     DwGroup& g = grp[v];
     if (g.njobs == 0) return RNB_OK;
+    // Jobs are added in the order the backward produces their operands (layer nh-1 first); launch them
+    // most-recent-first so that the operands written last (zb_0, zb_1, ...) are still in the memory-side
+    // cache when their job runs.
+    for (int a = 0, b = g.njobs - 1; a < b; ++a, --b) {
+      const DwJob t = g.job[a];
+      g.job[a] = g.job[b];
+      g.job[b] = t;
+    }
+    {
+      int end = 0;   // recompute the prefix sums of the block counts for the new order
+      for (int q = 0; q < g.njobs; ++q) {
+        DwJob& j = g.job[q];
+        const int kt = v == 0 ? 128 : 64;
+        const int tiles = ((j.N + 127) / 128) * ((j.K + kt - 1) / kt);
+        end += (tiles * j.splits + 7) / 8 * 8;
+        j.block_end = end;
+      }
+    }
     const dim3 grid((unsigned)g.job[g.njobs - 1].block_end);
     {
       ProfScope prof(flops[v], s);
-      if (v == 0) hipLaunchKernelGGL((gemm_dw_kernel<false, 128>), grid, dim3(256), 0, s, g);
+      static const bool lds_path = getenv("RNB_DW_LDS") != nullptr;   // A/B switch: staged-through-LDS kernels
+      if (v == 0 && !lds_path) hipLaunchKernelGGL((gemm_dw_direct_kernel<128, 3>), grid, dim3(256), 0, s, g);
+      else if (v == 1 && !lds_path) hipLaunchKernelGGL((gemm_dw_direct_kernel<64, 3>), grid, dim3(256), 0, s, g);
+      else if (v == 0) hipLaunchKernelGGL((gemm_dw_kernel<false, 128>), grid, dim3(256), 0, s, g);
       else if (v == 1) hipLaunchKernelGGL((gemm_dw_kernel<false, 64>), grid, dim3(256), 0, s, g);
       else hipLaunchKernelGGL((gemm_dw_kernel<true, 64>), grid, dim3(256), 0, s, g);
     }
@@ -651,8 +672,8 @@ struct DwBatch {
     return RNB_OK;
   }
   int flush_all() {
+    RNB_TRY(flush(1));   // holds the first layer's job: its operands are the most recent
     RNB_TRY(flush(0));
-    RNB_TRY(flush(1));
     return flush(2);
   }
 };

@@ -206,6 +206,10 @@ int main(int argc, char** argv) {
         report(name, time_it([&] {
                  hipLaunchKernelGGL((gemm_dw_kernel<false, 128>), dim3(g.job[njobs - 1].block_end), dim3(256), 0, 0, g);
                }, iters), 2 * flops * njobs);
+        snprintf(name, sizeof name, "dW direct (no LDS),   %d job(s)/launch, %d splits", njobs, splits);
+        report(name, time_it([&] {
+                 hipLaunchKernelGGL((gemm_dw_direct_kernel<128, 3>), dim3(g.job[njobs - 1].block_end), dim3(256), 0, 0, g);
+               }, iters), 2 * flops * njobs);
       }
     }
   }
