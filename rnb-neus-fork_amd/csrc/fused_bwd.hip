@@ -60,6 +60,36 @@ __device__ inline void for_each_acc(int n0, int lane, F f) {
   }
 }
 
+// Same visit, split per 32-column tile into a branch-free body for tiles that lie entirely below `limit`
+// (wave-uniform test: n0 and limit are scalars) and a general body for the one tile that may straddle it.
+// On gfx950 the fp32 MFMA and ordinary vector instructions exclude each other on a SIMD (tools/overlap_probe),
+// so every per-element compare / exec-mask round trip in an epilogue is matrix time lost.
+template <class FF, class FS>
+__device__ inline void for_each_acc_split(int n0, int lane, int limit, FF fast, FS slow) {
+  const int h = lane >> 5, cl = lane & 31;
+#pragma unroll
+  for (int tj = 0; tj < 2; ++tj) {
+    const int col = n0 + tj * 32 + cl;
+    if (n0 + tj * 32 + 32 <= limit) {
+#pragma unroll
+      for (int ti = 0; ti < BTI; ++ti)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rowc = ti * 32 + (r & 3) + 8 * (r >> 2);
+          fast(tj, ti, r, col, rowc, rowc + 4 * h);
+        }
+    } else {
+#pragma unroll
+      for (int ti = 0; ti < BTI; ++ti)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rowc = ti * 32 + (r & 3) + 8 * (r >> 2);
+          slow(tj, ti, r, col, rowc, rowc + 4 * h);
+        }
+    }
+  }
+}
+
 // issues the buffer loads of one [BT x 256] tile in accumulator layout (no wait: consumed after the MFMA loop)
 __device__ inline void prefetch_tile(const float* base, int64_t row0, int n0, int lane, AuxTile& t) {
   const BufRsrc rs = tile_rsrc(base + (size_t)row0 * FH, BT * FH * 4);
@@ -111,19 +141,25 @@ __global__ __launch_bounds__(256, 2) void fused_reverse_kernel(FusedBwdArgs g) {
     const bool is_skip = (l == g.skip);
     const int ksplit = is_skip ? FH - g.pe : FH;   // columns that belong to layer l-1's output
     const BufRsrc rg = tile_rsrc(g.gz[l - 1] + (size_t)row0 * FH, BT * FH * 4);
-    for_each_acc(n0, lane, [&](int tj, int ti, int r, int col, int rowc, int row) {
-      const unsigned voff = (unsigned)(4 * h * FH + col) * 4u;
-      const float v = acc[ti][tj][r];
-      float gzv;
-      if (col < ksplit) {
-        gzv = v * aD[ti][tj][r];
-      } else {
-        if (col < ksplit + g.pe) GE[row * FEP + (col - ksplit)] = v;   // skip connection: straight to g_e
-        gzv = 0.f;
-      }
-      Y[row * FP + col] = gzv;
-      bstore(rg, voff, rowc * FH * 4, gzv);
-    });
+    for_each_acc_split(
+        n0, lane, ksplit,
+        [&](int tj, int ti, int r, int col, int rowc, int row) {
+          const float gzv = acc[ti][tj][r] * aD[ti][tj][r];
+          Y[row * FP + col] = gzv;
+          bstore(rg, (unsigned)(4 * h * FH + col) * 4u, rowc * FH * 4, gzv);
+        },
+        [&](int tj, int ti, int r, int col, int rowc, int row) {
+          const float v = acc[ti][tj][r];
+          float gzv;
+          if (col < ksplit) {
+            gzv = v * aD[ti][tj][r];
+          } else {
+            if (col < ksplit + g.pe) GE[row * FEP + (col - ksplit)] = v;   // skip connection: straight to g_e
+            gzv = 0.f;
+          }
+          Y[row * FP + col] = gzv;
+          bstore(rg, (unsigned)(4 * h * FH + col) * 4u, rowc * FH * 4, gzv);
+        });
     lds_barrier();
     { float* t = X; X = Y; Y = t; }
   }
@@ -193,23 +229,34 @@ __global__ __launch_bounds__(256, 2) void fused_ra_kernel(FusedBwdArgs g) {
     const bool pe_tail = (l + 1 == g.skip);
     const BufRsrc rzR = tile_rsrc(g.zR[l] + (size_t)row0 * FH, BT * FH * 4);
     const BufRsrc ru = tile_rsrc(g.u[l + 1] + (size_t)row0 * FH, BT * FH * 4);
-    for_each_acc(n0, lane, [&](int tj, int ti, int r, int col, int rowc, int row) {
-      const unsigned voff = (unsigned)(4 * h * FH + col) * 4u;
-      const unsigned soff = rowc * FH * 4;
-      const float v = acc[ti][tj][r];
-      float zr, un;
-      if (col < n_real) {
-        const float D = aD[ti][tj][r];
-        zr = 100.f * v * aG[ti][tj][r] * (1.f - D);
-        un = v * D;
-      } else {
-        zr = 0.f;
-        un = (pe_tail && col < n_real + g.pe) ? E[row * FEP + (col - n_real)] : 0.f;
-      }
-      Y[row * FP + col] = un;
-      bstore(rzR, voff, soff, zr);
-      bstore(ru, voff, soff, un);
-    });
+    for_each_acc_split(
+        n0, lane, n_real,
+        [&](int tj, int ti, int r, int col, int rowc, int row) {
+          const unsigned voff = (unsigned)(4 * h * FH + col) * 4u;
+          const unsigned soff = rowc * FH * 4;
+          const float v = acc[ti][tj][r];
+          const float un = v * aD[ti][tj][r];
+          const float zr = ((v - un) * aG[ti][tj][r]) * 100.f;   // 100 v gz (1 - D)
+          Y[row * FP + col] = un;
+          bstore(rzR, voff, soff, zr);
+          bstore(ru, voff, soff, un);
+        },
+        [&](int tj, int ti, int r, int col, int rowc, int row) {
+          const unsigned voff = (unsigned)(4 * h * FH + col) * 4u;
+          const unsigned soff = rowc * FH * 4;
+          const float v = acc[ti][tj][r];
+          float zr, un;
+          if (col < n_real) {
+            un = v * aD[ti][tj][r];
+            zr = ((v - un) * aG[ti][tj][r]) * 100.f;
+          } else {
+            zr = 0.f;
+            un = (pe_tail && col < n_real + g.pe) ? E[row * FEP + (col - n_real)] : 0.f;
+          }
+          Y[row * FP + col] = un;
+          bstore(rzR, voff, soff, zr);
+          bstore(ru, voff, soff, un);
+        });
     lds_barrier();
     { float* t = X; X = Y; Y = t; }
   }
@@ -248,18 +295,23 @@ __global__ __launch_bounds__(256, 2) void fused_fb_kernel(FusedBwdArgs g) {
     const int n_real = g.n_real[l];
     const bool head = (l == g.nh - 1);
     const BufRsrc rzb = tile_rsrc(g.zb[l] + (size_t)row0 * FH, BT * FH * 4);
-    for_each_acc(n0, lane, [&](int tj, int ti, int r, int col, int rowc, int row) {
-      const unsigned voff = (unsigned)(4 * h * FH + col) * 4u;
-      const unsigned soff = rowc * FH * 4;
-      float v = acc[ti][tj][r];
-      float zb = 0.f;
-      if (col < n_real) {
-        if (head) v = fmaf(g.sbar[row0 + row] * g.inv_scale, g.packed[g.wsdf_off + col], v);
-        zb = fmaf(v, aD[ti][tj][r], aZ[ti][tj][r]);
-      }
-      Y[row * FP + col] = zb;
-      bstore(rzb, voff, soff, zb);
-    });
+    if (head) {   // + sbar / scale * w_sdf  (the sdf head's contribution to ab_{nh-1}); once per launch
+      for_each_acc(n0, lane, [&](int tj, int ti, int r, int col, int rowc, int row) {
+        acc[ti][tj][r] = fmaf(g.sbar[row0 + row] * g.inv_scale, g.packed[g.wsdf_off + col], acc[ti][tj][r]);
+      });
+    }
+    for_each_acc_split(
+        n0, lane, n_real,
+        [&](int tj, int ti, int r, int col, int rowc, int row) {
+          const float zb = fmaf(acc[ti][tj][r], aD[ti][tj][r], aZ[ti][tj][r]);
+          Y[row * FP + col] = zb;
+          bstore(rzb, (unsigned)(4 * h * FH + col) * 4u, rowc * FH * 4, zb);
+        },
+        [&](int tj, int ti, int r, int col, int rowc, int row) {
+          const float zb = col < n_real ? fmaf(acc[ti][tj][r], aD[ti][tj][r], aZ[ti][tj][r]) : 0.f;
+          Y[row * FP + col] = zb;
+          bstore(rzb, (unsigned)(4 * h * FH + col) * 4u, rowc * FH * 4, zb);
+        });
     if (l == 0) break;
     lds_barrier();
     { float* t = X; X = Y; Y = t; }
