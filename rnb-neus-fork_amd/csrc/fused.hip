@@ -120,20 +120,28 @@ __global__ __launch_bounds__(256, 2) void fused_forward_kernel(FusedFwdArgs g) {
 #pragma unroll
       for (int ti = 0; ti < TI; ++ti) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
+        for (int r = 0; r < 16; r += 2) {
+          // registers r, r + 1 are rows rowc, rowc + 1 of the same column: softplus on the pair (packed math)
           const int rowc = ti * 32 + (r & 3) + 8 * (r >> 2);   // compile-time part of the row
           const int row = rowc + 4 * h;
-          float a, D;
-          softplus_aD(acc[ti][tj][r] + bc, a, D);
+          vf2 a, D;
+          softplus_aD(vf2{acc[ti][tj][r] + bc, acc[ti][tj][r + 1] + bc}, a, D);
           if (!tile_full && col >= n_real) {   // only the tile straddling the skip connection's PE columns
-            a = (pe_tail && col < n_real + g.pe) ? E[row * FEP + (col - n_real)] : 0.f;
-            D = 0.f;
+            const bool pe_col = pe_tail && col < n_real + g.pe;
+            a = vf2{pe_col ? E[row * FEP + (col - n_real)] : 0.f, pe_col ? E[(row + 1) * FEP + (col - n_real)] : 0.f};
+            D = vf2{0.f, 0.f};
           }
-          Y[row * FP + col] = a;
+          Y[row * FP + col] = a.x;
+          Y[(row + 1) * FP + col] = a.y;
           if (SAVE) {
-            bstore(ra, voff, rowc * FH * 4, a);
-            bstore(rD, voff, rowc * FH * 4, D);
-            if (last && g.gz_last) bstore(rg, voff, rowc * FH * 4, ws * D);
+            bstore(ra, voff, rowc * FH * 4, a.x);
+            bstore(ra, voff, (rowc + 1) * FH * 4, a.y);
+            bstore(rD, voff, rowc * FH * 4, D.x);
+            bstore(rD, voff, (rowc + 1) * FH * 4, D.y);
+            if (last && g.gz_last) {
+              bstore(rg, voff, rowc * FH * 4, ws * D.x);
+              bstore(rg, voff, (rowc + 1) * FH * 4, ws * D.y);
+            }
           }
         }
       }

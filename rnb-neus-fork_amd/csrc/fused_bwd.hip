@@ -14,8 +14,11 @@
 
 namespace rnb {
 
-constexpr int BTI = 1;          // row tiles per workgroup (2 measured slower: 1 workgroup per CU)
-constexpr int BT = 32 * BTI;    // points per workgroup
+// TI = row tiles per workgroup (template parameter of every kernel below).  TI == 1: 32-point tiles, two
+// activation tiles in LDS (a layer reads one and writes the other: one barrier per layer).  TI == 2: 64-point
+// tiles, ONE tile updated in place behind a second barrier (two would leave room for only one workgroup per
+// CU); the matrix loop then runs 64 MFMAs per weight block instead of 32, which is what lifts it from ~77 %
+// to ~90 % of the matrix peak (tools/mfma_probe).
 
 struct FusedBwdArgs {
   const float* packed;
@@ -39,18 +42,22 @@ struct FusedBwdArgs {
   int hook_late, stagger;   // tuning knobs (RNB_HOOK_LATE, RNB_STAGGER)
 };
 
-typedef float AuxTile[BTI][2][16];   // one value per accumulator element of the wave's BT x 64 block
+// AuxTile<TI>: one value per accumulator element of the wave's (32 TI) x 64 block
+template <int TI>
+struct AuxTile {
+  float v[TI][2][16];
+};
 
 // visits the wave's BT x 64 accumulator block: f(tj, ti, r, col, rowc, row) with rowc the lane-independent
 // part of the row (compile-time after unrolling) and row = rowc + 4*(lane>>5)
-template <class F>
+template <int TI, class F>
 __device__ inline void for_each_acc(int n0, int lane, F f) {
   const int h = lane >> 5, cl = lane & 31;
 #pragma unroll
   for (int tj = 0; tj < 2; ++tj) {
     const int col = n0 + tj * 32 + cl;
 #pragma unroll
-    for (int ti = 0; ti < BTI; ++ti) {
+    for (int ti = 0; ti < TI; ++ti) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int rowc = ti * 32 + (r & 3) + 8 * (r >> 2);
@@ -64,7 +71,7 @@ __device__ inline void for_each_acc(int n0, int lane, F f) {
 // (wave-uniform test: n0 and limit are scalars) and a general body for the one tile that may straddle it.
 // On gfx950 the fp32 MFMA and ordinary vector instructions exclude each other on a SIMD (tools/overlap_probe),
 // so every per-element compare / exec-mask round trip in an epilogue is matrix time lost.
-template <class FF, class FS>
+template <int TI, class FF, class FS>
 __device__ inline void for_each_acc_split(int n0, int lane, int limit, FF fast, FS slow) {
   const int h = lane >> 5, cl = lane & 31;
 #pragma unroll
@@ -72,7 +79,7 @@ __device__ inline void for_each_acc_split(int n0, int lane, int limit, FF fast, 
     const int col = n0 + tj * 32 + cl;
     if (n0 + tj * 32 + 32 <= limit) {
 #pragma unroll
-      for (int ti = 0; ti < BTI; ++ti)
+      for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int rowc = ti * 32 + (r & 3) + 8 * (r >> 2);
@@ -80,7 +87,7 @@ __device__ inline void for_each_acc_split(int n0, int lane, int limit, FF fast, 
         }
     } else {
 #pragma unroll
-      for (int ti = 0; ti < BTI; ++ti)
+      for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int rowc = ti * 32 + (r & 3) + 8 * (r >> 2);
@@ -91,23 +98,35 @@ __device__ inline void for_each_acc_split(int n0, int lane, int limit, FF fast, 
 }
 
 // issues the buffer loads of one [BT x 256] tile in accumulator layout (no wait: consumed after the MFMA loop)
-__device__ inline void prefetch_tile(const float* base, int64_t row0, int n0, int lane, AuxTile& t) {
-  const BufRsrc rs = tile_rsrc(base + (size_t)row0 * FH, BT * FH * 4);
+template <int TI>
+__device__ inline void prefetch_tile(const float* base, int64_t row0, int n0, int lane, AuxTile<TI>& t) {
+  const BufRsrc rs = tile_rsrc(base + (size_t)row0 * FH, 32 * TI * FH * 4);
   const int h = lane >> 5;
-  for_each_acc(n0, lane, [&](int tj, int ti, int r, int col, int rowc, int row) {
-    t[ti][tj][r] = bload(rs, (unsigned)(4 * h * FH + col) * 4u, rowc * FH * 4);
+  for_each_acc<TI>(n0, lane, [&](int tj, int ti, int r, int col, int rowc, int row) {
+    t.v[ti][tj][r] = bload(rs, (unsigned)(4 * h * FH + col) * 4u, rowc * FH * 4);
   });
+}
+
+// matrix loop of one layer: two alternating weight-register sets for 32-point tiles, the one-set ring for
+// 64-point tiles (register budget)
+template <int TI, class Hook = NoHook>
+__device__ inline void layer_mma(const float* __restrict__ X, const float* __restrict__ W, int K, int n0, int lane,
+                                 v16f (&acc)[TI][2], Hook hook = Hook(), int hook_late = 0) {
+  if constexpr (TI == 1) layer_mma_nt<TI>(X, W, K, n0, lane, acc, hook, hook_late);
+  else layer_mma_nt_ring<TI>(X, W, K, n0, lane, acc, hook, 1);
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // R sweep
 // ---------------------------------------------------------------------------------------------------------
+template <int TI>
 __global__ __launch_bounds__(256, 2) void fused_reverse_kernel(FusedBwdArgs g) {
-  // two activation tiles (ping-pong): a layer reads one and writes the other, so one barrier per layer
-  __shared__ __attribute__((aligned(16))) float lds[2 * BT * FP + BT * FEP];
-  float* X = lds;              // input of the current layer
-  float* Y = lds + BT * FP;    // output of the current layer
-  float* GE = lds + 2 * BT * FP;   // d sdf / d e of the tile
+  constexpr int BT = 32 * TI;
+  constexpr int NBUF = TI == 1 ? 2 : 1;
+  __shared__ __attribute__((aligned(16))) float lds[NBUF * BT * FP + BT * FEP];
+  float* X = lds;                          // input of the current layer
+  float* Y = lds + (NBUF - 1) * BT * FP;   // output of the current layer (== X when updated in place)
+  float* GE = lds + NBUF * BT * FP;        // d sdf / d e of the tile
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = wave_id();
   const int64_t row0 = (int64_t)blockIdx.x * BT;
@@ -132,19 +151,20 @@ __global__ __launch_bounds__(256, 2) void fused_reverse_kernel(FusedBwdArgs g) {
   }
   __syncthreads();
 
-  v16f acc[BTI][2];
-  AuxTile aD;
+  v16f acc[TI][2];
+  AuxTile<TI> aD;
   for (int l = g.nh - 1; l >= 1; --l) {
-    zero_acc2<BTI>(acc);
-    layer_mma_nt<BTI>(X, g.packed + g.wT_off[l], FH, n0, lane, acc,   // g = gz_l W_l  (columns = inputs of layer l)
-                      [&]() { prefetch_tile(g.D[l - 1], row0, n0, lane, aD); }, g.hook_late);
+    zero_acc2<TI>(acc);
+    layer_mma<TI>(X, g.packed + g.wT_off[l], FH, n0, lane, acc,   // g = gz_l W_l  (columns = inputs of layer l)
+                     [&]() { prefetch_tile<TI>(g.D[l - 1], row0, n0, lane, aD); }, g.hook_late);
+    if constexpr (NBUF == 1) lds_barrier();   // every wave has finished reading the tile
     const bool is_skip = (l == g.skip);
     const int ksplit = is_skip ? FH - g.pe : FH;   // columns that belong to layer l-1's output
     const BufRsrc rg = tile_rsrc(g.gz[l - 1] + (size_t)row0 * FH, BT * FH * 4);
-    for_each_acc_split(
+    for_each_acc_split<TI>(
         n0, lane, ksplit,
         [&](int tj, int ti, int r, int col, int rowc, int row) {
-          const float gzv = acc[ti][tj][r] * aD[ti][tj][r];
+          const float gzv = acc[ti][tj][r] * aD.v[ti][tj][r];
           Y[row * FP + col] = gzv;
           bstore(rg, (unsigned)(4 * h * FH + col) * 4u, rowc * FH * 4, gzv);
         },
@@ -152,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void fused_reverse_kernel(FusedBwdArgs g) {
           const float v = acc[ti][tj][r];
           float gzv;
           if (col < ksplit) {
-            gzv = v * aD[ti][tj][r];
+            gzv = v * aD.v[ti][tj][r];
           } else {
             if (col < ksplit + g.pe) GE[row * FEP + (col - ksplit)] = v;   // skip connection: straight to g_e
             gzv = 0.f;
@@ -161,13 +181,13 @@ __global__ __launch_bounds__(256, 2) void fused_reverse_kernel(FusedBwdArgs g) {
           bstore(rg, (unsigned)(4 * h * FH + col) * 4u, rowc * FH * 4, gzv);
         });
     lds_barrier();
-    { float* t = X; X = Y; Y = t; }
+    if constexpr (NBUF == 2) { float* t = X; X = Y; Y = t; }
   }
   // layer 0: g_e += gz_0 W_0 (Ep = 64 columns: wave 0 only)
   if (wave == 0) {
-    zero_acc2<BTI>(acc);
-    layer_mma_nt<BTI>(X, g.packed + g.wT_off[0], FH, 0, lane, acc);
-    for_each_acc(0, lane, [&](int tj, int ti, int r, int col, int rowc, int row) {
+    zero_acc2<TI>(acc);
+    layer_mma<TI>(X, g.packed + g.wT_off[0], FH, 0, lane, acc);
+    for_each_acc<TI>(0, lane, [&](int tj, int ti, int r, int col, int rowc, int row) {
       if (col < g.pe) GE[row * FEP + col] += acc[ti][tj][r];
     });
   }
@@ -196,11 +216,14 @@ __global__ __launch_bounds__(256, 2) void fused_reverse_kernel(FusedBwdArgs g) {
 // ---------------------------------------------------------------------------------------------------------
 // RA sweep
 // ---------------------------------------------------------------------------------------------------------
+template <int TI>
 __global__ __launch_bounds__(256, 2) void fused_ra_kernel(FusedBwdArgs g) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * BT * FP + BT * FEP];
-  float* X = lds;              // ping-pong activation tiles (one barrier per layer)
-  float* Y = lds + BT * FP;
-  float* E = lds + 2 * BT * FP;   // adjoint of g_e of the tile (re-enters at the skip connection)
+  constexpr int BT = 32 * TI;
+  constexpr int NBUF = TI == 1 ? 2 : 1;
+  __shared__ __attribute__((aligned(16))) float lds[NBUF * BT * FP + BT * FEP];
+  float* X = lds;
+  float* Y = lds + (NBUF - 1) * BT * FP;
+  float* E = lds + NBUF * BT * FP;   // adjoint of g_e of the tile (re-enters at the skip connection)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = wave_id();
   const int64_t row0 = (int64_t)blockIdx.x * BT;
@@ -216,27 +239,31 @@ __global__ __launch_bounds__(256, 2) void fused_ra_kernel(FusedBwdArgs g) {
   }
   __syncthreads();
 
-  v16f acc[BTI][2];
-  AuxTile aD, aG;
+  v16f acc[TI][2];
+  AuxTile<TI> aD, aG;
   for (int l = 0; l < g.nh; ++l) {
-    zero_acc2<BTI>(acc);
-    layer_mma_nt<BTI>(X, g.packed + g.w_off[l], g.Kp[l], n0, lane, acc,   // gzb = u_l W_l^T
-                      [&]() {
-                        prefetch_tile(g.D[l], row0, n0, lane, aD);
-                        prefetch_tile(g.gz[l], row0, n0, lane, aG);
-                      }, g.hook_late);
+    zero_acc2<TI>(acc);
+    // TI == 2: only one operand tile fits next to the weight fragments during the matrix loop; the second
+    // one is requested right after it, into the registers the weight fragments leave behind
+    layer_mma<TI>(X, g.packed + g.w_off[l], g.Kp[l], n0, lane, acc,   // gzb = u_l W_l^T
+                     [&]() {
+                       prefetch_tile<TI>(g.D[l], row0, n0, lane, aD);
+                       if constexpr (TI == 1) prefetch_tile<TI>(g.gz[l], row0, n0, lane, aG);
+                     }, g.hook_late);
+    if constexpr (TI == 2) prefetch_tile<TI>(g.gz[l], row0, n0, lane, aG);
+    if constexpr (NBUF == 1) lds_barrier();
     const int n_real = g.n_real[l];
     const bool pe_tail = (l + 1 == g.skip);
     const BufRsrc rzR = tile_rsrc(g.zR[l] + (size_t)row0 * FH, BT * FH * 4);
     const BufRsrc ru = tile_rsrc(g.u[l + 1] + (size_t)row0 * FH, BT * FH * 4);
-    for_each_acc_split(
+    for_each_acc_split<TI>(
         n0, lane, n_real,
         [&](int tj, int ti, int r, int col, int rowc, int row) {
           const unsigned voff = (unsigned)(4 * h * FH + col) * 4u;
           const unsigned soff = rowc * FH * 4;
           const float v = acc[ti][tj][r];
-          const float un = v * aD[ti][tj][r];
-          const float zr = ((v - un) * aG[ti][tj][r]) * 100.f;   // 100 v gz (1 - D)
+          const float un = v * aD.v[ti][tj][r];
+          const float zr = ((v - un) * aG.v[ti][tj][r]) * 100.f;   // 100 v gz (1 - D)
           Y[row * FP + col] = un;
           bstore(rzR, voff, soff, zr);
           bstore(ru, voff, soff, un);
@@ -247,8 +274,8 @@ __global__ __launch_bounds__(256, 2) void fused_ra_kernel(FusedBwdArgs g) {
           const float v = acc[ti][tj][r];
           float zr, un;
           if (col < n_real) {
-            un = v * aD[ti][tj][r];
-            zr = ((v - un) * aG[ti][tj][r]) * 100.f;
+            un = v * aD.v[ti][tj][r];
+            zr = ((v - un) * aG.v[ti][tj][r]) * 100.f;
           } else {
             zr = 0.f;
             un = (pe_tail && col < n_real + g.pe) ? E[row * FEP + (col - n_real)] : 0.f;
@@ -258,17 +285,20 @@ __global__ __launch_bounds__(256, 2) void fused_ra_kernel(FusedBwdArgs g) {
           bstore(ru, voff, soff, un);
         });
     lds_barrier();
-    { float* t = X; X = Y; Y = t; }
+    if constexpr (NBUF == 2) { float* t = X; X = Y; Y = t; }
   }
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // FB sweep
 // ---------------------------------------------------------------------------------------------------------
+template <int TI>
 __global__ __launch_bounds__(256, 2) void fused_fb_kernel(FusedBwdArgs g) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * BT * FP];
-  float* X = lds;              // ping-pong activation tiles (one barrier per layer)
-  float* Y = lds + BT * FP;
+  constexpr int BT = 32 * TI;
+  constexpr int NBUF = TI == 1 ? 2 : 1;
+  __shared__ __attribute__((aligned(16))) float lds[NBUF * BT * FP];
+  float* X = lds;
+  float* Y = lds + (NBUF - 1) * BT * FP;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = wave_id();
   const int64_t row0 = (int64_t)blockIdx.x * BT;
@@ -276,11 +306,11 @@ __global__ __launch_bounds__(256, 2) void fused_fb_kernel(FusedBwdArgs g) {
   const int h = lane >> 5;
   stagger_start(g.stagger);
 
-  v16f acc[BTI][2];
-  AuxTile aD, aZ;
-  prefetch_tile(g.D[g.nh - 1], row0, n0, lane, aD);
-  prefetch_tile(g.zR[g.nh - 1], row0, n0, lane, aZ);
-  zero_acc2<BTI>(acc);
+  v16f acc[TI][2];
+  AuxTile<TI> aD, aZ;
+  prefetch_tile<TI>(g.D[g.nh - 1], row0, n0, lane, aD);
+  prefetch_tile<TI>(g.zR[g.nh - 1], row0, n0, lane, aZ);
+  zero_acc2<TI>(acc);
   if (g.fbar != nullptr) {   // ab_{nh-1} = fbar W_feat (+ the sdf-head term below)
     const float* fb = g.fbar + (size_t)row0 * g.ld_fbar;
     for (int idx = tid; idx < BT * FH / 4; idx += 256) {
@@ -288,7 +318,8 @@ __global__ __launch_bounds__(256, 2) void fused_fb_kernel(FusedBwdArgs g) {
       *reinterpret_cast<vf4*>(X + r * FP + c4 * 4) = *reinterpret_cast<const vf4*>(fb + (size_t)r * g.ld_fbar + c4 * 4);
     }
     __syncthreads();
-    layer_mma_nt<BTI>(X, g.packed + g.wfT_off, FH, n0, lane, acc);
+    layer_mma<TI>(X, g.packed + g.wfT_off, FH, n0, lane, acc);
+    if constexpr (NBUF == 1) lds_barrier();
   }
   for (int l = g.nh - 1; l >= 0; --l) {
     // epilogue of the product that produced ab_l: zb_l = ab_l * D_l + zR_l
@@ -296,31 +327,33 @@ __global__ __launch_bounds__(256, 2) void fused_fb_kernel(FusedBwdArgs g) {
     const bool head = (l == g.nh - 1);
     const BufRsrc rzb = tile_rsrc(g.zb[l] + (size_t)row0 * FH, BT * FH * 4);
     if (head) {   // + sbar / scale * w_sdf  (the sdf head's contribution to ab_{nh-1}); once per launch
-      for_each_acc(n0, lane, [&](int tj, int ti, int r, int col, int rowc, int row) {
+      for_each_acc<TI>(n0, lane, [&](int tj, int ti, int r, int col, int rowc, int row) {
         acc[ti][tj][r] = fmaf(g.sbar[row0 + row] * g.inv_scale, g.packed[g.wsdf_off + col], acc[ti][tj][r]);
       });
     }
-    for_each_acc_split(
+    for_each_acc_split<TI>(
         n0, lane, n_real,
         [&](int tj, int ti, int r, int col, int rowc, int row) {
-          const float zb = fmaf(acc[ti][tj][r], aD[ti][tj][r], aZ[ti][tj][r]);
+          const float zb = fmaf(acc[ti][tj][r], aD.v[ti][tj][r], aZ.v[ti][tj][r]);
           Y[row * FP + col] = zb;
           bstore(rzb, (unsigned)(4 * h * FH + col) * 4u, rowc * FH * 4, zb);
         },
         [&](int tj, int ti, int r, int col, int rowc, int row) {
-          const float zb = col < n_real ? fmaf(acc[ti][tj][r], aD[ti][tj][r], aZ[ti][tj][r]) : 0.f;
+          const float zb = col < n_real ? fmaf(acc[ti][tj][r], aD.v[ti][tj][r], aZ.v[ti][tj][r]) : 0.f;
           Y[row * FP + col] = zb;
           bstore(rzb, (unsigned)(4 * h * FH + col) * 4u, rowc * FH * 4, zb);
         });
     if (l == 0) break;
     lds_barrier();
-    { float* t = X; X = Y; Y = t; }
-    zero_acc2<BTI>(acc);
-    layer_mma_nt<BTI>(X, g.packed + g.wT_off[l], FH, n0, lane, acc,   // ab_{l-1} = zb_l W_l
-                      [&]() {
-                        prefetch_tile(g.D[l - 1], row0, n0, lane, aD);
-                        prefetch_tile(g.zR[l - 1], row0, n0, lane, aZ);
-                      }, g.hook_late);
+    if constexpr (NBUF == 2) { float* t = X; X = Y; Y = t; }
+    zero_acc2<TI>(acc);
+    layer_mma<TI>(X, g.packed + g.wT_off[l], FH, n0, lane, acc,   // ab_{l-1} = zb_l W_l
+                     [&]() {
+                       prefetch_tile<TI>(g.D[l - 1], row0, n0, lane, aD);
+                       if constexpr (TI == 1) prefetch_tile<TI>(g.zR[l - 1], row0, n0, lane, aZ);
+                     }, g.hook_late);
+    if constexpr (TI == 2) prefetch_tile<TI>(g.zR[l - 1], row0, n0, lane, aZ);
+    if constexpr (NBUF == 1) lds_barrier();   // every wave has finished reading the tile
   }
 }
 
@@ -357,6 +390,15 @@ static void fill_args(const Layout& L, const float* packed, PointBufs& pb, Fused
   g.stagger = sg ? atoi(sg) : 0;
 }
 
+// tile height of a sweep: measured defaults (R 651 -> 638 us and RA 717 -> 689 us with 64-point tiles; FB
+// 730 -> 801 us: its second operand tile only fits after the matrix loop and its latency is exposed);
+// RNB_BWD_TI = 1 | 2 overrides all three (A/B knob, also used by the parity tests)
+static int bwd_ti(int dflt) {
+  static const char* e = getenv("RNB_BWD_TI");
+  static const int v = e ? atoi(e) : 0;
+  return v == 1 || v == 2 ? v : dflt;
+}
+
 static double hidden_flops(const Layout& L, int64_t M, int first) {
   double fl = 0;
   for (int l = first; l < L.nh; ++l) fl += 2.0 * (double)M * L.hid[l].N * L.hid[l].K;
@@ -367,7 +409,8 @@ int fused_reverse(const Layout& L, const float* packed, PointBufs& pb, hipStream
   FusedBwdArgs g;
   fill_args(L, packed, pb, g);
   ProfScope prof(hidden_flops(L, pb.M, 0), s);
-  hipLaunchKernelGGL(fused_reverse_kernel, dim3((unsigned)(pb.Mp / BT)), dim3(256), 0, s, g);
+  if (bwd_ti(2) == 2) hipLaunchKernelGGL(fused_reverse_kernel<2>, dim3((unsigned)(pb.Mp / 64)), dim3(256), 0, s, g);
+  else hipLaunchKernelGGL(fused_reverse_kernel<1>, dim3((unsigned)(pb.Mp / 32)), dim3(256), 0, s, g);
   RNB_CHECK_LAUNCH();
   return RNB_OK;
 }
@@ -376,7 +419,8 @@ int fused_ra(const Layout& L, const float* packed, PointBufs& pb, hipStream_t s)
   FusedBwdArgs g;
   fill_args(L, packed, pb, g);
   ProfScope prof(hidden_flops(L, pb.M, 0), s);
-  hipLaunchKernelGGL(fused_ra_kernel, dim3((unsigned)(pb.Mp / BT)), dim3(256), 0, s, g);
+  if (bwd_ti(2) == 2) hipLaunchKernelGGL(fused_ra_kernel<2>, dim3((unsigned)(pb.Mp / 64)), dim3(256), 0, s, g);
+  else hipLaunchKernelGGL(fused_ra_kernel<1>, dim3((unsigned)(pb.Mp / 32)), dim3(256), 0, s, g);
   RNB_CHECK_LAUNCH();
   return RNB_OK;
 }
@@ -387,7 +431,8 @@ int fused_fb(const Layout& L, const float* packed, PointBufs& pb, bool with_colo
   g.fbar = with_color ? pb.cinb : nullptr;
   g.ld_fbar = L.Cinp;
   ProfScope prof(hidden_flops(L, pb.M, 1) + (with_color ? 2.0 * (double)pb.M * L.F * L.H : 0.0), s);
-  hipLaunchKernelGGL(fused_fb_kernel, dim3((unsigned)(pb.Mp / BT)), dim3(256), 0, s, g);
+  if (bwd_ti(1) == 2) hipLaunchKernelGGL(fused_fb_kernel<2>, dim3((unsigned)(pb.Mp / 64)), dim3(256), 0, s, g);
+  else hipLaunchKernelGGL(fused_fb_kernel<1>, dim3((unsigned)(pb.Mp / 32)), dim3(256), 0, s, g);
   RNB_CHECK_LAUNCH();
   return RNB_OK;
 }

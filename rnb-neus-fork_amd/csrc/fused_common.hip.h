@@ -77,6 +77,47 @@ __device__ inline void layer_mma_nt(const float* __restrict__ X, const float* __
   }
 }
 
+// Same product with ONE set of weight registers (32 instead of 64): a k-group's fragments are re-requested
+// for the next 32-k block as soon as the group's MFMAs have been issued, i.e. the prefetch runs exactly one
+// block (4 k-groups) ahead.  L2-resident weights need no more; the 64-point sweeps need the registers.
+template <int TI, class Hook = NoHook>
+__device__ inline void layer_mma_nt_ring(const float* __restrict__ X, const float* __restrict__ W, int K, int n0,
+                                         int lane, v16f (&acc)[TI][2], Hook hook = Hook(), int hookQ = 1) {
+  const int i = lane & 31, h = lane >> 5;
+  const int nQ = K / 32;
+  const float* p0 = W + (size_t)(n0 + i) * K + h * 16;
+  const float* p1 = p0 + (size_t)32 * K;
+  vf4 b[2][4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    b[0][q] = *reinterpret_cast<const vf4*>(p0 + q * 4);
+    b[1][q] = *reinterpret_cast<const vf4*>(p1 + q * 4);
+  }
+  for (int Q = 0; Q < nQ; ++Q) {
+    const int Qn = Q + 1 < nQ ? Q + 1 : Q;   // the last block re-requests itself (harmless, keeps the loop uniform)
+    if (Q == hookQ || (nQ <= hookQ && Q == 0)) hook();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      vf4 a[TI];
+#pragma unroll
+      for (int ti = 0; ti < TI; ++ti)
+        a[ti] = *reinterpret_cast<const vf4*>(X + (ti * 32 + i) * FP + Q * 32 + h * 16 + q * 4);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+          for (int ti = 0; ti < TI; ++ti)
+            acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ti][c], b[tj][q][c], acc[ti][tj], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      b[0][q] = *reinterpret_cast<const vf4*>(p0 + Qn * 32 + q * 4);
+      b[1][q] = *reinterpret_cast<const vf4*>(p1 + Qn * 32 + q * 4);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
 template <int TI>
 __device__ inline void zero_acc2(v16f (&acc)[TI][2]) {
 #pragma unroll

@@ -534,26 +534,48 @@ __device__ inline float softplus100(float z) {
   const float t = z * 100.f;
   return t > 20.f ? z : log1pf(expf(t)) * 0.01f;
 }
-// softplus and its derivative in one go: a = softplus(z), D = sigmoid(100 z) (= exactly 1 above the
-// threshold, like PyTorch's softplus backward).  e = exp(t) through the hardware exp2 with a two-term
-// Cody-Waite reduction (|rel err| ~ 1 ulp for t <= 20), log1p(e) = log(u) * e / (u - 1) with u = fl(1 + e)
-// (the classic rounding-compensated form; hardware log2).  ~20 VALU instructions per element.
+// softplus and its derivative in one go: a = softplus_100(z), D = sigmoid(100 z).
+// On gfx950 the fp32 MFMA and ordinary vector instructions exclude each other on a SIMD, so this function is
+// paid for in matrix time: it is written for instruction count (16 VALU + 3 transcendentals per element,
+// most of them packable two elements at a time — see the vf2 overload).
+//   w = exp(-|t|), t = 100 z        (never overflows; no range clamp needed)
+//   a = max(z, 0) + log1p(w) / 100  (for t > 20 the second term is below half an ulp of z: a == z exactly,
+//                                    PyTorch's threshold branch, models/fields.py:80)
+//   D = 1 / (1 + w)  (t >= 0)   |   w / (1 + w)  (t < 0)        (== 1 exactly for t > 20)
+// exp through the hardware exp2 with the rounding error of the product -|t| log2(e) fed back to first order;
+// log1p(w) = log(u) + (w - (u - 1)) / u with u = fl(1 + w) (rounding-compensated, hardware log2 and rcp).
 __device__ inline void softplus_aD(float z, float& a, float& D) {
-  // branch-free (selects only): the epilogues run this 64x per lane next to the matrix pipe
+  constexpr float L2E = 1.44269504088896341f, LN2 = 0.693147180559945309f;
   const float t = z * 100.f;
-  const float tc = fminf(fmaxf(t, -87.f), 20.f);
-  const float n = rintf(tc * 1.44269504088896341f);
-  // tc - n ln2 with ln2 = hi + lo, hi = fl(ln2) = 0.693147182464599609375, lo = -1.904654299957768e-9
-  const float r = fmaf(n, 1.90465429995776804e-09f, fmaf(n, -0.693147182464599609375f, tc));
-  const float e = ldexpf(__builtin_amdgcn_exp2f(r * 1.44269504088896341f), (int)n);
-  const float u = 1.f + e;
-  const float um1 = u - 1.f;
-  const float lg = __builtin_amdgcn_logf(u) * 0.693147180559945309f;
-  const float corr = e * __builtin_amdgcn_rcpf(um1 == 0.f ? 1.f : um1);   // e / (u - 1): rounding of 1 + e
-  const float l1p = um1 == 0.f ? e : lg * corr;
-  const bool lin = t > 20.f;
-  a = lin ? z : l1p * 0.01f;
-  D = lin ? 1.f : e * __builtin_amdgcn_rcpf(u);
+  const float nt = -fabsf(t);
+  const float p = nt * L2E;
+  const float q = __builtin_fmaf(nt, L2E, -p);
+  const float w0 = __builtin_amdgcn_exp2f(p);
+  const float w = __builtin_fmaf(w0, q * LN2, w0);
+  const float u = 1.f + w;
+  const float r = __builtin_amdgcn_rcpf(u);
+  const float lg = __builtin_amdgcn_logf(u);
+  const float l1p = __builtin_fmaf(lg, LN2, (w - (u - 1.f)) * r);
+  a = __builtin_fmaf(l1p, 0.01f, fmaxf(z, 0.f));
+  D = t >= 0.f ? r : w * r;
+}
+// two elements at a time: the multiplies / adds / fmas become v_pk_*_f32 (one issue slot for both)
+__device__ inline void softplus_aD(vf2 z, vf2& a, vf2& D) {
+  constexpr float L2E = 1.44269504088896341f, LN2 = 0.693147180559945309f;
+  const vf2 t = z * 100.f;
+  const vf2 nt = {-fabsf(t.x), -fabsf(t.y)};
+  const vf2 p = nt * L2E;
+  const vf2 q = __builtin_elementwise_fma(nt, vf2{L2E, L2E}, -p);
+  const vf2 w0 = {__builtin_amdgcn_exp2f(p.x), __builtin_amdgcn_exp2f(p.y)};
+  const vf2 w = __builtin_elementwise_fma(w0, q * LN2, w0);
+  const vf2 u = w + 1.f;
+  const vf2 r = {__builtin_amdgcn_rcpf(u.x), __builtin_amdgcn_rcpf(u.y)};
+  const vf2 lg = {__builtin_amdgcn_logf(u.x), __builtin_amdgcn_logf(u.y)};
+  const vf2 l1p = __builtin_elementwise_fma(lg, vf2{LN2, LN2}, (w - (u - 1.f)) * r);
+  const vf2 zp = {fmaxf(z.x, 0.f), fmaxf(z.y, 0.f)};
+  a = __builtin_elementwise_fma(l1p, vf2{0.01f, 0.01f}, zp);
+  const vf2 wr = w * r;
+  D = vf2{t.x >= 0.f ? r.x : wr.x, t.y >= 0.f ? r.y : wr.y};
 }
 // D = d softplus / dz = sigmoid(100 z) expressed through a = softplus(z):  D = 1 - exp(-100 a)
 // (exactly 1 above the threshold, where a == z); E = 1 - D, and softplus'' = 100 D E.
