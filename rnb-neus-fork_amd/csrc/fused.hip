@@ -97,7 +97,6 @@ __global__ __launch_bounds__(256, 2) void fused_forward_kernel(FusedFwdArgs g) {
   const int h = lane >> 5, cl = lane & 31;
   v16f acc[TI][2];
   for (int l = 0; l < g.nh; ++l) {
-    zero_acc2<TI>(acc);
     layer_mma_nt<TI>(X, g.packed + g.w_off[l], g.Kp[l], n0, lane, acc);
     if constexpr (NBUF == 1) lds_barrier();   // every wave has finished reading the input activations
     const float* bias = g.packed + g.b_off[l];
@@ -125,7 +124,8 @@ __global__ __launch_bounds__(256, 2) void fused_forward_kernel(FusedFwdArgs g) {
           const int rowc = ti * 32 + (r & 3) + 8 * (r >> 2);   // compile-time part of the row
           const int row = rowc + 4 * h;
           vf2 a, D;
-          softplus_aD(vf2{acc[ti][tj][r] + bc, acc[ti][tj][r + 1] + bc}, a, D);
+          if constexpr (SAVE) softplus_aD(vf2{acc[ti][tj][r] + bc, acc[ti][tj][r + 1] + bc}, a, D);
+          else a = softplus_a(vf2{acc[ti][tj][r] + bc, acc[ti][tj][r + 1] + bc});
           if (!tile_full && col >= n_real) {   // only the tile straddling the skip connection's PE columns
             const bool pe_col = pe_tail && col < n_real + g.pe;
             a = vf2{pe_col ? E[row * FEP + (col - n_real)] : 0.f, pe_col ? E[(row + 1) * FEP + (col - n_real)] : 0.f};
@@ -169,7 +169,6 @@ __global__ __launch_bounds__(256, 2) void fused_forward_kernel(FusedFwdArgs g) {
   }
   // ---- feature head: rows 1.. of the output layer, written into the albedo network's input ------------
   if (g.with_feat) {
-    zero_acc2<TI>(acc);
     layer_mma_nt<TI>(X, g.packed + g.wf_off, FH, n0, lane, acc);
     const float* bias = g.packed + g.bf_off;
     const BufRsrc rc = tile_rsrc(g.cin + (size_t)row0 * g.Cinp, FT * g.Cinp * 4);

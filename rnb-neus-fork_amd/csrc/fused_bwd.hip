@@ -113,7 +113,7 @@ template <int TI, class Hook = NoHook>
 __device__ inline void layer_mma(const float* __restrict__ X, const float* __restrict__ W, int K, int n0, int lane,
                                  v16f (&acc)[TI][2], Hook hook = Hook(), int hook_late = 0) {
   if constexpr (TI == 1) layer_mma_nt<TI>(X, W, K, n0, lane, acc, hook, hook_late);
-  else layer_mma_nt_ring<TI>(X, W, K, n0, lane, acc, hook, 1);
+  else layer_mma_nt_ring<TI>(X, W, K, n0, lane, acc, hook);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -154,7 +154,6 @@ __global__ __launch_bounds__(256, 2) void fused_reverse_kernel(FusedBwdArgs g) {
   v16f acc[TI][2];
   AuxTile<TI> aD;
   for (int l = g.nh - 1; l >= 1; --l) {
-    zero_acc2<TI>(acc);
     layer_mma<TI>(X, g.packed + g.wT_off[l], FH, n0, lane, acc,   // g = gz_l W_l  (columns = inputs of layer l)
                      [&]() { prefetch_tile<TI>(g.D[l - 1], row0, n0, lane, aD); }, g.hook_late);
     if constexpr (NBUF == 1) lds_barrier();   // every wave has finished reading the tile
@@ -185,7 +184,6 @@ __global__ __launch_bounds__(256, 2) void fused_reverse_kernel(FusedBwdArgs g) {
   }
   // layer 0: g_e += gz_0 W_0 (Ep = 64 columns: wave 0 only)
   if (wave == 0) {
-    zero_acc2<TI>(acc);
     layer_mma<TI>(X, g.packed + g.wT_off[0], FH, 0, lane, acc);
     for_each_acc<TI>(0, lane, [&](int tj, int ti, int r, int col, int rowc, int row) {
       if (col < g.pe) GE[row * FEP + col] += acc[ti][tj][r];
@@ -242,7 +240,6 @@ __global__ __launch_bounds__(256, 2) void fused_ra_kernel(FusedBwdArgs g) {
   v16f acc[TI][2];
   AuxTile<TI> aD, aG;
   for (int l = 0; l < g.nh; ++l) {
-    zero_acc2<TI>(acc);
     // TI == 2: only one operand tile fits next to the weight fragments during the matrix loop; the second
     // one is requested right after it, into the registers the weight fragments leave behind
     layer_mma<TI>(X, g.packed + g.w_off[l], g.Kp[l], n0, lane, acc,   // gzb = u_l W_l^T
@@ -346,7 +343,6 @@ __global__ __launch_bounds__(256, 2) void fused_fb_kernel(FusedBwdArgs g) {
     if (l == 0) break;
     lds_barrier();
     if constexpr (NBUF == 2) { float* t = X; X = Y; Y = t; }
-    zero_acc2<TI>(acc);
     layer_mma<TI>(X, g.packed + g.wT_off[l], FH, n0, lane, acc,   // ab_{l-1} = zb_l W_l
                      [&]() {
                        prefetch_tile<TI>(g.D[l - 1], row0, n0, lane, aD);

@@ -28,8 +28,11 @@ struct NoHook {
   __device__ void operator()() const {}
 };
 
-// the 4 k-groups (x 4 MFMA k-steps) of one 32-k block with the block's weight fragments in `b`
-template <int TI>
+// the 4 k-groups (x 4 MFMA k-steps) of one 32-k block with the block's weight fragments in `b`.
+// FIRST: the very first MFMA of every accumulator takes the constant 0 as its C operand (an inline
+// constant of the instruction) instead of a zeroed register tile: saves the 16 v_mov per accumulator that
+// would otherwise be paid in matrix time at the top of every layer.
+template <int TI, bool FIRST = false>
 __device__ inline void mma_block(const float* __restrict__ X, int Q, int i, int h, const vf4 (&b)[2][4],
                                  v16f (&acc)[TI][2]) {
 #pragma unroll
@@ -43,8 +46,14 @@ __device__ inline void mma_block(const float* __restrict__ X, int Q, int i, int 
 #pragma unroll
       for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
-        for (int ti = 0; ti < TI; ++ti)
-          acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ti][c], b[tj][q][c], acc[ti][tj], 0, 0, 0);
+        for (int ti = 0; ti < TI; ++ti) {
+          if (FIRST && q == 0 && c == 0) {
+            const v16f zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ti][c], b[tj][q][c], zero, 0, 0, 0);
+          } else {
+            acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ti][c], b[tj][q][c], acc[ti][tj], 0, 0, 0);
+          }
+        }
     }
     // keep each k-group's fragment reads behind the previous group's MFMAs (hoisting them all costs
     // registers and, measured, 15 % of the matrix-pipe utilisation)
@@ -62,12 +71,19 @@ __device__ inline void mma_block(const float* __restrict__ X, int Q, int i, int 
 template <int TI, class Hook = NoHook>
 __device__ inline void layer_mma_nt(const float* __restrict__ X, const float* __restrict__ W, int K, int n0, int lane,
                                     v16f (&acc)[TI][2], Hook hook = Hook(), int hook_late = 0) {
+  // acc = X W^T (overwritten, not accumulated: the first MFMA of every accumulator starts from the constant 0)
   const int i = lane & 31, h = lane >> 5;
   const int nQ = K / 32;   // even
   const int hookQ = hook_late ? (nQ >= 2 ? nQ - 2 : 0) : (nQ > 2 ? 1 : 0);
   vf4 b0[2][4], b1[2][4];
   load_b_block(W, K, n0, 0, lane, b0);
-  for (int Q = 0; Q < nQ; Q += 2) {
+  load_b_block(W, K, n0, 1, lane, b1);
+  if (hookQ == 0) hook();
+  mma_block<TI, true>(X, 0, i, h, b0, acc);
+  if (2 < nQ) load_b_block(W, K, n0, 2, lane, b0);
+  if (hookQ == 1) hook();
+  mma_block<TI>(X, 1, i, h, b1, acc);
+  for (int Q = 2; Q < nQ; Q += 2) {
     load_b_block(W, K, n0, Q + 1, lane, b1);
     if (Q == hookQ) hook();
     mma_block<TI>(X, Q, i, h, b0, acc);
@@ -80,9 +96,40 @@ __device__ inline void layer_mma_nt(const float* __restrict__ X, const float* __
 // Same product with ONE set of weight registers (32 instead of 64): a k-group's fragments are re-requested
 // for the next 32-k block as soon as the group's MFMAs have been issued, i.e. the prefetch runs exactly one
 // block (4 k-groups) ahead.  L2-resident weights need no more; the 64-point sweeps need the registers.
+template <int TI, bool FIRST>
+__device__ inline void ring_block(const float* __restrict__ X, const float* __restrict__ p0,
+                                  const float* __restrict__ p1, int Q, int Qn, int i, int h, vf4 (&b)[2][4],
+                                  v16f (&acc)[TI][2]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    vf4 a[TI];
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti)
+      a[ti] = *reinterpret_cast<const vf4*>(X + (ti * 32 + i) * FP + Q * 32 + h * 16 + q * 4);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti) {
+          if (FIRST && q == 0 && c == 0) {
+            const v16f zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ti][c], b[tj][q][c], zero, 0, 0, 0);
+          } else {
+            acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ti][c], b[tj][q][c], acc[ti][tj], 0, 0, 0);
+          }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    b[0][q] = *reinterpret_cast<const vf4*>(p0 + Qn * 32 + q * 4);
+    b[1][q] = *reinterpret_cast<const vf4*>(p1 + Qn * 32 + q * 4);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
 template <int TI, class Hook = NoHook>
 __device__ inline void layer_mma_nt_ring(const float* __restrict__ X, const float* __restrict__ W, int K, int n0,
-                                         int lane, v16f (&acc)[TI][2], Hook hook = Hook(), int hookQ = 1) {
+                                         int lane, v16f (&acc)[TI][2], Hook hook = Hook()) {
+  // acc = X W^T (overwritten, like layer_mma_nt)
   const int i = lane & 31, h = lane >> 5;
   const int nQ = K / 32;
   const float* p0 = W + (size_t)(n0 + i) * K + h * 16;
@@ -93,28 +140,12 @@ __device__ inline void layer_mma_nt_ring(const float* __restrict__ X, const floa
     b[0][q] = *reinterpret_cast<const vf4*>(p0 + q * 4);
     b[1][q] = *reinterpret_cast<const vf4*>(p1 + q * 4);
   }
-  for (int Q = 0; Q < nQ; ++Q) {
+  if (nQ == 1) hook();
+  ring_block<TI, true>(X, p0, p1, 0, nQ > 1 ? 1 : 0, i, h, b, acc);
+  for (int Q = 1; Q < nQ; ++Q) {
     const int Qn = Q + 1 < nQ ? Q + 1 : Q;   // the last block re-requests itself (harmless, keeps the loop uniform)
-    if (Q == hookQ || (nQ <= hookQ && Q == 0)) hook();
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      vf4 a[TI];
-#pragma unroll
-      for (int ti = 0; ti < TI; ++ti)
-        a[ti] = *reinterpret_cast<const vf4*>(X + (ti * 32 + i) * FP + Q * 32 + h * 16 + q * 4);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-#pragma unroll
-        for (int tj = 0; tj < 2; ++tj)
-#pragma unroll
-          for (int ti = 0; ti < TI; ++ti)
-            acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ti][c], b[tj][q][c], acc[ti][tj], 0, 0, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      b[0][q] = *reinterpret_cast<const vf4*>(p0 + Qn * 32 + q * 4);
-      b[1][q] = *reinterpret_cast<const vf4*>(p1 + Qn * 32 + q * 4);
-      __builtin_amdgcn_sched_barrier(0);
-    }
+    if (Q == 1) hook();
+    ring_block<TI, false>(X, p0, p1, Q, Qn, i, h, b, acc);
   }
 }
 

@@ -577,6 +577,23 @@ __device__ inline void softplus_aD(vf2 z, vf2& a, vf2& D) {
   const vf2 wr = w * r;
   D = vf2{t.x >= 0.f ? r.x : wr.x, t.y >= 0.f ? r.y : wr.y};
 }
+// a alone (forward-only evaluations, e.g. the sampling passes): no reciprocal — the compensation term
+// (w - (u - 1)) / u is at most half an ulp of u, so 1 / u ~ 1 - w inside it changes a by < eps w / 2.
+__device__ inline vf2 softplus_a(vf2 z) {
+  constexpr float L2E = 1.44269504088896341f, LN2 = 0.693147180559945309f;
+  const vf2 t = z * 100.f;
+  const vf2 nt = {-fabsf(t.x), -fabsf(t.y)};
+  const vf2 p = nt * L2E;
+  const vf2 q = __builtin_elementwise_fma(nt, vf2{L2E, L2E}, -p);
+  const vf2 w0 = {__builtin_amdgcn_exp2f(p.x), __builtin_amdgcn_exp2f(p.y)};
+  const vf2 w = __builtin_elementwise_fma(w0, q * LN2, w0);
+  const vf2 u = w + 1.f;
+  const vf2 lg = {__builtin_amdgcn_logf(u.x), __builtin_amdgcn_logf(u.y)};
+  const vf2 d = w - (u - 1.f);
+  const vf2 l1p = __builtin_elementwise_fma(lg, vf2{LN2, LN2}, __builtin_elementwise_fma(-d, w, d));
+  const vf2 zp = {fmaxf(z.x, 0.f), fmaxf(z.y, 0.f)};
+  return __builtin_elementwise_fma(l1p, vf2{0.01f, 0.01f}, zp);
+}
 // D = d softplus / dz = sigmoid(100 z) expressed through a = softplus(z):  D = 1 - exp(-100 a)
 // (exactly 1 above the threshold, where a == z); E = 1 - D, and softplus'' = 100 D E.
 __device__ inline void softplus_DE(float a, float& D, float& E) {
