@@ -239,7 +239,8 @@ def main():
             roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch",
                     "traffic_detail": traffic_detail,
-                    "kernel": "fp32-MFMA family: fused_forward/reverse/ra/fb_kernel, gemm_dw_kernel, gemm_rows_kernel<*>",
+                    "kernel": "fp32-MFMA family: fused_forward/reverse/ra/fb_kernel, gemm_dw_direct_kernel, "
+                              "gemm_rows_kernel<*>",
                     "launches_per_step": gemm_n.value / args.steps,
                     "avg_launch_us": round(1e3 * gemm_ms.value / gemm_n.value, 2),
                     "flop_per_launch": round(gemm_fl.value / gemm_n.value, 1),

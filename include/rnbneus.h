@@ -232,7 +232,7 @@ int rnb_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
                   double beta1, double beta2, double eps, double weight_decay, int64_t step, rnb_stream_t stream);
 
 /* Measurement aid for bench.py (not part of the reference's interface): while enabled, every launch of
- * the fp32-MFMA layer-GEMM kernels (gemm_rows_kernel<...>, gemm_dw_kernel) is bracketed by HIP events on
+ * the fp32-MFMA kernels (fused_*_kernel, gemm_dw_*_kernel, gemm_rows_kernel<...>) is bracketed by HIP events on
  * its launch stream.  After the caller has synchronised, rnb_profile_collect returns the summed device
  * time (ms), the number of launches and their summed algorithmic FLOPs (real layer shapes) since the
  * last enable/collect.  This is the only mutable global state of the library; it is off by default. */
