@@ -8,9 +8,11 @@
 #include <stdio.h>
 #include <stdlib.h>
 typedef float v16f __attribute__((ext_vector_type(16)));
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
-template <int VMODE>   // 0: exp/log/rcp chain (softplus-like), 1: plain fma chain, 2: global dword stores
+template <int VMODE, int MTYPE = 0>   // VMODE 0: exp/log/rcp chain (softplus-like), 1: plain fma chain, 2: global dword
+                                      // stores; MTYPE 0: v_mfma_f32_32x32x2_f32, 1: v_mfma_f32_32x32x16_bf16
 __global__ __launch_bounds__(512) void k(float* out, int m_iters, int v_iters, int run_m, int run_v) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -19,11 +21,16 @@ __global__ __launch_bounds__(512) void k(float* out, int m_iters, int v_iters, i
     v16f acc[4];
     for (int a = 0; a < 4; ++a) for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
     float x = 0.01f * lane, y = 0.5f;
+    v8bf xb, yb;
+    for (int j = 0; j < 8; ++j) { xb[j] = (__bf16)(0.01f * lane + j); yb[j] = (__bf16)0.5f; }
     for (int it = 0; it < m_iters; ++it) {
 #pragma unroll
       for (int u = 0; u < 8; ++u)
 #pragma unroll
-        for (int a = 0; a < 4; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, acc[a], 0, 0, 0);
+        for (int a = 0; a < 4; ++a) {
+          if (MTYPE == 0) acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, acc[a], 0, 0, 0);
+          else acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xb, yb, acc[a], 0, 0, 0);
+        }
     }
     float s = 0.f;
     for (int a = 0; a < 4; ++a) for (int r = 0; r < 16; ++r) s += acc[a][r];
@@ -70,11 +77,11 @@ static float time_it(F f, int iters) {
   return ms * 1e3f / iters;
 }
 
-template <int VMODE>
+template <int VMODE, int MTYPE = 0>
 static void run(const char* name, float* out, int m_iters, int v_iters) {
   const int wgs = 256;
   auto t = [&](int rm, int rv) {
-    return time_it([&] { hipLaunchKernelGGL(k<VMODE>, dim3(wgs), dim3(512), 0, 0, out, m_iters, v_iters, rm, rv); }, 10);
+    return time_it([&] { hipLaunchKernelGGL((k<VMODE, MTYPE>), dim3(wgs), dim3(512), 0, 0, out, m_iters, v_iters, rm, rv); }, 10);
   };
   const float tm = t(1, 0), tv = t(0, 1), tb = t(1, 1);
   printf("%-28s MFMA alone %8.1f us | other alone %8.1f us | both %8.1f us  (max %.1f, sum %.1f)\n", name, tm, tv, tb,
@@ -88,5 +95,9 @@ int main() {
   run<0>("softplus-like VALU (half)", out, 2000, 1300);
   run<1>("fma chain VALU", out, 2000, 3400);
   run<2>("global dword stores", out, 2000, 6000);
+  printf("-- v_mfma_f32_32x32x16_bf16 as the matrix stream --\n");
+  run<0, 1>("softplus-like VALU", out, 4000, 2600);
+  run<1, 1>("fma chain VALU", out, 4000, 3400);
+  run<2, 1>("global dword stores", out, 4000, 6000);
   return 0;
 }
