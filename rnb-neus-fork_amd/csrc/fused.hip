@@ -35,10 +35,14 @@ struct FusedFwdArgs {
 };
 
 // TI = row tiles per workgroup (64 points for TI = 2; 32 points for TI = 1, used for small batches so that
-// every CU still gets a workgroup).
-template <int TI, bool SAVE>
-__global__ __launch_bounds__(256, 2) void fused_forward_kernel(FusedFwdArgs g) {
+// every CU still gets a workgroup).  NW = waves per workgroup: 4 (each wave 64 output columns) or 8 (32 columns
+// each) — the latter for batches so small that a CU holds a single workgroup: two waves per SIMD instead of one
+// hide each other's LDS / L2 waits.
+template <int TI, bool SAVE, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_forward_kernel(FusedFwdArgs g) {
   constexpr int FT = 32 * TI;
+  constexpr int NT = 64 * NW;     // threads
+  constexpr int TJ = 8 / NW;      // 32-column tiles per wave
   // TI == 1: two activation tiles (a layer reads one, writes the other: one barrier per layer);
   // TI == 2: one tile updated in place behind a second barrier (two tiles would not leave room for two
   // workgroups per CU)
@@ -50,12 +54,12 @@ __global__ __launch_bounds__(256, 2) void fused_forward_kernel(FusedFwdArgs g) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = wave_id();
   const int64_t row0 = (int64_t)blockIdx.x * FT;
-  const int n0 = wave * 64;
+  const int n0 = wave * 32 * TJ;
   stagger_start(g.stagger);
 
   // ---- positional encoding of the tile: X[:, 0:Ep] = [x, sin(2^k x), cos(2^k x)], zero padded -------
   {
-    constexpr int PARTS = 256 / FT;
+    constexpr int PARTS = NT / FT;
     const int p = tid % FT, part = tid / FT;
     const int64_t row = row0 + p;
     float x[3] = {0.f, 0.f, 0.f};
@@ -88,16 +92,16 @@ __global__ __launch_bounds__(256, 2) void fused_forward_kernel(FusedFwdArgs g) {
   }
   __syncthreads();
   if (SAVE) {   // e is an operand of the backward (dW of layer 0) and of the R sweep: FT x Ep floats
-    for (int idx = tid; idx < FT * g.Ep; idx += 256) {
+    for (int idx = tid; idx < FT * g.Ep; idx += NT) {
       const int r = idx / g.Ep, c = idx - r * g.Ep;
       g.e[(row0 + r) * g.Ep + c] = X[r * FP + c];
     }
   }
 
   const int h = lane >> 5, cl = lane & 31;
-  v16f acc[TI][2];
+  v16f acc[TI][TJ];
   for (int l = 0; l < g.nh; ++l) {
-    layer_mma_nt<TI>(X, g.packed + g.w_off[l], g.Kp[l], n0, lane, acc);
+    layer_mma_nt<TI, NoHook, TJ>(X, g.packed + g.w_off[l], g.Kp[l], n0, lane, acc);
     if constexpr (NBUF == 1) lds_barrier();   // every wave has finished reading the input activations
     const float* bias = g.packed + g.b_off[l];
     // saved state goes out through buffer stores: one 32-bit lane offset per column tile plus a
@@ -110,7 +114,7 @@ __global__ __launch_bounds__(256, 2) void fused_forward_kernel(FusedFwdArgs g) {
     const bool pe_tail = (l + 1 == g.skip);
     const bool last = (l + 1 == g.nh);
 #pragma unroll
-    for (int tj = 0; tj < 2; ++tj) {
+    for (int tj = 0; tj < TJ; ++tj) {
       const int col = n0 + tj * 32 + cl;
       const float bc = bias[col];
       const float ws = (SAVE && last && g.gz_last) ? g.packed[g.wsdf_off + col] : 0.f;
@@ -157,8 +161,8 @@ __global__ __launch_bounds__(256, 2) void fused_forward_kernel(FusedFwdArgs g) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) w[u] = ws[lane + 64 * u];
     const float bs = g.packed[g.bsdf_off];
-    for (int rr = 0; rr < FT / 4; ++rr) {
-      const int row = wave * (FT / 4) + rr;
+    for (int rr = 0; rr < FT / NW; ++rr) {
+      const int row = wave * (FT / NW) + rr;
       float s = 0.f;
 #pragma unroll
       for (int u = 0; u < 4; ++u) s = fmaf(X[row * FP + lane + 64 * u], w[u], s);
@@ -169,12 +173,12 @@ __global__ __launch_bounds__(256, 2) void fused_forward_kernel(FusedFwdArgs g) {
   }
   // ---- feature head: rows 1.. of the output layer, written into the albedo network's input ------------
   if (g.with_feat) {
-    layer_mma_nt<TI>(X, g.packed + g.wf_off, FH, n0, lane, acc);
+    layer_mma_nt<TI, NoHook, TJ>(X, g.packed + g.wf_off, FH, n0, lane, acc);
     const float* bias = g.packed + g.bf_off;
     const BufRsrc rc = tile_rsrc(g.cin + (size_t)row0 * g.Cinp, FT * g.Cinp * 4);
     const unsigned rowb = (unsigned)g.Cinp * 4u;   // bytes per row of the albedo-net input
 #pragma unroll
-    for (int tj = 0; tj < 2; ++tj) {
+    for (int tj = 0; tj < TJ; ++tj) {
       const int col = n0 + tj * 32 + cl;
       if (col < g.F) {
         const float bc = bias[col];
@@ -247,9 +251,12 @@ int fused_forward(const Layout& L, const float* packed, const float* pts, int64_
   // 64-point tiles when that still gives every CU >= 2 workgroups, 32-point tiles for small batches
   static const char* force_ti = getenv("RNB_FWD_TI");   // tuning knob: "1" or "2" forces the tile height
   const bool small = force_ti ? (force_ti[0] == '1') : (pb.Mp / 64 < 512);
+  static const char* force_nw = getenv("RNB_FWD_NW");   // tuning knob: "4" or "8" waves for small forward-only batches
   if (small) {
     const unsigned blocks = (unsigned)(pb.Mp / 32);
+    const bool wide = force_nw ? (force_nw[0] == '8') : (blocks <= 256);   // at most one workgroup per CU
     if (save) hipLaunchKernelGGL((fused_forward_kernel<1, true>), dim3(blocks), dim3(256), 0, s, g);
+    else if (wide) hipLaunchKernelGGL((fused_forward_kernel<1, false, 8>), dim3(blocks), dim3(512), 0, s, g);
     else hipLaunchKernelGGL((fused_forward_kernel<1, false>), dim3(blocks), dim3(256), 0, s, g);
   } else {
     const unsigned blocks = (unsigned)(pb.Mp / 64);

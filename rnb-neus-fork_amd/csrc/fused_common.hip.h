@@ -11,13 +11,15 @@ constexpr int FH = 256;       // hidden width of the fused path
 constexpr int FP = FH + 4;    // LDS pitch of the activation tile
 constexpr int FEP = 40;       // LDS pitch of the positional-encoding copy kept for the skip connection
 
-// One (32*TI) x 64 output block per wave: C[rows][n0..n0+63] = X[rows][K] * W[n][K]^T, K a multiple of 32.
+// One (32*TI) x (32*TJ) output block per wave (TJ = 2 unless stated): C[rows][n0..] = X[rows][K] * W[n][K]^T, K a
+// multiple of 32.
 // k-permutation inside each 32-k block: lane half h takes k = 32Q + 16h + 4q + c, so every lane streams 64
 // contiguous bytes of its weight row per block.
-__device__ inline void load_b_block(const float* __restrict__ W, int K, int n0, int Q, int lane, vf4 (&b)[2][4]) {
+template <int TJ>
+__device__ inline void load_b_block(const float* __restrict__ W, int K, int n0, int Q, int lane, vf4 (&b)[TJ][4]) {
   const int j = lane & 31, h = lane >> 5;
 #pragma unroll
-  for (int tj = 0; tj < 2; ++tj) {
+  for (int tj = 0; tj < TJ; ++tj) {
     const float* p = W + (size_t)(n0 + tj * 32 + j) * K + Q * 32 + h * 16;
 #pragma unroll
     for (int q = 0; q < 4; ++q) b[tj][q] = *reinterpret_cast<const vf4*>(p + q * 4);
@@ -32,9 +34,9 @@ struct NoHook {
 // FIRST: the very first MFMA of every accumulator takes the constant 0 as its C operand (an inline
 // constant of the instruction) instead of a zeroed register tile: saves the 16 v_mov per accumulator that
 // would otherwise be paid in matrix time at the top of every layer.
-template <int TI, bool FIRST = false>
-__device__ inline void mma_block(const float* __restrict__ X, int Q, int i, int h, const vf4 (&b)[2][4],
-                                 v16f (&acc)[TI][2]) {
+template <int TI, bool FIRST = false, int TJ = 2>
+__device__ inline void mma_block(const float* __restrict__ X, int Q, int i, int h, const vf4 (&b)[TJ][4],
+                                 v16f (&acc)[TI][TJ]) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     vf4 a[TI];
@@ -44,7 +46,7 @@ __device__ inline void mma_block(const float* __restrict__ X, int Q, int i, int 
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
 #pragma unroll
-      for (int tj = 0; tj < 2; ++tj)
+      for (int tj = 0; tj < TJ; ++tj)
 #pragma unroll
         for (int ti = 0; ti < TI; ++ti) {
           if (FIRST && q == 0 && c == 0) {
@@ -68,28 +70,28 @@ __device__ inline void mma_block(const float* __restrict__ X, int Q, int i, int 
 // the place to issue the epilogue's operand loads (the vector-memory counter retires in order, so loads
 // issued before the first weight block would have to land before the first MFMA).  hook_late: run it in
 // the second-to-last block instead of the second.
-template <int TI, class Hook = NoHook>
+template <int TI, class Hook = NoHook, int TJ = 2>
 __device__ inline void layer_mma_nt(const float* __restrict__ X, const float* __restrict__ W, int K, int n0, int lane,
-                                    v16f (&acc)[TI][2], Hook hook = Hook(), int hook_late = 0) {
+                                    v16f (&acc)[TI][TJ], Hook hook = Hook(), int hook_late = 0) {
   // acc = X W^T (overwritten, not accumulated: the first MFMA of every accumulator starts from the constant 0)
   const int i = lane & 31, h = lane >> 5;
   const int nQ = K / 32;   // even
   const int hookQ = hook_late ? (nQ >= 2 ? nQ - 2 : 0) : (nQ > 2 ? 1 : 0);
-  vf4 b0[2][4], b1[2][4];
-  load_b_block(W, K, n0, 0, lane, b0);
-  load_b_block(W, K, n0, 1, lane, b1);
+  vf4 b0[TJ][4], b1[TJ][4];
+  load_b_block<TJ>(W, K, n0, 0, lane, b0);
+  load_b_block<TJ>(W, K, n0, 1, lane, b1);
   if (hookQ == 0) hook();
-  mma_block<TI, true>(X, 0, i, h, b0, acc);
-  if (2 < nQ) load_b_block(W, K, n0, 2, lane, b0);
+  mma_block<TI, true, TJ>(X, 0, i, h, b0, acc);
+  if (2 < nQ) load_b_block<TJ>(W, K, n0, 2, lane, b0);
   if (hookQ == 1) hook();
-  mma_block<TI>(X, 1, i, h, b1, acc);
+  mma_block<TI, false, TJ>(X, 1, i, h, b1, acc);
   for (int Q = 2; Q < nQ; Q += 2) {
-    load_b_block(W, K, n0, Q + 1, lane, b1);
+    load_b_block<TJ>(W, K, n0, Q + 1, lane, b1);
     if (Q == hookQ) hook();
-    mma_block<TI>(X, Q, i, h, b0, acc);
-    if (Q + 2 < nQ) load_b_block(W, K, n0, Q + 2, lane, b0);
+    mma_block<TI, false, TJ>(X, Q, i, h, b0, acc);
+    if (Q + 2 < nQ) load_b_block<TJ>(W, K, n0, Q + 2, lane, b0);
     if (Q + 1 == hookQ) hook();
-    mma_block<TI>(X, Q + 1, i, h, b1, acc);
+    mma_block<TI, false, TJ>(X, Q + 1, i, h, b1, acc);
   }
 }
 
