@@ -1,0 +1,106 @@
+"""GPU edge cases of the renderer interface: ragged and tiny ray counts, a large batch (max size the bench
+shape is sharded from), shard consistency (the property the data-parallel split relies on), the SDF grid query
+of extract_fields and an empty batch.  Tolerances as in test_gpu_parity.py."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import rnb_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def R():
+    assert torch.cuda.is_available(), "GPU tests need a device"
+    import rnb_neus_fork_amd as pkg
+    pkg.native.load()
+    return pkg
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def _tiny(R, seed=0):
+    mc = O.ModelConf(sdf=O.SDFConf(d_out=65, d_hidden=64), color=O.ColorConf(d_feature=64, d_hidden=64),
+                     render=O.RenderConf(n_samples=16, n_importance=16))
+    torch.manual_seed(seed)
+    p = O.init_params(mc)
+    with torch.no_grad():
+        p["dev.variance"].fill_(0.4)
+    return mc, p, R.build_from_named_params(mc, p, _dev())
+
+
+@pytest.mark.parametrize("B", [1, 3, 37, 129])
+def test_ragged_ray_counts_match_oracle(R, B):
+    """Ray counts that are not a multiple of any tile size (points are padded to 128 internally)."""
+    mc, p, (sdf, dev, col, ren) = _tiny(R)
+    batch = O.synthetic_batch(B, seed=11, step=B)
+    b = {k: v.to(_dev()) for k, v in batch.items()}
+    out = ren.render_rnb(b["rays_o"], b["rays_d"], b["near"], b["far"], b["lights_dir"], cos_anneal_ratio=0.7,
+                         t_rand=b["t_rand"])
+    assert out["color_fine"].shape == (3, B, 3) and out["weights"].shape == (B, 32)
+    loss = O.rnb_loss(out, b["true_rgb"], b["mask"])[0]
+    loss.backward()
+    z = ren.last_z_vals.cpu()
+    pr = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    ref = O.render_rnb(pr, mc, batch["rays_o"], batch["rays_d"], batch["near"], batch["far"], batch["lights_dir"],
+                       cos_anneal_ratio=0.7, z_vals=z)
+    O.rnb_loss(ref, batch["true_rgb"], batch["mask"])[0].backward()
+    for k in ("color_fine", "weights", "weight_sum", "gradients", "cdf_fine", "gradient_error"):
+        torch.testing.assert_close(out[k].detach().cpu(), ref[k].detach(), rtol=1e-4, atol=2e-5,
+                                   msg=lambda m: f"{k}: {m}")
+    for name, leaf in (("sdf.lin1.weight_v", sdf.lin1.weight_v), ("sdf.lin8.bias", sdf.lin8.bias),
+                       ("color.lin0.weight_v", col.lin0.weight_v), ("dev.variance", dev.variance)):
+        g, gr = leaf.grad.cpu().double(), pr[name].grad.double()
+        assert float((g - gr).norm()) <= 2e-3 * float(gr.norm()) + 1e-7, name
+
+
+def test_shards_of_a_batch_render_like_the_whole_batch(R):
+    """Rays are independent: rendering two halves of a batch on given depths reproduces the whole batch
+    (what parallel.shard_batch relies on); 4096 rays = the largest per-GPU batch of BASELINE's configs."""
+    mc, p, (sdf, dev, col, ren) = _tiny(R, seed=2)
+    batch = O.synthetic_batch(4096, seed=13, step=1)
+    b = {k: v.to(_dev()) for k, v in batch.items()}
+    with torch.no_grad():
+        whole = ren.render_rnb(b["rays_o"], b["rays_d"], b["near"], b["far"], b["lights_dir"], cos_anneal_ratio=1.0,
+                               t_rand=b["t_rand"])
+        z = ren.last_z_vals
+        parts = []
+        for lo, hi in ((0, 1000), (1000, 4096)):        # deliberately ragged split
+            parts.append(ren.render_rnb(b["rays_o"][lo:hi], b["rays_d"][lo:hi], b["near"][lo:hi], b["far"][lo:hi],
+                                        b["lights_dir"][:, lo:hi], cos_anneal_ratio=1.0, t_rand=b["t_rand"][lo:hi]))
+            assert torch.equal(ren.last_z_vals, z[lo:hi])   # sampling is per ray: bit-identical depths
+    assert whole["weights"].shape == (4096, 32)
+    torch.testing.assert_close(torch.cat([q["weights"] for q in parts]), whole["weights"], rtol=0, atol=0)
+    torch.testing.assert_close(torch.cat([q["color_fine"] for q in parts], dim=1), whole["color_fine"], rtol=0, atol=0)
+    assert bool(torch.isfinite(whole["color_fine"]).all())
+
+
+def test_extract_fields_matches_oracle_grid(R):
+    """models/renderer.py:10-25 / :1219-1224: -sdf on a regular grid, in chunks."""
+    mc, p, (sdf, dev, col, ren) = _tiny(R, seed=3)
+    res = 20
+    lo = torch.tensor([-1.0, -0.9, -0.8])
+    hi = torch.tensor([1.0, 0.9, 1.1])
+    u = ren.extract_fields(lo, hi, res, chunk=8)       # chunk does not divide the resolution
+    assert u.shape == (res, res, res) and u.dtype == np.float32
+    xs = [torch.linspace(float(lo[i]), float(hi[i]), res) for i in range(3)]
+    xx, yy, zz = torch.meshgrid(*xs, indexing="ij")
+    pts = torch.stack([xx.reshape(-1), yy.reshape(-1), zz.reshape(-1)], dim=-1)
+    ref = -O.sdf_forward(p, mc.sdf, pts)[:, 0].reshape(res, res, res)
+    torch.testing.assert_close(torch.from_numpy(u), ref, rtol=1e-4, atol=2e-5)
+
+
+def test_empty_batch_is_rejected_cleanly(R):
+    mc, p, (sdf, dev, col, ren) = _tiny(R)
+    e = torch.zeros(0, 3, device=_dev())
+    with pytest.raises((RuntimeError, ValueError, R.native.NativeError)):
+        ren.render_rnb(e, e, e[:, :1], e[:, :1], torch.zeros(3, 0, 1, 3, device=_dev()), cos_anneal_ratio=1.0)
+    # the renderer is still usable afterwards
+    batch = O.synthetic_batch(4, seed=1, step=0)
+    b = {k: v.to(_dev()) for k, v in batch.items()}
+    out = ren.render_rnb(b["rays_o"], b["rays_d"], b["near"], b["far"], b["lights_dir"], cos_anneal_ratio=1.0,
+                         t_rand=b["t_rand"])
+    assert bool(torch.isfinite(out["color_fine"]).all())
