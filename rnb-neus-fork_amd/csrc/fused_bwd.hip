@@ -42,19 +42,19 @@ struct FusedBwdArgs {
   int hook_late, stagger;   // tuning knobs (RNB_HOOK_LATE, RNB_STAGGER)
 };
 
-// AuxTile<TI>: one value per accumulator element of the wave's (32 TI) x 64 block
-template <int TI>
+// AuxTile<TI, TJ>: one value per accumulator element of the wave's (32 TI) x (32 TJ) block
+template <int TI, int TJ = 2>
 struct AuxTile {
-  float v[TI][2][16];
+  float v[TI][TJ][16];
 };
 
 // visits the wave's BT x 64 accumulator block: f(tj, ti, r, col, rowc, row) with rowc the lane-independent
 // part of the row (compile-time after unrolling) and row = rowc + 4*(lane>>5)
-template <int TI, class F>
+template <int TI, int TJ = 2, class F>
 __device__ inline void for_each_acc(int n0, int lane, F f) {
   const int h = lane >> 5, cl = lane & 31;
 #pragma unroll
-  for (int tj = 0; tj < 2; ++tj) {
+  for (int tj = 0; tj < TJ; ++tj) {
     const int col = n0 + tj * 32 + cl;
 #pragma unroll
     for (int ti = 0; ti < TI; ++ti) {
@@ -71,11 +71,11 @@ __device__ inline void for_each_acc(int n0, int lane, F f) {
 // (wave-uniform test: n0 and limit are scalars) and a general body for the one tile that may straddle it.
 // On gfx950 the fp32 MFMA and ordinary vector instructions exclude each other on a SIMD (tools/overlap_probe),
 // so every per-element compare / exec-mask round trip in an epilogue is matrix time lost.
-template <int TI, class FF, class FS>
+template <int TI, int TJ = 2, class FF, class FS>
 __device__ inline void for_each_acc_split(int n0, int lane, int limit, FF fast, FS slow) {
   const int h = lane >> 5, cl = lane & 31;
 #pragma unroll
-  for (int tj = 0; tj < 2; ++tj) {
+  for (int tj = 0; tj < TJ; ++tj) {
     const int col = n0 + tj * 32 + cl;
     if (n0 + tj * 32 + 32 <= limit) {
 #pragma unroll
@@ -98,30 +98,34 @@ __device__ inline void for_each_acc_split(int n0, int lane, int limit, FF fast, 
 }
 
 // issues the buffer loads of one [BT x 256] tile in accumulator layout (no wait: consumed after the MFMA loop)
-template <int TI>
-__device__ inline void prefetch_tile(const float* base, int64_t row0, int n0, int lane, AuxTile<TI>& t) {
+template <int TI, int TJ = 2>
+__device__ inline void prefetch_tile(const float* base, int64_t row0, int n0, int lane, AuxTile<TI, TJ>& t) {
   const BufRsrc rs = tile_rsrc(base + (size_t)row0 * FH, 32 * TI * FH * 4);
   const int h = lane >> 5;
-  for_each_acc<TI>(n0, lane, [&](int tj, int ti, int r, int col, int rowc, int row) {
+  for_each_acc<TI, TJ>(n0, lane, [&](int tj, int ti, int r, int col, int rowc, int row) {
     t.v[ti][tj][r] = bload(rs, (unsigned)(4 * h * FH + col) * 4u, rowc * FH * 4);
   });
 }
 
-// matrix loop of one layer: two alternating weight-register sets for 32-point tiles, the one-set ring for
-// 64-point tiles (register budget)
-template <int TI, class Hook = NoHook>
+// matrix loop of one layer: two alternating weight-register sets, except for 64-point tiles with 64-column
+// waves, which use the one-set ring (register budget)
+template <int TI, int TJ = 2, class Hook = NoHook>
 __device__ inline void layer_mma(const float* __restrict__ X, const float* __restrict__ W, int K, int n0, int lane,
-                                 v16f (&acc)[TI][2], Hook hook = Hook(), int hook_late = 0) {
-  if constexpr (TI == 1) layer_mma_nt<TI>(X, W, K, n0, lane, acc, hook, hook_late);
-  else layer_mma_nt_ring<TI>(X, W, K, n0, lane, acc, hook);
+                                 v16f (&acc)[TI][TJ], Hook hook = Hook(), int hook_late = 0) {
+  if constexpr (TI == 2 && TJ == 2) layer_mma_nt_ring<TI>(X, W, K, n0, lane, acc, hook);
+  else layer_mma_nt<TI, Hook, TJ>(X, W, K, n0, lane, acc, hook, hook_late);
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // R sweep
 // ---------------------------------------------------------------------------------------------------------
-template <int TI>
-__global__ __launch_bounds__(256, 2) void fused_reverse_kernel(FusedBwdArgs g) {
+template <int TI, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_reverse_kernel(FusedBwdArgs g) {
   constexpr int BT = 32 * TI;
+  constexpr int NT = 64 * NW;   // threads
+  constexpr int TJ = 8 / NW;    // 32-column tiles per wave
+  // both operand tiles of an epilogue fit next to the weight fragments unless the wave owns 64 x 64 outputs
+  [[maybe_unused]] constexpr bool BOTH_IN_LOOP = !(TI == 2 && TJ == 2);
   constexpr int NBUF = TI == 1 ? 2 : 1;
   __shared__ __attribute__((aligned(16))) float lds[NBUF * BT * FP + BT * FEP];
   float* X = lds;                          // input of the current layer
@@ -130,7 +134,7 @@ __global__ __launch_bounds__(256, 2) void fused_reverse_kernel(FusedBwdArgs g) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = wave_id();
   const int64_t row0 = (int64_t)blockIdx.x * BT;
-  const int n0 = wave * 64;
+  const int n0 = wave * 32 * TJ;
   const int h = lane >> 5;
   stagger_start(g.stagger);
 
@@ -139,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void fused_reverse_kernel(FusedBwdArgs g) {
     const float* Dl = g.D[g.nh - 1] + (size_t)row0 * FH;
     float* gzl = g.gz[g.nh - 1] + (size_t)row0 * FH;
     const float* ws = g.packed + g.wsdf_off;
-    for (int idx = tid; idx < BT * FH / 4; idx += 256) {
+    for (int idx = tid; idx < BT * FH / 4; idx += NT) {
       const int r = idx >> 6, c4 = idx & 63;
       const vf4 d = *reinterpret_cast<const vf4*>(Dl + r * FH + c4 * 4);
       const vf4 w = *reinterpret_cast<const vf4*>(ws + c4 * 4);
@@ -147,20 +151,20 @@ __global__ __launch_bounds__(256, 2) void fused_reverse_kernel(FusedBwdArgs g) {
       *reinterpret_cast<vf4*>(X + r * FP + c4 * 4) = v;
       *reinterpret_cast<vf4*>(gzl + r * FH + c4 * 4) = v;
     }
-    for (int idx = tid; idx < BT * FEP; idx += 256) GE[idx] = 0.f;
+    for (int idx = tid; idx < BT * FEP; idx += NT) GE[idx] = 0.f;
   }
   __syncthreads();
 
-  v16f acc[TI][2];
-  AuxTile<TI> aD;
+  v16f acc[TI][TJ];
+  AuxTile<TI, TJ> aD;
   for (int l = g.nh - 1; l >= 1; --l) {
-    layer_mma<TI>(X, g.packed + g.wT_off[l], FH, n0, lane, acc,   // g = gz_l W_l  (columns = inputs of layer l)
-                     [&]() { prefetch_tile<TI>(g.D[l - 1], row0, n0, lane, aD); }, g.hook_late);
+    layer_mma<TI, TJ>(X, g.packed + g.wT_off[l], FH, n0, lane, acc,   // g = gz_l W_l  (columns = inputs of layer l)
+                     [&]() { prefetch_tile<TI, TJ>(g.D[l - 1], row0, n0, lane, aD); }, g.hook_late);
     if constexpr (NBUF == 1) lds_barrier();   // every wave has finished reading the tile
     const bool is_skip = (l == g.skip);
     const int ksplit = is_skip ? FH - g.pe : FH;   // columns that belong to layer l-1's output
     const BufRsrc rg = tile_rsrc(g.gz[l - 1] + (size_t)row0 * FH, BT * FH * 4);
-    for_each_acc_split<TI>(
+    for_each_acc_split<TI, TJ>(
         n0, lane, ksplit,
         [&](int tj, int ti, int r, int col, int rowc, int row) {
           const float gzv = acc[ti][tj][r] * aD.v[ti][tj][r];
@@ -182,10 +186,10 @@ __global__ __launch_bounds__(256, 2) void fused_reverse_kernel(FusedBwdArgs g) {
     lds_barrier();
     if constexpr (NBUF == 2) { float* t = X; X = Y; Y = t; }
   }
-  // layer 0: g_e += gz_0 W_0 (Ep = 64 columns: wave 0 only)
-  if (wave == 0) {
-    layer_mma<TI>(X, g.packed + g.wT_off[0], FH, 0, lane, acc);
-    for_each_acc<TI>(0, lane, [&](int tj, int ti, int r, int col, int rowc, int row) {
+  // layer 0: g_e += gz_0 W_0 (Ep = 64 columns: the waves that own columns 0..63)
+  if (n0 < 64) {
+    layer_mma<TI, TJ>(X, g.packed + g.wT_off[0], FH, n0, lane, acc);
+    for_each_acc<TI, TJ>(n0, lane, [&](int tj, int ti, int r, int col, int rowc, int row) {
       if (col < g.pe) GE[row * FEP + col] += acc[ti][tj][r];
     });
   }
@@ -214,9 +218,13 @@ __global__ __launch_bounds__(256, 2) void fused_reverse_kernel(FusedBwdArgs g) {
 // ---------------------------------------------------------------------------------------------------------
 // RA sweep
 // ---------------------------------------------------------------------------------------------------------
-template <int TI>
-__global__ __launch_bounds__(256, 2) void fused_ra_kernel(FusedBwdArgs g) {
+template <int TI, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_ra_kernel(FusedBwdArgs g) {
   constexpr int BT = 32 * TI;
+  constexpr int NT = 64 * NW;   // threads
+  constexpr int TJ = 8 / NW;    // 32-column tiles per wave
+  // both operand tiles of an epilogue fit next to the weight fragments unless the wave owns 64 x 64 outputs
+  [[maybe_unused]] constexpr bool BOTH_IN_LOOP = !(TI == 2 && TJ == 2);
   constexpr int NBUF = TI == 1 ? 2 : 1;
   __shared__ __attribute__((aligned(16))) float lds[NBUF * BT * FP + BT * FEP];
   float* X = lds;
@@ -225,11 +233,11 @@ __global__ __launch_bounds__(256, 2) void fused_ra_kernel(FusedBwdArgs g) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = wave_id();
   const int64_t row0 = (int64_t)blockIdx.x * BT;
-  const int n0 = wave * 64;
+  const int n0 = wave * 32 * TJ;
   const int h = lane >> 5;
   stagger_start(g.stagger);
 
-  for (int idx = tid; idx < BT * g.Ep; idx += 256) {
+  for (int idx = tid; idx < BT * g.Ep; idx += NT) {
     const int r = idx / g.Ep, c = idx - r * g.Ep;
     const float v = g.geb[(row0 + r) * g.Ep + c];
     X[r * FP + c] = v;
@@ -237,23 +245,23 @@ __global__ __launch_bounds__(256, 2) void fused_ra_kernel(FusedBwdArgs g) {
   }
   __syncthreads();
 
-  v16f acc[TI][2];
-  AuxTile<TI> aD, aG;
+  v16f acc[TI][TJ];
+  AuxTile<TI, TJ> aD, aG;
   for (int l = 0; l < g.nh; ++l) {
     // TI == 2: only one operand tile fits next to the weight fragments during the matrix loop; the second
     // one is requested right after it, into the registers the weight fragments leave behind
-    layer_mma<TI>(X, g.packed + g.w_off[l], g.Kp[l], n0, lane, acc,   // gzb = u_l W_l^T
+    layer_mma<TI, TJ>(X, g.packed + g.w_off[l], g.Kp[l], n0, lane, acc,   // gzb = u_l W_l^T
                      [&]() {
-                       prefetch_tile<TI>(g.D[l], row0, n0, lane, aD);
-                       if constexpr (TI == 1) prefetch_tile<TI>(g.gz[l], row0, n0, lane, aG);
+                       prefetch_tile<TI, TJ>(g.D[l], row0, n0, lane, aD);
+                       if constexpr (BOTH_IN_LOOP) prefetch_tile<TI, TJ>(g.gz[l], row0, n0, lane, aG);
                      }, g.hook_late);
-    if constexpr (TI == 2) prefetch_tile<TI>(g.gz[l], row0, n0, lane, aG);
+    if constexpr (!BOTH_IN_LOOP) prefetch_tile<TI, TJ>(g.gz[l], row0, n0, lane, aG);
     if constexpr (NBUF == 1) lds_barrier();
     const int n_real = g.n_real[l];
     const bool pe_tail = (l + 1 == g.skip);
     const BufRsrc rzR = tile_rsrc(g.zR[l] + (size_t)row0 * FH, BT * FH * 4);
     const BufRsrc ru = tile_rsrc(g.u[l + 1] + (size_t)row0 * FH, BT * FH * 4);
-    for_each_acc_split<TI>(
+    for_each_acc_split<TI, TJ>(
         n0, lane, n_real,
         [&](int tj, int ti, int r, int col, int rowc, int row) {
           const unsigned voff = (unsigned)(4 * h * FH + col) * 4u;
@@ -289,9 +297,13 @@ __global__ __launch_bounds__(256, 2) void fused_ra_kernel(FusedBwdArgs g) {
 // ---------------------------------------------------------------------------------------------------------
 // FB sweep
 // ---------------------------------------------------------------------------------------------------------
-template <int TI>
-__global__ __launch_bounds__(256, 2) void fused_fb_kernel(FusedBwdArgs g) {
+template <int TI, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_fb_kernel(FusedBwdArgs g) {
   constexpr int BT = 32 * TI;
+  constexpr int NT = 64 * NW;   // threads
+  constexpr int TJ = 8 / NW;    // 32-column tiles per wave
+  // both operand tiles of an epilogue fit next to the weight fragments unless the wave owns 64 x 64 outputs
+  [[maybe_unused]] constexpr bool BOTH_IN_LOOP = !(TI == 2 && TJ == 2);
   constexpr int NBUF = TI == 1 ? 2 : 1;
   __shared__ __attribute__((aligned(16))) float lds[NBUF * BT * FP];
   float* X = lds;
@@ -299,23 +311,23 @@ __global__ __launch_bounds__(256, 2) void fused_fb_kernel(FusedBwdArgs g) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = wave_id();
   const int64_t row0 = (int64_t)blockIdx.x * BT;
-  const int n0 = wave * 64;
+  const int n0 = wave * 32 * TJ;
   const int h = lane >> 5;
   stagger_start(g.stagger);
 
-  v16f acc[TI][2];
-  AuxTile<TI> aD, aZ;
-  prefetch_tile<TI>(g.D[g.nh - 1], row0, n0, lane, aD);
-  prefetch_tile<TI>(g.zR[g.nh - 1], row0, n0, lane, aZ);
-  zero_acc2<TI>(acc);
+  v16f acc[TI][TJ];
+  AuxTile<TI, TJ> aD, aZ;
+  prefetch_tile<TI, TJ>(g.D[g.nh - 1], row0, n0, lane, aD);
+  prefetch_tile<TI, TJ>(g.zR[g.nh - 1], row0, n0, lane, aZ);
+  for (int ti_ = 0; ti_ < TI; ++ti_) for (int tj_ = 0; tj_ < TJ; ++tj_) for (int r_ = 0; r_ < 16; ++r_) acc[ti_][tj_][r_] = 0.f;
   if (g.fbar != nullptr) {   // ab_{nh-1} = fbar W_feat (+ the sdf-head term below)
     const float* fb = g.fbar + (size_t)row0 * g.ld_fbar;
-    for (int idx = tid; idx < BT * FH / 4; idx += 256) {
+    for (int idx = tid; idx < BT * FH / 4; idx += NT) {
       const int r = idx >> 6, c4 = idx & 63;
       *reinterpret_cast<vf4*>(X + r * FP + c4 * 4) = *reinterpret_cast<const vf4*>(fb + (size_t)r * g.ld_fbar + c4 * 4);
     }
     __syncthreads();
-    layer_mma<TI>(X, g.packed + g.wfT_off, FH, n0, lane, acc);
+    layer_mma<TI, TJ>(X, g.packed + g.wfT_off, FH, n0, lane, acc);
     if constexpr (NBUF == 1) lds_barrier();
   }
   for (int l = g.nh - 1; l >= 0; --l) {
@@ -324,11 +336,11 @@ __global__ __launch_bounds__(256, 2) void fused_fb_kernel(FusedBwdArgs g) {
     const bool head = (l == g.nh - 1);
     const BufRsrc rzb = tile_rsrc(g.zb[l] + (size_t)row0 * FH, BT * FH * 4);
     if (head) {   // + sbar / scale * w_sdf  (the sdf head's contribution to ab_{nh-1}); once per launch
-      for_each_acc<TI>(n0, lane, [&](int tj, int ti, int r, int col, int rowc, int row) {
+      for_each_acc<TI, TJ>(n0, lane, [&](int tj, int ti, int r, int col, int rowc, int row) {
         acc[ti][tj][r] = fmaf(g.sbar[row0 + row] * g.inv_scale, g.packed[g.wsdf_off + col], acc[ti][tj][r]);
       });
     }
-    for_each_acc_split<TI>(
+    for_each_acc_split<TI, TJ>(
         n0, lane, n_real,
         [&](int tj, int ti, int r, int col, int rowc, int row) {
           const float zb = fmaf(acc[ti][tj][r], aD.v[ti][tj][r], aZ.v[ti][tj][r]);
@@ -343,12 +355,12 @@ __global__ __launch_bounds__(256, 2) void fused_fb_kernel(FusedBwdArgs g) {
     if (l == 0) break;
     lds_barrier();
     if constexpr (NBUF == 2) { float* t = X; X = Y; Y = t; }
-    layer_mma<TI>(X, g.packed + g.wT_off[l], FH, n0, lane, acc,   // ab_{l-1} = zb_l W_l
+    layer_mma<TI, TJ>(X, g.packed + g.wT_off[l], FH, n0, lane, acc,   // ab_{l-1} = zb_l W_l
                      [&]() {
-                       prefetch_tile<TI>(g.D[l - 1], row0, n0, lane, aD);
-                       if constexpr (TI == 1) prefetch_tile<TI>(g.zR[l - 1], row0, n0, lane, aZ);
+                       prefetch_tile<TI, TJ>(g.D[l - 1], row0, n0, lane, aD);
+                       if constexpr (BOTH_IN_LOOP) prefetch_tile<TI, TJ>(g.zR[l - 1], row0, n0, lane, aZ);
                      }, g.hook_late);
-    if constexpr (TI == 2) prefetch_tile<TI>(g.zR[l - 1], row0, n0, lane, aZ);
+    if constexpr (!BOTH_IN_LOOP) prefetch_tile<TI, TJ>(g.zR[l - 1], row0, n0, lane, aZ);
     if constexpr (NBUF == 1) lds_barrier();   // every wave has finished reading the tile
   }
 }
@@ -386,6 +398,16 @@ static void fill_args(const Layout& L, const float* packed, PointBufs& pb, Fused
   g.stagger = sg ? atoi(sg) : 0;
 }
 
+// waves per workgroup of the 64-point variants: 4 (64 x 64 outputs per wave, two workgroups per CU) or 8
+// (64 x 32 per wave, one workgroup per CU, no register spills, both operand tiles prefetched).  Measured:
+// R 628 -> 618 us, RA 693 -> 774 us, FB(64-point) 801 -> 702 us (= its 32-point variant): only R takes 8.
+// RNB_BWD_NW = 4 | 8 overrides all three
+static int bwd_nw(int dflt) {
+  static const char* e = getenv("RNB_BWD_NW");
+  static const int v = e ? atoi(e) : 0;
+  return v == 4 || v == 8 ? v : dflt;
+}
+
 // tile height of a sweep: measured defaults (R 651 -> 638 us and RA 717 -> 689 us with 64-point tiles; FB
 // 730 -> 801 us: its second operand tile only fits after the matrix loop and its latency is exposed);
 // RNB_BWD_TI = 1 | 2 overrides all three (A/B knob, also used by the parity tests)
@@ -405,7 +427,8 @@ int fused_reverse(const Layout& L, const float* packed, PointBufs& pb, hipStream
   FusedBwdArgs g;
   fill_args(L, packed, pb, g);
   ProfScope prof(hidden_flops(L, pb.M, 0), s);
-  if (bwd_ti(2) == 2) hipLaunchKernelGGL(fused_reverse_kernel<2>, dim3((unsigned)(pb.Mp / 64)), dim3(256), 0, s, g);
+  if (bwd_ti(2) == 2 && bwd_nw(8) == 8) hipLaunchKernelGGL((fused_reverse_kernel<2, 8>), dim3((unsigned)(pb.Mp / 64)), dim3(512), 0, s, g);
+  else if (bwd_ti(2) == 2) hipLaunchKernelGGL(fused_reverse_kernel<2>, dim3((unsigned)(pb.Mp / 64)), dim3(256), 0, s, g);
   else hipLaunchKernelGGL(fused_reverse_kernel<1>, dim3((unsigned)(pb.Mp / 32)), dim3(256), 0, s, g);
   RNB_CHECK_LAUNCH();
   return RNB_OK;
@@ -415,7 +438,8 @@ int fused_ra(const Layout& L, const float* packed, PointBufs& pb, hipStream_t s)
   FusedBwdArgs g;
   fill_args(L, packed, pb, g);
   ProfScope prof(hidden_flops(L, pb.M, 0), s);
-  if (bwd_ti(2) == 2) hipLaunchKernelGGL(fused_ra_kernel<2>, dim3((unsigned)(pb.Mp / 64)), dim3(256), 0, s, g);
+  if (bwd_ti(2) == 2 && bwd_nw(4) == 8) hipLaunchKernelGGL((fused_ra_kernel<2, 8>), dim3((unsigned)(pb.Mp / 64)), dim3(512), 0, s, g);
+  else if (bwd_ti(2) == 2) hipLaunchKernelGGL(fused_ra_kernel<2>, dim3((unsigned)(pb.Mp / 64)), dim3(256), 0, s, g);
   else hipLaunchKernelGGL(fused_ra_kernel<1>, dim3((unsigned)(pb.Mp / 32)), dim3(256), 0, s, g);
   RNB_CHECK_LAUNCH();
   return RNB_OK;
@@ -427,7 +451,8 @@ int fused_fb(const Layout& L, const float* packed, PointBufs& pb, bool with_colo
   g.fbar = with_color ? pb.cinb : nullptr;
   g.ld_fbar = L.Cinp;
   ProfScope prof(hidden_flops(L, pb.M, 1) + (with_color ? 2.0 * (double)pb.M * L.F * L.H : 0.0), s);
-  if (bwd_ti(1) == 2) hipLaunchKernelGGL(fused_fb_kernel<2>, dim3((unsigned)(pb.Mp / 64)), dim3(256), 0, s, g);
+  if (bwd_ti(1) == 2 && bwd_nw(4) == 8) hipLaunchKernelGGL((fused_fb_kernel<2, 8>), dim3((unsigned)(pb.Mp / 64)), dim3(512), 0, s, g);
+  else if (bwd_ti(1) == 2) hipLaunchKernelGGL(fused_fb_kernel<2>, dim3((unsigned)(pb.Mp / 64)), dim3(256), 0, s, g);
   else hipLaunchKernelGGL(fused_fb_kernel<1>, dim3((unsigned)(pb.Mp / 32)), dim3(256), 0, s, g);
   RNB_CHECK_LAUNCH();
   return RNB_OK;

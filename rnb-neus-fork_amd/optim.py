@@ -75,8 +75,16 @@ class FlatAdam:
                              [p.grad.reshape(-1).to(torch.float32) for p in self.params])
         return self._gather
 
+    def _check_homes(self):
+        base = self.flat.data_ptr()
+        for p, o in zip(self.params, self.offsets):
+            if p.data_ptr() != base + 4 * o:
+                raise RuntimeError("FlatAdam: a parameter no longer lives in the flat buffer (was the module moved "
+                                   "or its .data replaced after the optimizer was built?); rebuild the optimizer")
+
     @torch.no_grad()
     def step(self):
+        self._check_homes()
         g = self._flat_grad()
         grp = self.param_groups[0]
         self.step_count += 1

@@ -384,7 +384,8 @@ print("RESULT" + json.dumps(res))
     # RNB_DW_LDS=1: the dW GEMMs staged through LDS instead of the direct-fragment kernel
     # RNB_BWD_TI: 32- / 64-point tiles in all three backward sweeps (the default mixes them)
     for tag, env in (("fused", {}), ("generic", {"RNB_NO_FUSED": "1"}), ("dw_lds", {"RNB_DW_LDS": "1"}),
-                     ("bwd_ti1", {"RNB_BWD_TI": "1"}), ("bwd_ti2", {"RNB_BWD_TI": "2"})):
+                     ("bwd_ti1", {"RNB_BWD_TI": "1"}), ("bwd_ti2", {"RNB_BWD_TI": "2", "RNB_BWD_NW": "4"}),
+                     ("bwd_ti2_nw8", {"RNB_BWD_TI": "2", "RNB_BWD_NW": "8"})):
         e = dict(os.environ)
         e.update(env)
         r = subprocess.run([sys.executable, "-c", code], cwd=root, env=e, capture_output=True, text=True, timeout=600)
@@ -393,6 +394,6 @@ print("RESULT" + json.dumps(res))
         res[tag] = json.loads(line[len("RESULT"):])
     assert abs(res["fused"]["loss"] - res["generic"]["loss"]) < 1e-5
     assert abs(res["fused"]["wsum"] - res["generic"]["wsum"]) < 1e-3
-    for other in ("generic", "dw_lds", "bwd_ti1", "bwd_ti2"):
+    for other in ("generic", "dw_lds", "bwd_ti1", "bwd_ti2", "bwd_ti2_nw8"):
         for a, c in zip(res["fused"]["g"], res[other]["g"]):
             assert abs(a - c) <= 1e-3 * max(abs(c), 1e-8) + 1e-9, other

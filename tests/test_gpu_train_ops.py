@@ -108,6 +108,18 @@ def test_flat_adam_needs_all_grads(R):
         opt.step()
 
 
+def test_flat_adam_detects_rehomed_parameters(R):
+    dev = torch.device("cuda:0")
+    ps = _param_set(dev, 3)
+    opt = R.FlatAdam(ps)
+    for p in ps:
+        p.grad = torch.zeros_like(p)
+    opt.step()
+    ps[2].data = ps[2].data.clone()          # what module.to(...) / load with assign would do
+    with pytest.raises(RuntimeError, match="flat buffer"):
+        opt.step()
+
+
 def test_train_step_with_library_loss_and_flat_adam_tracks_torch_ops(R):
     """Three train steps of the tiny model: library loss + FlatAdam vs. the oracle's torch-op loss +
     torch.optim.Adam around the same renderer; parameters must stay together."""
