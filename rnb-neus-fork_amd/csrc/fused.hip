@@ -31,7 +31,6 @@ struct FusedFwdArgs {
   float* a[RNB_MAX_LIN];
   float* D[RNB_MAX_LIN];
   float* gz_last;       // [Mp,256] seed of the reverse sweep: w_sdf * D_last (optional)
-  int stagger;          // tuning knob (RNB_STAGGER)
 };
 
 // TI = row tiles per workgroup (64 points for TI = 2; 32 points for TI = 1, used for small batches so that
@@ -55,7 +54,6 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_forward_kernel
   const int wave = wave_id();
   const int64_t row0 = (int64_t)blockIdx.x * FT;
   const int n0 = wave * 32 * TJ;
-  stagger_start(g.stagger);
 
   // ---- positional encoding of the tile: X[:, 0:Ep] = [x, sin(2^k x), cos(2^k x)], zero padded -------
   {
@@ -240,8 +238,6 @@ int fused_forward(const Layout& L, const float* packed, const float* pts, int64_
   g.x4 = pb.x;
   g.e = pb.e;
   g.gz_last = need_gz_last ? pb.gz[L.nh - 1] : nullptr;
-  static const char* sg = getenv("RNB_STAGGER");
-  g.stagger = sg ? atoi(sg) : 0;
   // algorithmic FLOPs of the sweep (real layer shapes), for the optional event instrumentation
   double fl = 0;
   for (int l = 0; l < L.nh; ++l) fl += 2.0 * (double)M * L.hid[l].N * L.hid[l].K;

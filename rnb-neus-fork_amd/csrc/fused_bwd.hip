@@ -39,7 +39,6 @@ struct FusedBwdArgs {
   const float* sbar;    // [Mp]        (FB)
   const float* fbar;    // [Mp,ld_fbar] first 256 columns, or nullptr (FB, no_albedo)
   int ld_fbar;
-  int hook_late, stagger;   // tuning knobs (RNB_HOOK_LATE, RNB_STAGGER)
 };
 
 // AuxTile<TI, TJ>: one value per accumulator element of the wave's (32 TI) x (32 TJ) block
@@ -136,7 +135,6 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_reverse_kernel
   const int64_t row0 = (int64_t)blockIdx.x * BT;
   const int n0 = wave * 32 * TJ;
   const int h = lane >> 5;
-  stagger_start(g.stagger);
 
   // seed: gz_{nh-1} = w_sdf * D_{nh-1}  (row 0 of the output layer is d sdf / d a_last)
   {
@@ -159,7 +157,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_reverse_kernel
   AuxTile<TI, TJ> aD;
   for (int l = g.nh - 1; l >= 1; --l) {
     layer_mma<TI, TJ>(X, g.packed + g.wT_off[l], FH, n0, lane, acc,   // g = gz_l W_l  (columns = inputs of layer l)
-                     [&]() { prefetch_tile<TI, TJ>(g.D[l - 1], row0, n0, lane, aD); }, g.hook_late);
+                     [&]() { prefetch_tile<TI, TJ>(g.D[l - 1], row0, n0, lane, aD); });
     if constexpr (NBUF == 1) lds_barrier();   // every wave has finished reading the tile
     const bool is_skip = (l == g.skip);
     const int ksplit = is_skip ? FH - g.pe : FH;   // columns that belong to layer l-1's output
@@ -235,7 +233,6 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_ra_kernel(Fuse
   const int64_t row0 = (int64_t)blockIdx.x * BT;
   const int n0 = wave * 32 * TJ;
   const int h = lane >> 5;
-  stagger_start(g.stagger);
 
   for (int idx = tid; idx < BT * g.Ep; idx += NT) {
     const int r = idx / g.Ep, c = idx - r * g.Ep;
@@ -254,7 +251,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_ra_kernel(Fuse
                      [&]() {
                        prefetch_tile<TI, TJ>(g.D[l], row0, n0, lane, aD);
                        if constexpr (BOTH_IN_LOOP) prefetch_tile<TI, TJ>(g.gz[l], row0, n0, lane, aG);
-                     }, g.hook_late);
+                     });
     if constexpr (!BOTH_IN_LOOP) prefetch_tile<TI, TJ>(g.gz[l], row0, n0, lane, aG);
     if constexpr (NBUF == 1) lds_barrier();
     const int n_real = g.n_real[l];
@@ -313,7 +310,6 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_fb_kernel(Fuse
   const int64_t row0 = (int64_t)blockIdx.x * BT;
   const int n0 = wave * 32 * TJ;
   const int h = lane >> 5;
-  stagger_start(g.stagger);
 
   v16f acc[TI][TJ];
   AuxTile<TI, TJ> aD, aZ;
@@ -359,7 +355,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_fb_kernel(Fuse
                      [&]() {
                        prefetch_tile<TI, TJ>(g.D[l - 1], row0, n0, lane, aD);
                        if constexpr (BOTH_IN_LOOP) prefetch_tile<TI, TJ>(g.zR[l - 1], row0, n0, lane, aZ);
-                     }, g.hook_late);
+                     });
     if constexpr (!BOTH_IN_LOOP) prefetch_tile<TI, TJ>(g.zR[l - 1], row0, n0, lane, aZ);
     if constexpr (NBUF == 1) lds_barrier();   // every wave has finished reading the tile
   }
@@ -392,10 +388,6 @@ static void fill_args(const Layout& L, const float* packed, PointBufs& pb, Fused
   g.nrm = pb.nrm;
   g.geb = pb.geb;
   g.sbar = pb.sbar;
-  static const char* hl = getenv("RNB_HOOK_LATE");
-  static const char* sg = getenv("RNB_STAGGER");
-  g.hook_late = hl ? atoi(hl) : 0;
-  g.stagger = sg ? atoi(sg) : 0;
 }
 
 // waves per workgroup of the 64-point variants: 4 (64 x 64 outputs per wave, two workgroups per CU) or 8

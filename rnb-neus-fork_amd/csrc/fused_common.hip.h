@@ -162,14 +162,4 @@ __device__ inline void zero_acc2(v16f (&acc)[TI][2]) {
 }
 
 
-// optional start-up stagger: every other group of 8 workgroups sleeps `units` x 64 cycles so that the
-// workgroups sharing a CU do not run their matrix phases and epilogues in lockstep (tuning knob)
-__device__ inline void stagger_start(int units) {
-  // the two workgroups that share a CU at start-up are either dispatch neighbours on one XCD (b, b+8) or a
-  // first-round / second-round pair (b, b+256): flip the parity for both patterns
-  if (units > 0 && (((blockIdx.x >> 3) ^ (blockIdx.x >> 8)) & 1)) {
-    for (int i = 0; i < units; i += 64) __builtin_amdgcn_s_sleep(64);
-  }
-}
-
 }  // namespace rnb
