@@ -213,6 +213,20 @@ int rnb_render_bwd(const rnb_model_desc* desc, const float* packed, const rnb_re
 int rnb_algorithmic_flops(const rnb_model_desc* desc, int64_t B, int32_t flags, double* train_flops,
                           double* forward_flops);
 
+/* Ray / target generation of one train_rnb step on the device: what Dataset.ps_gen_random_rays_at_view_on_all_lights
+ * (models/dataset.py:351-376), the per-pixel light gather (exp_runner.py:214-220) and near_far_from_sphere
+ * (models/dataset.py:448-458) compute on the host, for one view whose tensors are resident in device memory.
+ *   intrinsics_inv, pose [4,4] row-major (intrinsics_all_inv[img_idx], pose_all[img_idx]);
+ *   images, images_warmup, light_directions [n_lights, H, W, 3] of the view (each may be NULL with its output);
+ *   mask [H, W, mask_channels] (channel 0 is used); pixels_x, pixels_y [B] int64, 0 <= x < W, 0 <= y < H.
+ * Outputs: data [B,7] = rays_o | rays_v | mask; true_rgb, true_rgb_warmup, lights_dir [n_lights, B, 3];
+ * near, far [B] (both or neither). */
+int rnb_gen_rays_at_view(const float* intrinsics_inv, const float* pose, const float* images,
+                         const float* images_warmup, const float* mask, int32_t mask_channels,
+                         const float* light_directions, const int64_t* pixels_x, const int64_t* pixels_y, int64_t B,
+                         int32_t n_lights, int32_t H, int32_t W, float* data, float* true_rgb,
+                         float* true_rgb_warmup, float* lights_dir, float* near, float* far, rnb_stream_t stream);
+
 /* The loss of train_rnb (exp_runner.py:241-258) and its gradients with respect to the renderer outputs, one
  * launch:  loss = sum|(color_fine - true_rgb) * mask| / ((sum(mask) + 1e-5) * n_lights)
  *               + igr_weight * gradient_error

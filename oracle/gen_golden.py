@@ -240,6 +240,59 @@ def sharpen(mc, sdf, dev, col, ren, steps, B, lr=1e-3):
         dev.variance.fill_(0.6)
 
 
+def raygen_case():
+    """Golden vectors of the reference's per-step ray generation (models/dataset.py:351-376) on a synthetic
+    3-view / 3-light / 20x24 capture.  The Dataset class is instantiated without its file-reading __init__
+    (needs OpenCV + image files); `cv2` is an inert placeholder module and `.cuda()` is the identity while the
+    reference method runs (there is no GPU in the build container)."""
+    if "cv2" not in sys.modules:
+        sys.modules["cv2"] = types.ModuleType("cv2")
+    import_reference()
+    from models.dataset import Dataset  # type: ignore
+    g = torch.Generator().manual_seed(123)
+    V, L, H, W = 3, 3, 20, 24
+    ds = Dataset.__new__(Dataset)
+    ds.H, ds.W, ds.n_images, ds.n_lights = H, W, V, L
+    ds.images = torch.rand(V, L, H, W, 3, generator=g)
+    ds.images_warmup = torch.rand(V, L, H, W, 3, generator=g)
+    ds.masks = (torch.rand(V, H, W, generator=g) > 0.4).float().unsqueeze(3)
+    ld = torch.randn(V, L, H, W, 3, generator=g)
+    ds.light_directions = ld / ld.norm(dim=-1, keepdim=True)
+    lw = torch.randn(V, L, 3, generator=g)
+    ds.light_directions_warmup = lw / lw.norm(dim=-1, keepdim=True)
+    K = torch.eye(4).repeat(V, 1, 1)
+    K[:, 0, 0] = 30.0 + torch.rand(V, generator=g)
+    K[:, 1, 1] = 31.0 + torch.rand(V, generator=g)
+    K[:, 0, 2] = W / 2.0
+    K[:, 1, 2] = H / 2.0
+    ds.intrinsics_all_inv = torch.inverse(K)
+    q, _ = torch.linalg.qr(torch.randn(V, 3, 3, generator=g))
+    pose = torch.eye(4).repeat(V, 1, 1)
+    pose[:, :3, :3] = q
+    pose[:, :3, 3] = 3.0 * torch.nn.functional.normalize(torch.randn(V, 3, generator=g), dim=-1)
+    ds.pose_all = pose
+    out = {"images": ds.images, "images_warmup": ds.images_warmup, "masks": ds.masks,
+           "light_directions": ds.light_directions, "light_directions_warmup": ds.light_directions_warmup,
+           "intrinsics_all_inv": ds.intrinsics_all_inv, "pose_all": ds.pose_all}
+    orig_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        for case, (img_idx, B, seed) in enumerate([(0, 50, 7), (2, 2, 8), (1, 333, 9)]):   # B = 1 breaks the reference (.squeeze(), dataset.py:367)
+            torch.random.manual_seed(seed)   # exp_runner.py:170 seeds before every draw
+            data, wu, rgb, px, py = ds.ps_gen_random_rays_at_view_on_all_lights(img_idx, B)
+            near, far = ds.near_far_from_sphere(data[:, :3], data[:, 3:6])
+            lights = ds.light_directions[img_idx, :, py.cpu(), px.cpu(), :]     # exp_runner.py:214-218
+            pre = f"c{case}_"
+            out.update({pre + "img_idx": torch.tensor(img_idx), pre + "data": data, pre + "images_warmup": wu,
+                        pre + "images": rgb, pre + "pixels_x": px, pre + "pixels_y": py, pre + "near": near,
+                        pre + "far": far, pre + "lights_dir": lights})
+    finally:
+        torch.Tensor.cuda = orig_cuda
+    path = os.path.join(OUT, "raygen_small.npz")
+    np.savez_compressed(path, **{k: v.detach().cpu().numpy() for k, v in out.items()})
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -278,5 +331,11 @@ def main():
              store_weights=True, grad_stride=1)
 
 
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "raygen":
+    os.makedirs(OUT, exist_ok=True)
+    raygen_case()
+    sys.exit(0)
+
 if __name__ == "__main__":
     main()
+    raygen_case()

@@ -554,3 +554,25 @@ def synthetic_batch(B: int, n_lights: int = 3, seed: int = 0, step: int = 0, n_v
     mask = (closest.norm(dim=-1, keepdim=True) < 0.5).float()
     return {"rays_o": o, "rays_d": d, "near": near, "far": far, "t_rand": t_rand,
             "lights_dir": lights, "true_rgb": true_rgb, "mask": mask}
+
+
+# --------------------------------------------------------------------------------------
+# 8f-2  per-step ray / target generation — models/dataset.py:351-376, exp_runner.py:214-220
+# --------------------------------------------------------------------------------------
+def gen_rays_at_view(ds: dict, img_idx: int, pixels_x: torch.Tensor, pixels_y: torch.Tensor):
+    """Restatement of Dataset.ps_gen_random_rays_at_view_on_all_lights (dataset.py:359-376) for given pixel
+    draws, plus the light gather of exp_runner.py:218 and near_far_from_sphere (dataset.py:448-458).
+    `ds` holds the Dataset tensors: images, images_warmup, masks, light_directions, intrinsics_all_inv, pose_all."""
+    images_warmup = ds["images_warmup"][img_idx, :, pixels_y, pixels_x, :]          # dataset.py:359
+    images = ds["images"][img_idx, :, pixels_y, pixels_x, :]                        # :360
+    mask = ds["masks"][img_idx][(pixels_y, pixels_x)]                               # :363
+    p = torch.stack([pixels_x, pixels_y, torch.ones_like(pixels_y)], dim=-1).float()   # :365
+    p = torch.matmul(ds["intrinsics_all_inv"][img_idx, None, :3, :3], p[:, :, None]).squeeze()   # :367
+    rays_v = p / torch.linalg.norm(p, ord=2, dim=-1, keepdim=True)                  # :369
+    rays_v = torch.matmul(ds["pose_all"][img_idx, None, :3, :3], rays_v[:, :, None]).squeeze()   # :371
+    rays_o = ds["pose_all"][img_idx, None, :3, 3].expand(rays_v.shape)              # :373
+    data = torch.cat([rays_o, rays_v, mask[:, :1]], dim=-1)                         # :376
+    lights_dir = ds["light_directions"][img_idx, :, pixels_y, pixels_x, :]          # exp_runner.py:218
+    near, far = near_far_from_sphere(data[:, :3], data[:, 3:6])
+    return {"data": data, "images_warmup": images_warmup, "images": images, "lights_dir": lights_dir,
+            "near": near, "far": far}

@@ -11,7 +11,25 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def case_names():
-    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+    """Renderer fixtures (tiny_* / full_*); raygen_* fixtures have their own loader below."""
+    names = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+    return [n for n in names if not n.startswith("raygen")]
+
+
+def load_raygen(name="raygen_small"):
+    """Golden vectors of the reference's per-step ray generation (oracle/gen_golden.py::raygen_case):
+    returns (dataset tensors, list of cases)."""
+    import torch
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False)
+    ds = {k: torch.from_numpy(z[k]) for k in ("images", "images_warmup", "masks", "light_directions",
+                                               "light_directions_warmup", "intrinsics_all_inv", "pose_all")}
+    cases = []
+    i = 0
+    while f"c{i}_data" in z.files:
+        pre = f"c{i}_"
+        cases.append({k[len(pre):]: torch.from_numpy(z[k]) for k in z.files if k.startswith(pre)})
+        i += 1
+    return ds, cases
 
 
 class Golden:

@@ -1,0 +1,83 @@
+"""GPU parity of the device-resident ray / target generation (rnb_gen_rays_at_view, DeviceRays) against the
+golden vectors of the reference's Dataset methods and against the oracle.  Gathers (colours, mask, lights) are
+bit-exact; ray directions / near / far within 1e-6 (a 3-term dot product whose fused / unfused evaluation is
+not specified by torch.matmul)."""
+import pytest
+import torch
+
+from oracle import rnb_oracle as O
+from tests.golden_util import load_raygen
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def R():
+    assert torch.cuda.is_available(), "GPU tests need a device"
+    import rnb_neus_fork_amd as pkg
+    pkg.native.load()
+    return pkg
+
+
+def _rays(R, ds):
+    return R.DeviceRays(ds["images"], ds["images_warmup"], ds["masks"], ds["light_directions"],
+                        ds["light_directions_warmup"], ds["intrinsics_all_inv"], ds["pose_all"], "cuda:0")
+
+
+def test_reference_method_signature_and_values(R):
+    ds, cases = load_raygen()
+    dr = _rays(R, ds)
+    for c in cases:
+        v, B = int(c["img_idx"]), c["pixels_x"].numel()
+        data, wu, rgb, px, py = dr.ps_gen_random_rays_at_view_on_all_lights(v, B, c["pixels_x"], c["pixels_y"])
+        assert data.shape == (B, 7) and wu.shape == (3, B, 3) and rgb.shape == (3, B, 3)
+        assert torch.equal(px.cpu(), c["pixels_x"]) and torch.equal(py.cpu(), c["pixels_y"])
+        assert torch.equal(rgb.cpu(), c["images"]) and torch.equal(wu.cpu(), c["images_warmup"])
+        assert torch.equal(data[:, 6].cpu(), c["data"][:, 6])                 # mask
+        assert torch.equal(data[:, :3].cpu(), c["data"][:, :3])               # rays_o: a copy of the pose
+        torch.testing.assert_close(data[:, 3:6].cpu(), c["data"][:, 3:6], rtol=0, atol=1e-6)
+        near, far = dr.near_far_from_sphere(data[:, :3], data[:, 3:6])
+        torch.testing.assert_close(near.cpu(), c["near"], rtol=0, atol=2e-6)
+        torch.testing.assert_close(far.cpu(), c["far"], rtol=0, atol=2e-6)
+        lights = dr.light_directions_at(v, py, px)
+        assert torch.equal(lights.cpu(), c["lights_dir"])
+
+
+@pytest.mark.parametrize("warmup", [False, True])
+def test_one_launch_step_inputs(R, warmup):
+    ds, cases = load_raygen()
+    dr = _rays(R, ds)
+    c = cases[2]
+    v, B = int(c["img_idx"]), c["pixels_x"].numel()
+    s = dr.sample(v, B, warmup=warmup, pixels_x=c["pixels_x"], pixels_y=c["pixels_y"])
+    ref = O.gen_rays_at_view(ds, v, c["pixels_x"], c["pixels_y"])
+    assert s["rays_o"].shape == (B, 3) and s["mask"].shape == (B, 1) and s["near"].shape == (B, 1)
+    torch.testing.assert_close(s["rays_d"].cpu(), ref["data"][:, 3:6], rtol=0, atol=1e-6)
+    torch.testing.assert_close(s["near"].cpu(), ref["near"], rtol=0, atol=2e-6)
+    torch.testing.assert_close(s["far"].cpu(), ref["far"], rtol=0, atol=2e-6)
+    if warmup:
+        assert torch.equal(s["true_rgb"].cpu(), ref["images_warmup"])
+        assert s["lights_dir"].shape == (3, 1, 1, 3)
+        assert torch.equal(s["lights_dir"].reshape(3, 3).cpu(), ds["light_directions_warmup"][v])
+    else:
+        assert torch.equal(s["true_rgb"].cpu(), ref["images"])
+        assert s["lights_dir"].shape == (3, B, 1, 3)
+        assert torch.equal(s["lights_dir"].reshape(3, B, 3).cpu(), ref["lights_dir"])
+
+
+def test_device_draws_single_ray_and_bad_indices(R):
+    ds, cases = load_raygen()
+    dr = _rays(R, ds)
+    s = dr.sample(1, 4096)                       # pixels drawn on the device
+    px, py = s["pixels_x"].cpu(), s["pixels_y"].cpu()
+    assert int(px.min()) >= 0 and int(px.max()) < dr.W and int(py.min()) >= 0 and int(py.max()) < dr.H
+    assert len(torch.unique(py * dr.W + px)) > 400          # 480 pixels, 4096 draws: nearly all are hit
+    ref = O.gen_rays_at_view(ds, 1, px, py)
+    assert torch.equal(s["true_rgb"].cpu(), ref["images"])
+    one = dr.sample(0, 1, pixels_x=torch.tensor([3]), pixels_y=torch.tensor([5]))   # B = 1 (the reference's
+    assert one["rays_d"].shape == (1, 3)                                              # .squeeze() breaks there)
+    assert torch.equal(one["true_rgb"].cpu()[:, 0], ds["images"][0, :, 5, 3])
+    with pytest.raises(IndexError):
+        dr.sample(7, 4)
+    with pytest.raises(ValueError):
+        dr.sample(0, 4, pixels_x=torch.tensor([1, 2]), pixels_y=torch.tensor([1, 2]))

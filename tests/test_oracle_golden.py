@@ -81,3 +81,21 @@ def test_geometric_init_reproduces_reference_state():
     g = Golden("full_warmup_geo")
     assert not g.has_weights
     g.params()  # asserts the checksums of every tensor
+
+
+def test_raygen_oracle_matches_reference_vectors():
+    """oracle.gen_rays_at_view against the reference's Dataset.ps_gen_random_rays_at_view_on_all_lights /
+    near_far_from_sphere / light gather (models/dataset.py:351-376, :448-458; exp_runner.py:214-218) on the
+    reference's own pixel draws: same ops on the same inputs -> bit-exact."""
+    from tests.golden_util import load_raygen
+    ds, cases = load_raygen()
+    assert len(cases) == 3
+    for c in cases:
+        out = O.gen_rays_at_view(ds, int(c["img_idx"]), c["pixels_x"], c["pixels_y"])
+        assert torch.equal(out["data"], c["data"])
+        assert torch.equal(out["images"], c["images"])
+        assert torch.equal(out["images_warmup"], c["images_warmup"])
+        assert torch.equal(out["lights_dir"], c["lights_dir"])
+        assert torch.equal(out["near"], c["near"]) and torch.equal(out["far"], c["far"])
+        B = c["pixels_x"].numel()
+        assert c["data"].shape == (B, 7) and c["images"].shape == (3, B, 3)
