@@ -72,3 +72,38 @@ def test_two_rank_gradients_are_the_mean_of_local_gradients():
     for rank, rel, differs in res:
         assert rel < 1e-5, f"rank {rank}: DP gradient differs from the mean of local gradients by {rel:.2e}"
         assert differs > 1e-3, "the two shards should produce different local gradients"
+
+
+def _grid_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import rnb_neus_fork_amd as R
+    from oracle import rnb_oracle as O
+    dev = torch.device("cuda:0")
+    mc = O.ModelConf(sdf=O.SDFConf(d_out=65, d_hidden=64), color=O.ColorConf(d_feature=64, d_hidden=64),
+                     render=O.RenderConf(n_samples=16, n_importance=16))
+    torch.manual_seed(0)
+    p = O.init_params(mc)
+    sdf, devn, col, ren = R.build_from_named_params(mc, p, dev)
+    lo, hi = torch.tensor([-1.0, -1.0, -1.0]), torch.tensor([1.0, 1.0, 1.0])
+    single = ren.extract_fields(lo, hi, 24, chunk=8)               # 3 x-slabs, no group
+    ren.set_data_parallel()
+    sharded = ren.extract_fields(lo, hi, 24, chunk=8)              # slabs dealt to the 2 ranks + all-reduce
+    q.put((rank, float(abs(single - sharded).max()), float(abs(single).max())))
+    dist.destroy_process_group()
+
+
+def test_extract_fields_sharded_over_ranks_equals_single_rank():
+    """the SDF grid shards by x-slab; every rank ends up with the full volume."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grid_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    for rank, diff, mag in res:
+        assert diff == 0.0 and mag > 0.1, f"rank {rank}: sharded grid differs by {diff}"
