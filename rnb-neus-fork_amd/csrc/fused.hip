@@ -251,7 +251,8 @@ int fused_forward(const Layout& L, const float* packed, const float* pts, int64_
   if (small) {
     const unsigned blocks = (unsigned)(pb.Mp / 32);
     const bool wide = force_nw ? (force_nw[0] == '8') : (blocks <= 256);   // at most one workgroup per CU
-    if (save) hipLaunchKernelGGL((fused_forward_kernel<1, true>), dim3(blocks), dim3(256), 0, s, g);
+    if (save && wide) hipLaunchKernelGGL((fused_forward_kernel<1, true, 8>), dim3(blocks), dim3(512), 0, s, g);
+    else if (save) hipLaunchKernelGGL((fused_forward_kernel<1, true>), dim3(blocks), dim3(256), 0, s, g);
     else if (wide) hipLaunchKernelGGL((fused_forward_kernel<1, false, 8>), dim3(blocks), dim3(512), 0, s, g);
     else hipLaunchKernelGGL((fused_forward_kernel<1, false>), dim3(blocks), dim3(256), 0, s, g);
   } else {

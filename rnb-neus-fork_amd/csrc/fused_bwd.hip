@@ -119,7 +119,7 @@ __device__ inline void layer_mma(const float* __restrict__ X, const float* __res
 // R sweep
 // ---------------------------------------------------------------------------------------------------------
 template <int TI, int NW = 4>
-__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_reverse_kernel(FusedBwdArgs g) {
+__global__ __launch_bounds__(64 * NW, (NW == 8 && TI == 2) ? 1 : 2) void fused_reverse_kernel(FusedBwdArgs g) {
   constexpr int BT = 32 * TI;
   constexpr int NT = 64 * NW;   // threads
   constexpr int TJ = 8 / NW;    // 32-column tiles per wave
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_reverse_kernel
 // RA sweep
 // ---------------------------------------------------------------------------------------------------------
 template <int TI, int NW = 4>
-__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_ra_kernel(FusedBwdArgs g) {
+__global__ __launch_bounds__(64 * NW, (NW == 8 && TI == 2) ? 1 : 2) void fused_ra_kernel(FusedBwdArgs g) {
   constexpr int BT = 32 * TI;
   constexpr int NT = 64 * NW;   // threads
   constexpr int TJ = 8 / NW;    // 32-column tiles per wave
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_ra_kernel(Fuse
 // FB sweep
 // ---------------------------------------------------------------------------------------------------------
 template <int TI, int NW = 4>
-__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_fb_kernel(FusedBwdArgs g) {
+__global__ __launch_bounds__(64 * NW, (NW == 8 && TI == 2) ? 1 : 2) void fused_fb_kernel(FusedBwdArgs g) {
   constexpr int BT = 32 * TI;
   constexpr int NT = 64 * NW;   // threads
   constexpr int TJ = 8 / NW;    // 32-column tiles per wave
@@ -390,19 +390,20 @@ static void fill_args(const Layout& L, const float* packed, PointBufs& pb, Fused
   g.sbar = pb.sbar;
 }
 
-// waves per workgroup of the 64-point variants: 4 (64 x 64 outputs per wave, two workgroups per CU) or 8
-// (64 x 32 per wave, one workgroup per CU, no register spills, both operand tiles prefetched).  Measured:
-// R 628 -> 618 us, RA 693 -> 774 us, FB(64-point) 801 -> 702 us (= its 32-point variant): only R takes 8.
-// RNB_BWD_NW = 4 | 8 overrides all three
+// Variant of the three sweeps: tile height TI (32 / 64 points) x waves per workgroup NW (4: 64 columns per wave;
+// 8: 32 columns per wave).  Measured on 65,536 points (us; R / RA / FB):
+//   TI=1 NW=4: 651 / 717 / 700      two workgroups per CU, 2 waves per SIMD
+//   TI=2 NW=4: 628 / 693 / 801      64-point tiles in place; 49-65 spilled registers, FB's 2nd tile exposed
+//   TI=2 NW=8: 618 / 774 / 702      one workgroup per CU, no spills
+//   TI=1 NW=8: 603 / 671 / 669      two workgroups per CU, 4 waves per SIMD (<= 128 registers)   <- default
+// More resident waves beat larger tiles: what limits these kernels is waiting (operand tiles from HBM, weight
+// fragments from L2), which only other waves' MFMAs can fill.  RNB_BWD_TI / RNB_BWD_NW override all three.
 static int bwd_nw(int dflt) {
   static const char* e = getenv("RNB_BWD_NW");
   static const int v = e ? atoi(e) : 0;
   return v == 4 || v == 8 ? v : dflt;
 }
 
-// tile height of a sweep: measured defaults (R 651 -> 638 us and RA 717 -> 689 us with 64-point tiles; FB
-// 730 -> 801 us: its second operand tile only fits after the matrix loop and its latency is exposed);
-// RNB_BWD_TI = 1 | 2 overrides all three (A/B knob, also used by the parity tests)
 static int bwd_ti(int dflt) {
   static const char* e = getenv("RNB_BWD_TI");
   static const int v = e ? atoi(e) : 0;
@@ -419,8 +420,9 @@ int fused_reverse(const Layout& L, const float* packed, PointBufs& pb, hipStream
   FusedBwdArgs g;
   fill_args(L, packed, pb, g);
   ProfScope prof(hidden_flops(L, pb.M, 0), s);
-  if (bwd_ti(2) == 2 && bwd_nw(8) == 8) hipLaunchKernelGGL((fused_reverse_kernel<2, 8>), dim3((unsigned)(pb.Mp / 64)), dim3(512), 0, s, g);
-  else if (bwd_ti(2) == 2) hipLaunchKernelGGL(fused_reverse_kernel<2>, dim3((unsigned)(pb.Mp / 64)), dim3(256), 0, s, g);
+  if (bwd_ti(1) == 2 && bwd_nw(8) == 8) hipLaunchKernelGGL((fused_reverse_kernel<2, 8>), dim3((unsigned)(pb.Mp / 64)), dim3(512), 0, s, g);
+  else if (bwd_ti(1) == 2) hipLaunchKernelGGL(fused_reverse_kernel<2>, dim3((unsigned)(pb.Mp / 64)), dim3(256), 0, s, g);
+  else if (bwd_nw(8) == 8) hipLaunchKernelGGL((fused_reverse_kernel<1, 8>), dim3((unsigned)(pb.Mp / 32)), dim3(512), 0, s, g);
   else hipLaunchKernelGGL(fused_reverse_kernel<1>, dim3((unsigned)(pb.Mp / 32)), dim3(256), 0, s, g);
   RNB_CHECK_LAUNCH();
   return RNB_OK;
@@ -430,8 +432,9 @@ int fused_ra(const Layout& L, const float* packed, PointBufs& pb, hipStream_t s)
   FusedBwdArgs g;
   fill_args(L, packed, pb, g);
   ProfScope prof(hidden_flops(L, pb.M, 0), s);
-  if (bwd_ti(2) == 2 && bwd_nw(4) == 8) hipLaunchKernelGGL((fused_ra_kernel<2, 8>), dim3((unsigned)(pb.Mp / 64)), dim3(512), 0, s, g);
-  else if (bwd_ti(2) == 2) hipLaunchKernelGGL(fused_ra_kernel<2>, dim3((unsigned)(pb.Mp / 64)), dim3(256), 0, s, g);
+  if (bwd_ti(1) == 2 && bwd_nw(8) == 8) hipLaunchKernelGGL((fused_ra_kernel<2, 8>), dim3((unsigned)(pb.Mp / 64)), dim3(512), 0, s, g);
+  else if (bwd_ti(1) == 2) hipLaunchKernelGGL(fused_ra_kernel<2>, dim3((unsigned)(pb.Mp / 64)), dim3(256), 0, s, g);
+  else if (bwd_nw(8) == 8) hipLaunchKernelGGL((fused_ra_kernel<1, 8>), dim3((unsigned)(pb.Mp / 32)), dim3(512), 0, s, g);
   else hipLaunchKernelGGL(fused_ra_kernel<1>, dim3((unsigned)(pb.Mp / 32)), dim3(256), 0, s, g);
   RNB_CHECK_LAUNCH();
   return RNB_OK;
@@ -443,8 +446,9 @@ int fused_fb(const Layout& L, const float* packed, PointBufs& pb, bool with_colo
   g.fbar = with_color ? pb.cinb : nullptr;
   g.ld_fbar = L.Cinp;
   ProfScope prof(hidden_flops(L, pb.M, 1) + (with_color ? 2.0 * (double)pb.M * L.F * L.H : 0.0), s);
-  if (bwd_ti(1) == 2 && bwd_nw(4) == 8) hipLaunchKernelGGL((fused_fb_kernel<2, 8>), dim3((unsigned)(pb.Mp / 64)), dim3(512), 0, s, g);
+  if (bwd_ti(1) == 2 && bwd_nw(8) == 8) hipLaunchKernelGGL((fused_fb_kernel<2, 8>), dim3((unsigned)(pb.Mp / 64)), dim3(512), 0, s, g);
   else if (bwd_ti(1) == 2) hipLaunchKernelGGL(fused_fb_kernel<2>, dim3((unsigned)(pb.Mp / 64)), dim3(256), 0, s, g);
+  else if (bwd_nw(8) == 8) hipLaunchKernelGGL((fused_fb_kernel<1, 8>), dim3((unsigned)(pb.Mp / 32)), dim3(512), 0, s, g);
   else hipLaunchKernelGGL(fused_fb_kernel<1>, dim3((unsigned)(pb.Mp / 32)), dim3(256), 0, s, g);
   RNB_CHECK_LAUNCH();
   return RNB_OK;

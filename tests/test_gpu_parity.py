@@ -384,7 +384,7 @@ print("RESULT" + json.dumps(res))
     # RNB_DW_LDS=1: the dW GEMMs staged through LDS instead of the direct-fragment kernel
     # RNB_BWD_TI: 32- / 64-point tiles in all three backward sweeps (the default mixes them)
     for tag, env in (("fused", {}), ("generic", {"RNB_NO_FUSED": "1"}), ("dw_lds", {"RNB_DW_LDS": "1"}),
-                     ("bwd_ti1", {"RNB_BWD_TI": "1"}), ("bwd_ti2", {"RNB_BWD_TI": "2", "RNB_BWD_NW": "4"}),
+                     ("bwd_ti1", {"RNB_BWD_TI": "1", "RNB_BWD_NW": "4"}), ("bwd_ti2", {"RNB_BWD_TI": "2", "RNB_BWD_NW": "4"}),
                      ("bwd_ti2_nw8", {"RNB_BWD_TI": "2", "RNB_BWD_NW": "8"})):
         e = dict(os.environ)
         e.update(env)
