@@ -1,9 +1,10 @@
 // Fused reverse-shaped sweeps of the 256-wide SDF network (same skeleton as fused_forward_kernel: a tile of
 // points per workgroup stays in LDS across all layers, weights stream from L2, saved state leaves through
 // fire-and-forget buffer stores).  The per-element operands of the epilogues (D_l, gz_l, zR_l) are
-// prefetched into registers with buffer loads issued BEFORE the layer's matrix loop, so they land while the
-// matrix cores run; 32-point tiles keep that prefetch (2 x 32 registers) inside the register budget and put
-// three workgroups on a CU.
+// prefetched into registers with buffer loads issued inside the layer's matrix loop (after the first weight
+// block has been requested), so they land while the matrix cores run.  Default shape: 32-point tiles, 8 waves
+// of 32 x 32 outputs, two workgroups per CU = 4 waves per SIMD within 128 registers (see the variant table
+// near the end of the file).
 //
 //   fused_reverse_kernel  R : gz_l = g_l * D_l, g_{l-1} = gz_l W_l, normal = J_pe^T g_e   (fields.py:114-127)
 //   fused_ra_kernel       RA: adjoint of R (second-order terms zR_l and the u_l operands of dW)
