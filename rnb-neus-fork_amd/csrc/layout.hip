@@ -96,7 +96,10 @@ int make_layout(const rnb_model_desc* d, Layout* L) {
     L->Co = d->col_d_out;
     L->Cop = kPad;
     L->squeeze = d->col_squeeze_out;
-    for (int l = 0; l < L->nc; ++l) place(L->col[l], L->Hc, l == 0 ? L->Cin : L->Hc, 1.f, off);
+    for (int l = 0; l < L->nc; ++l) {
+      place(L->col[l], L->Hc, l == 0 ? L->Cin : L->Hc, 1.f, off);
+      place_transpose(L->col[l], off);   // the albedo net's backward products also run as k-contiguous GEMMs
+    }
     place(L->colo, L->Co, L->Hc, 1.f, off);
   }
   L->total = off;

@@ -790,10 +790,11 @@ int sweep_backward(const Layout& L, const float* packed, PointBufs& pb, bool wit
       RNB_TRY(dw.add(p, p, 1, ln.Np, ln.Kp, packed_grad + ln.w_off, ln.Kp, packed_grad + ln.b_off, 0, mm_flops(M, ln)));
       if (l > 0) {
         EpiReluMask epi{pb.ac[l - 1], pb.zc[l - 1], L.Hcp, L.col[l - 1].N};
-        RNB_TRY((launch_rows<true, EpiReluMask>(pb.zc[l], L.Hcp, packed + ln.w_off, ln.Kp, Mp, ln.Kp, ln.Np, epi, mm_flops(M, ln), s)));
+        // zc_{l-1} = (zc_l W_l) * relu': k-contiguous product against the transposed copy W_l^T [Kp x Np]
+        RNB_TRY((launch_rows<false, EpiReluMask>(pb.zc[l], L.Hcp, packed + ln.wT_off, ln.Np, Mp, ln.Kp, ln.Np, epi, mm_flops(M, ln), s)));
       } else {
         EpiStore epi{pb.cinb, L.Cinp};
-        RNB_TRY((launch_rows<true, EpiStore>(pb.zc[0], L.Hcp, packed + ln.w_off, ln.Kp, Mp, ln.Kp, ln.Np, epi, mm_flops(M, ln), s)));
+        RNB_TRY((launch_rows<false, EpiStore>(pb.zc[0], L.Hcp, packed + ln.wT_off, ln.Np, Mp, ln.Kp, ln.Np, epi, mm_flops(M, ln), s)));
       }
     }
   }

@@ -171,7 +171,7 @@ static int build_table(const rnb_model_desc* d, const Layout& L, const rnb_mlp_p
     for (int l = 0; l < L.nc; ++l) {
       const Lin& ln = L.col[l];
       add_entry(t, color, gc, l, wc, 0, ln.N, ln.Np, ln.K, ln.Kp, ln.w_off, ln.b_off, 1.f, l == 0 ? L.F : 0,
-                l == 0 ? 2 * L.pev : 0);
+                l == 0 ? 2 * L.pev : 0, ln.wT_off);
     }
     add_entry(t, color, gc, L.nc, wc, 0, L.colo.N, L.colo.Np, L.colo.K, L.colo.Kp, L.colo.w_off, L.colo.b_off, 1.f, 0, 0);
   }

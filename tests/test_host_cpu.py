@@ -49,7 +49,7 @@ def test_packed_layout_size_and_workspace_queries():
     # 8 hidden layers + feature head (each with a transposed copy for the reverse-shaped sweeps) + sdf row
     # + albedo net, all padded to multiples of 32
     expect = (2 * 256 * 64 + 256) + 7 * (2 * 256 * 256 + 256) + (2 * 256 * 256 + 256) + 256 + 32 \
-        + (256 * 320 + 256) + (256 * 256 + 256) + (32 * 256 + 32)
+        + (2 * 256 * 320 + 256) + (2 * 256 * 256 + 256) + (32 * 256 + 32)
     assert n.value == expect
     b = C.c_int64()
     R.native.check(lib.rnb_render_workspace_bytes(C.byref(d), 512, 128, R.native.MODE_MVPS, C.byref(b)))
