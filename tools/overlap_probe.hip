@@ -11,7 +11,7 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
-template <int VMODE, int MTYPE = 0>   // VMODE 0: exp/log/rcp chain (softplus-like), 1: plain fma chain, 2: global dword
+template <int VMODE, int MTYPE = 0, int PRIO = 0>   // PRIO: s_setprio of the non-matrix waves; VMODE 0: exp/log/rcp chain (softplus-like), 1: plain fma chain, 2: global dword
                                       // stores; MTYPE 0: v_mfma_f32_32x32x2_f32, 1: v_mfma_f32_32x32x16_bf16
 __global__ __launch_bounds__(512) void k(float* out, int m_iters, int v_iters, int run_m, int run_v) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -37,6 +37,7 @@ __global__ __launch_bounds__(512) void k(float* out, int m_iters, int v_iters, i
     out[(size_t)blockIdx.x * 512 + threadIdx.x] = s;
   } else {
     if (!run_v) return;
+    if (PRIO) __builtin_amdgcn_s_setprio(PRIO);
     float v[8];
     for (int j = 0; j < 8; ++j) v[j] = 0.001f * (lane + j);
     float* o = out + (size_t)(gridDim.x + blockIdx.x) * 512 * 64;
@@ -77,11 +78,11 @@ static float time_it(F f, int iters) {
   return ms * 1e3f / iters;
 }
 
-template <int VMODE, int MTYPE = 0>
+template <int VMODE, int MTYPE = 0, int PRIO = 0>
 static void run(const char* name, float* out, int m_iters, int v_iters) {
   const int wgs = 256;
   auto t = [&](int rm, int rv) {
-    return time_it([&] { hipLaunchKernelGGL((k<VMODE, MTYPE>), dim3(wgs), dim3(512), 0, 0, out, m_iters, v_iters, rm, rv); }, 10);
+    return time_it([&] { hipLaunchKernelGGL((k<VMODE, MTYPE, PRIO>), dim3(wgs), dim3(512), 0, 0, out, m_iters, v_iters, rm, rv); }, 10);
   };
   const float tm = t(1, 0), tv = t(0, 1), tb = t(1, 1);
   printf("%-28s MFMA alone %8.1f us | other alone %8.1f us | both %8.1f us  (max %.1f, sum %.1f)\n", name, tm, tv, tb,
@@ -95,6 +96,10 @@ int main() {
   run<0>("softplus-like VALU (half)", out, 2000, 1300);
   run<1>("fma chain VALU", out, 2000, 3400);
   run<2>("global dword stores", out, 2000, 6000);
+  printf("-- non-matrix waves at s_setprio 3 --\n");
+  run<0, 0, 3>("softplus-like VALU", out, 2000, 2600);
+  run<1, 0, 3>("fma chain VALU", out, 2000, 3400);
+  run<2, 0, 3>("global dword stores", out, 2000, 6000);
   printf("-- v_mfma_f32_32x32x16_bf16 as the matrix stream --\n");
   run<0, 1>("softplus-like VALU", out, 4000, 2600);
   run<1, 1>("fma chain VALU", out, 4000, 3400);
