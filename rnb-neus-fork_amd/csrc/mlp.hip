@@ -178,10 +178,9 @@ __global__ void color_out_kernel(const float* __restrict__ ac, int Hcp, int Hc, 
 }
 
 // backward of the albedo output layer: zo = albbar * alb(1-alb); zc_last = (zo Wo) * relu'(ac);
-// dWo += zo^T ac ; dbo += sum zo.   One workgroup (512 threads) handles `rows_per_blk` points: thread =
-// (4 columns, row phase of 8); every access is 16 bytes per lane along a row.  blockIdx.y = 256-column chunk;
-// Co <= 4.  Few, fat workgroups: every workgroup ends in atomics on the SAME 3 x 256 addresses, which the L2
-// serialises (~0.1 us each), so their number — not the streaming — bounds the kernel.
+// dWo += zo^T ac ; dbo += sum zo.   A workgroup owns 32 columns (blockIdx.y) and a slab of rows (blockIdx.x):
+// thread = (4 columns, one of 64 row phases); 16-byte accesses, one 128-byte line per row and matrix; an output
+// address receives one atomic per row slab (same-address atomics serialise in the L2).  Co <= 4.
 __global__ __launch_bounds__(512) void color_out_bwd_kernel(const float* __restrict__ albbar,
                                                             const float* __restrict__ alb,
                                                             const float* __restrict__ ac, int Hcp, int Hc,
@@ -189,11 +188,10 @@ __global__ __launch_bounds__(512) void color_out_bwd_kernel(const float* __restr
                                                             int squeeze, int64_t M, int rows_per_blk,
                                                             float* __restrict__ zc, float* __restrict__ dWo,
                                                             float* __restrict__ dbo) {
-  __shared__ float red[7][4][256];   // [phase 1..7][c][column]
-  __shared__ float redb[8][4];
-  const int tid = threadIdx.x, cg = tid & 63, ph = tid >> 6;
-  const int kl = cg * 4, k0 = blockIdx.y * 256 + kl;
-  const bool col_ok = k0 < Hcp;
+  __shared__ float red[64][4][33];
+  __shared__ float redb[64][4];
+  const int tid = threadIdx.x, cg = tid & 7, ph = tid >> 3;
+  const int kl = cg * 4, k0 = blockIdx.y * 32 + kl;
   const bool bias_blk = blockIdx.y == 0;
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_blk;
   const int64_t r1 = min(M, r0 + rows_per_blk);
@@ -202,11 +200,11 @@ __global__ __launch_bounds__(512) void color_out_bwd_kernel(const float* __restr
   for (int c = 0; c < 4; ++c)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      w[c][j] = (col_ok && c < Co && k0 + j < Hc) ? Wo[c * ldwo + k0 + j] : 0.f;
+      w[c][j] = (c < Co && k0 + j < Hc) ? Wo[c * ldwo + k0 + j] : 0.f;
       dw[c][j] = 0.f;
     }
 #pragma unroll 4
-  for (int64_t row = r0 + ph; row < r1; row += 8) {
+  for (int64_t row = r0 + ph; row < r1; row += 64) {
     const vf4 a4 = *reinterpret_cast<const vf4*>(alb + row * 4);
     const vf4 g4 = *reinterpret_cast<const vf4*>(albbar + row * 4);
     float zo[4];
@@ -216,47 +214,36 @@ __global__ __launch_bounds__(512) void color_out_bwd_kernel(const float* __restr
 #pragma unroll
       for (int c = 0; c < 4; ++c) db[c] += zo[c];
     }
-    if (col_ok) {
-      const vf4 av = *reinterpret_cast<const vf4*>(ac + row * Hcp + k0);
-      vf4 z;
+    const vf4 av = *reinterpret_cast<const vf4*>(ac + row * Hcp + k0);
+    vf4 z;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float t = 0.f;
+    for (int j = 0; j < 4; ++j) {
+      float t = 0.f;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { t = fmaf(zo[c], w[c][j], t); dw[c][j] = fmaf(zo[c], av[j], dw[c][j]); }
-        z[j] = (k0 + j < Hc && av[j] > 0.f) ? t : 0.f;
-      }
-      *reinterpret_cast<vf4*>(zc + row * Hcp + k0) = z;
+      for (int c = 0; c < 4; ++c) { t = fmaf(zo[c], w[c][j], t); dw[c][j] = fmaf(zo[c], av[j], dw[c][j]); }
+      z[j] = (k0 + j < Hc && av[j] > 0.f) ? t : 0.f;
     }
+    *reinterpret_cast<vf4*>(zc + row * Hcp + k0) = z;
   }
-  // combine the 8 row phases, then one atomic per (c, column) and workgroup
-  if (ph > 0) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+  for (int c = 0; c < 4; ++c)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) red[ph - 1][c][kl + j] = dw[c][j];
-  }
+    for (int j = 0; j < 4; ++j) red[ph][c][kl + j] = dw[c][j];
   if (cg == 0) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) redb[ph][c] = db[c];
   }
   __syncthreads();
-  if (ph == 0 && col_ok) {
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float t = dw[c][j];
-#pragma unroll
-        for (int q = 0; q < 7; ++q) t += red[q][c][kl + j];
-        if (c < Co && k0 + j < Hc) atomicAdd(dWo + c * ldwo + k0 + j, t);
-      }
-  }
-  if (bias_blk && tid < Co) {
+  if (tid < 128) {            // (c, column) pairs of this chunk
+    const int c = tid >> 5, col = tid & 31;
     float t = 0.f;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) t += redb[q][tid];
-    atomicAdd(dbo + tid, t);
+    for (int q = 0; q < 64; ++q) t += red[q][c][col];
+    if (c < Co && blockIdx.y * 32 + col < Hc) atomicAdd(dWo + c * ldwo + blockIdx.y * 32 + col, t);
+  } else if (bias_blk && tid < 128 + Co) {
+    const int c = tid - 128;
+    float t = 0.f;
+    for (int q = 0; q < 64; ++q) t += redb[q][c];
+    atomicAdd(dbo + c, t);
   }
 }
 
@@ -319,52 +306,41 @@ __global__ __launch_bounds__(64) void nbar_geb_kernel(const float* __restrict__ 
 }
 
 // gradient of the sdf-head row: dw_sdf[k] += sum_rows ( sbar/scale * a_last + u_last ), db_sdf += sum sbar/scale
-// 512 threads: thread = (4 columns, row phase of 8), 16 bytes per lane along the rows; fp64 partial sums (long
-// signed sums).  blockIdx.y = 256-column chunk.  Few, fat workgroups (same-address atomics, see
-// color_out_bwd_kernel).
+// A workgroup owns 32 columns (blockIdx.y) and a slab of rows (blockIdx.x): thread = (4 columns, one of 64 row
+// phases), i.e. every row contributes one 128-byte line per matrix, and an output address only receives one
+// atomic per row slab (same-address atomics serialise in the L2: with whole-row workgroups every address took
+// one atomic from every workgroup).  fp64 partial sums (long signed sums).
 __global__ __launch_bounds__(512) void sdf_head_bwd_kernel(const float* __restrict__ a, const float* __restrict__ ulast,
                                                            int Hp, int H, const float* __restrict__ sbar,
                                                            float inv_scale, int64_t M, int rows_per_blk,
                                                            float* __restrict__ dwsdf, float* __restrict__ dbsdf) {
-  __shared__ double red[7][256];
-  __shared__ double redb[8];
-  const int tid = threadIdx.x, cg = tid & 63, ph = tid >> 6;
-  const int kl = cg * 4, k0 = blockIdx.y * 256 + kl;
-  const bool col_ok = k0 < Hp;
+  __shared__ double red[64][33];
+  __shared__ double redb[64];
+  const int tid = threadIdx.x, cg = tid & 7, ph = tid >> 3;
+  const int kl = cg * 4, k0 = blockIdx.y * 32 + kl;
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_blk;
   const int64_t r1 = min(M, r0 + rows_per_blk);
   double s[4] = {0.0, 0.0, 0.0, 0.0}, sb = 0.0;
 #pragma unroll 4
-  for (int64_t row = r0 + ph; row < r1; row += 8) {
+  for (int64_t row = r0 + ph; row < r1; row += 64) {
     const float t = sbar[row] * inv_scale;
     if (cg == 0) sb += (double)t;
-    if (col_ok) {
-      const vf4 av = *reinterpret_cast<const vf4*>(a + row * Hp + k0);
-      const vf4 uv = *reinterpret_cast<const vf4*>(ulast + row * Hp + k0);
+    const vf4 av = *reinterpret_cast<const vf4*>(a + row * Hp + k0);
+    const vf4 uv = *reinterpret_cast<const vf4*>(ulast + row * Hp + k0);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) s[j] += (double)(t * av[j] + uv[j]);
-    }
+    for (int j = 0; j < 4; ++j) s[j] += (double)(t * av[j] + uv[j]);
   }
-  if (ph > 0) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) red[ph - 1][kl + j] = s[j];
-  }
+  for (int j = 0; j < 4; ++j) red[ph][kl + j] = s[j];
   if (cg == 0) redb[ph] = sb;
   __syncthreads();
-  if (ph == 0 && col_ok) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (k0 + j < H) {
-        double t = s[j];
-#pragma unroll
-        for (int q = 0; q < 7; ++q) t += red[q][kl + j];
-        atomicAdd(dwsdf + k0 + j, (float)t);
-      }
-  }
-  if (tid == 0 && blockIdx.y == 0) {
+  if (tid < 32) {
     double t = 0.0;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) t += redb[q];
+    for (int q = 0; q < 64; ++q) t += red[q][tid];
+    if (blockIdx.y * 32 + tid < H) atomicAdd(dwsdf + blockIdx.y * 32 + tid, (float)t);
+  } else if (tid == 32 && blockIdx.y == 0) {
+    double t = 0.0;
+    for (int q = 0; q < 64; ++q) t += redb[q];
     atomicAdd(dbsdf, (float)t);
   }
 }
@@ -679,12 +655,6 @@ struct DwBatch {
 };
 
 static inline unsigned blocks_for(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
-// rows per workgroup of the column-sum kernels: ~256 workgroups (bounded same-address atomics), >= 64 rows
-static inline int reduce_rows_per_block(int64_t M) {
-  int64_t r = (M + 255) / 256;
-  r = (r + 7) / 8 * 8;
-  return (int)(r < 64 ? 64 : r);
-}
 
 int launch_copy_cols(const float* src, int ld, int ncols, int64_t M, float* out, hipStream_t s) {
   hipLaunchKernelGGL(copy_cols_kernel, dim3(blocks_for(M * ncols, 256)), dim3(256), 0, s, src, ld, ncols, M, out);
@@ -777,8 +747,11 @@ int sweep_backward(const Layout& L, const float* packed, PointBufs& pb, bool wit
   DwBatch dw(M, s);
   // ---- C': albedo network backward ---------------------------------------------------------------
   if (with_color) {
-    const int rows_per_blk = reduce_rows_per_block(M);
-    hipLaunchKernelGGL(color_out_bwd_kernel, dim3(blocks_for(M, rows_per_blk), (L.Hcp + 255) / 256), dim3(512), 0, s, pb.albbar, pb.alb,
+    const int chunks = L.Hcp / 32;   // 32-column chunks x row slabs, ~256 workgroups, slabs a multiple of 64 rows
+    int64_t slabs = (256 + chunks - 1) / chunks;
+    int rows_per_blk = (int)((M + slabs - 1) / slabs);
+    rows_per_blk = (rows_per_blk + 63) / 64 * 64;
+    hipLaunchKernelGGL(color_out_bwd_kernel, dim3(blocks_for(M, rows_per_blk), chunks), dim3(512), 0, s, pb.albbar, pb.alb,
                        pb.ac[L.nc - 1], L.Hcp, L.Hc, packed + L.colo.w_off, L.colo.Kp, L.Co, L.squeeze, M,
                        rows_per_blk, pb.zc[L.nc - 1], packed_grad + L.colo.w_off, packed_grad + L.colo.b_off);
     RNB_CHECK_LAUNCH();
@@ -820,8 +793,12 @@ int sweep_backward(const Layout& L, const float* packed, PointBufs& pb, bool wit
   }
   // ---- sdf-head row gradient ---------------------------------------------------------------------
   {
-    const int rows_per_blk = reduce_rows_per_block(M);
-    hipLaunchKernelGGL(sdf_head_bwd_kernel, dim3(blocks_for(M, rows_per_blk), (L.Hp + 255) / 256), dim3(512), 0, s, pb.a[L.nh - 1],
+    // Hp / 32 column chunks x row slabs, ~256 workgroups in total, slabs a multiple of the 64 row phases
+    const int chunks = L.Hp / 32;
+    int64_t slabs = (256 + chunks - 1) / chunks;
+    int rows_per_blk = (int)((M + slabs - 1) / slabs);
+    rows_per_blk = (rows_per_blk + 63) / 64 * 64;
+    hipLaunchKernelGGL(sdf_head_bwd_kernel, dim3(blocks_for(M, rows_per_blk), chunks), dim3(512), 0, s, pb.a[L.nh - 1],
                        pb.u[L.nh], L.Hp, L.H, pb.sbar, 1.f / L.sdf_scale, M, rows_per_blk,
                        packed_grad + L.wsdf_off, packed_grad + L.bsdf_off);
     RNB_CHECK_LAUNCH();
