@@ -160,3 +160,27 @@ def test_checkpoint_layout_round_trip(tmp_path):
     assert all(torch.equal(a, b) for a, b in zip(sdf.parameters(), sdf2.parameters()))
     assert CK.latest_checkpoint(str(tmp_path / "checkpoints")) == path
     assert CK.latest_checkpoint(str(tmp_path / "checkpoints"), end_iter=100) is None
+
+
+def test_package_synthetic_batches_equal_the_oracle_generator():
+    """bench.py's measured leg draws its rays from the package, the CPU baseline from the oracle: same workload."""
+    from rnb_neus_fork_amd import synthetic as S
+    for kw in (dict(step=0), dict(step=5, warmup=True), dict(step=3, n_lights=2)):
+        a = S.synthetic_batch(64, seed=0, **kw)
+        b = O.synthetic_batch(64, seed=0, **kw)
+        assert a.keys() == b.keys()
+        assert all(torch.equal(a[k], b[k]) for k in a)
+    n, f = S.near_far_from_sphere(torch.tensor([[0.0, 0.0, -3.0]]), torch.tensor([[0.0, 0.0, 1.0]]))
+    assert float(n) == pytest.approx(2.0) and float(f) == pytest.approx(4.0)
+
+
+def test_cpu_tensors_are_rejected_by_the_train_helpers():
+    """No CPU path anywhere: the loss, the flat optimizer and the ray generator refuse host tensors."""
+    with pytest.raises(RuntimeError, match="GPU"):
+        R.FlatAdam([torch.nn.Parameter(torch.zeros(3))])
+    with pytest.raises(RuntimeError, match="GPU"):
+        R.rnb_loss({"color_fine": torch.zeros(3, 4, 3), "weight_sum": torch.zeros(4, 1),
+                    "gradient_error": torch.zeros(())}, torch.zeros(3, 4, 3), torch.zeros(4, 1))
+    with pytest.raises(RuntimeError, match="GPU"):
+        R.DeviceRays(torch.zeros(1, 1, 2, 2, 3), None, torch.zeros(1, 2, 2, 1), None, None, torch.eye(4)[None],
+                     torch.eye(4)[None], "cpu")
