@@ -60,12 +60,18 @@ class DeviceRays:
             pixels_x = torch.randint(0, self.W, (batch_size,), device=self.device)
             pixels_y = torch.randint(0, self.H, (batch_size,), device=self.device)
         else:
-            pixels_x = pixels_x.to(device=self.device, dtype=torch.int64).contiguous()
-            pixels_y = pixels_y.to(device=self.device, dtype=torch.int64).contiguous()
             if pixels_x.shape != (batch_size,) or pixels_y.shape != (batch_size,):
                 raise ValueError("pixels_x / pixels_y must hold batch_size indices")
-            ok = (pixels_x >= 0) & (pixels_x < self.W) & (pixels_y >= 0) & (pixels_y < self.H)
-            torch._assert_async(ok.all())
+            on_host = not pixels_x.is_cuda and not pixels_y.is_cuda
+            if on_host:   # host indices are checked on the host (an IndexError, like torch indexing)
+                if batch_size and (int(pixels_x.min()) < 0 or int(pixels_x.max()) >= self.W
+                                   or int(pixels_y.min()) < 0 or int(pixels_y.max()) >= self.H):
+                    raise IndexError(f"pixel index out of range for a {self.H} x {self.W} image")
+            pixels_x = pixels_x.to(device=self.device, dtype=torch.int64).contiguous()
+            pixels_y = pixels_y.to(device=self.device, dtype=torch.int64).contiguous()
+            if not on_host:   # device indices: asynchronous device-side check, no host round trip
+                ok = (pixels_x >= 0) & (pixels_x < self.W) & (pixels_y >= 0) & (pixels_y < self.H)
+                torch._assert_async(ok.all())
         return pixels_x, pixels_y
 
     def _launch(self, img_idx, pixels_x, pixels_y, want_rgb, want_warmup, want_lights, want_near_far):

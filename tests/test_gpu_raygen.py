@@ -79,5 +79,7 @@ def test_device_draws_single_ray_and_bad_indices(R):
     assert torch.equal(one["true_rgb"].cpu()[:, 0], ds["images"][0, :, 5, 3])
     with pytest.raises(IndexError):
         dr.sample(7, 4)
+    with pytest.raises(IndexError):                                  # host pixel indices are range-checked
+        dr.sample(0, 2, pixels_x=torch.tensor([0, dr.W]), pixels_y=torch.tensor([0, 0]))
     with pytest.raises(ValueError):
         dr.sample(0, 4, pixels_x=torch.tensor([1, 2]), pixels_y=torch.tensor([1, 2]))
