@@ -3,12 +3,17 @@
 One "step" = one train_rnb iteration (exp_runner.py:174-263) on one synthetic ray batch already resident
 in HBM: weight-norm materialisation, hierarchical sampling (64 coarse + 4x16 importance samples), fine
 pass forward (SDF net, analytic normal, albedo net, composite), the R9 loss, the explicit backward,
-[RCCL all-reduce of the flat gradient buffer when N > 1] and Adam.  Workload = BASELINE.json configs[1]:
-wmask_rnb.conf, 512 rays x (64+64) samples per GPU, 3 lights, fp32.
+[RCCL all-reduce of the flat gradient buffer when N > 1] and Adam.  Default workload = BASELINE.json
+configs[1]: wmask_rnb.conf, 512 rays x (64+64) samples per GPU, 3 lights, fp32.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N ...            # WORLD_SIZE unset: this process SPAWNS N ranks (one per GPU) itself,
+                                            # before it touches a GPU, and exits with their status
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W          # the driver's form: ranks come from the env
+    python bench.py --gpus 8 --scaling strong --global-rays 4096       # BASELINE config 4 (strong scaling)
+    python bench.py --dtype bf16 --samples 256                         # BASELINE config 5's arithmetic (bf16 sweeps)
+    python bench.py --mode mesh --resolution 512                       # validate_mesh's SDF grid (forward only)
 
 Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for every field).
 """
@@ -18,6 +23,8 @@ import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,48 +32,91 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # same guide, "Peak BF16/FP16 MFMA ~2.5 PF dense"
+HBM_PEAK_GBS = 8000.0           # same guide, "HBM3E peak BW 8.0 TB/s spec"
+PROFILES = os.path.join(ROOT, "profiles")
 
 
-def measured_traffic(n_gpus, rays):
+def measured_traffic(name, n_gpus, rays, samples):
     """HBM bytes per MFMA-family launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
     see profiles/README.md).  PMC collection needs its own rocprofv3 runs, so bench.py reports the stored
-    measurement of the same workload (N=1, 512 rays) and null for any other shape."""
+    measurement of the same workload and null for any other shape."""
     try:
-        with open(TRAFFIC_JSON) as f:
+        with open(os.path.join(PROFILES, name)) as f:
             t = json.load(f)
-        if n_gpus == 1 and rays == t.get("rays", 512):
-            return round(t["hbm_bytes_per_launch"]), {"hbm_bytes_per_step": round(t["hbm_bytes_per_step"]),
-                                                       "launches_per_step": t["launches_per_step"],
-                                                       "source": "profiles/hbm_traffic.json"}
+        if n_gpus == 1 and rays == t.get("rays", 512) and samples == t.get("samples", 128):
+            return t
     except Exception:
         pass
-    return None, None
+    return None
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--rays", type=int, default=512, help="rays per GPU per step")
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 50)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default 10)")
+    ap.add_argument("--rays", type=int, default=512, help="rays per GPU per step (weak scaling)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--global-rays", type=int, default=4096, help="rays per step of the whole job (strong scaling)")
+    ap.add_argument("--samples", type=int, default=128, help="samples per ray (half coarse, half importance)")
+    ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
+                    help="arithmetic of the SDF-network sweeps (bf16: bf16 operands, fp32 accumulate; config 5)")
+    ap.add_argument("--mode", choices=("train", "mesh"), default="train")
+    ap.add_argument("--resolution", type=int, default=512, help="--mode mesh: grid points per axis")
     ap.add_argument("--warmup-mode", action="store_true", help="render_rnb_warmup instead of render_rnb")
     ap.add_argument("--no-albedo", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--no-gemm-events", action="store_true")
+    ap.add_argument("--deterministic", action="store_true", help="ordered reductions instead of fp32 atomics")
     ap.add_argument("--torch-train-ops", action="store_true",
                     help="loss as the reference's chain of torch ops and torch.optim.Adam(fused=True) instead of "
                          "the library's one-launch loss and flat Adam")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.steps is None:
+        a.steps = 50 if a.mode == "train" else 3
+    if a.warmup is None:
+        a.warmup = 10 if a.mode == "train" else 1
+    return a
+
+
+# -------------------------------------------------------------------------------------------------------
+# launcher: python bench.py --gpus N without a torchrun environment
+# -------------------------------------------------------------------------------------------------------
+def spawn_ranks(args):
+    """Starts one child process per rank BEFORE this process touches a GPU (a process that has initialised HIP
+    must not be replaced or forked on this pool) and waits for them.  With fewer devices than ranks (a one-GPU
+    development box) the ranks share device 0 over gloo: a functional rehearsal of the N > 1 path, flagged
+    `"rehearsal": true` in the JSON line — never a scaling measurement."""
+    import torch   # import only; torch.cuda.device_count() does not initialise the GPU on this image
+    n = args.gpus
+    ndev = torch.cuda.device_count()
+    rehearsal = ndev < n
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        if rehearsal:
+            env.update(RNB_SHARE_GPU="1", RNB_DIST_BACKEND="gloo")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    if rc != 0:
+        print(f"[bench] a rank failed (exit {rc}): fewer than {n} ranks completed", file=sys.stderr)
+    return rc
 
 
 def torch_rnb_loss(render_out, true_rgb, mask, igr_weight=0.1, mask_weight=0.1):
     """The loss exactly as exp_runner.py:229-258 writes it (torch ops on the renderer's outputs)."""
+    import torch
     import torch.nn.functional as F
     n_lights = true_rgb.shape[0]
     mask = (mask > 0.5).float() if mask_weight > 0.0 else torch.ones_like(mask)
@@ -78,18 +128,20 @@ def torch_rnb_loss(render_out, true_rgb, mask, igr_weight=0.1, mask_weight=0.1):
     return color_loss + eik * igr_weight + mask_loss * mask_weight, {}
 
 
-def make_oracle_conf():
-    from oracle import rnb_oracle as O
-    return O, O.ModelConf()
-
-
-def cpu_baseline(rays, steps, warmup_mode, no_albedo):
-    """The oracle (a PyTorch-CPU restatement with the reference's op structure: two fine SDF forwards,
-    autograd double backward, Adam) timed on this box's host cores on a bounded sample."""
-    O, mc = make_oracle_conf()
+def cpu_threads():
     # the GPU box grants 16 host cores per GPU; os.cpu_count() reports the whole host
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    threads = int(os.environ.get("RNB_CPU_THREADS", min(avail, 16)))
+    return int(os.environ.get("RNB_CPU_THREADS", min(avail, 16)))
+
+
+def cpu_baseline(rays, samples, steps, warmup_mode, no_albedo):
+    """The oracle (a PyTorch-CPU restatement with the reference's op structure: two fine SDF forwards,
+    autograd double backward, Adam) timed on this box's host cores on a bounded sample.  The oracle computes in
+    fp32 whatever --dtype says: the reference has no reduced-precision path."""
+    import torch
+    from oracle import rnb_oracle as O
+    mc = O.ModelConf(render=O.RenderConf(n_samples=samples // 2, n_importance=samples // 2))
+    threads = cpu_threads()
     torch.set_num_threads(threads)
     torch.manual_seed(0)
     p = O.init_params(mc)
@@ -114,13 +166,34 @@ def cpu_baseline(rays, steps, warmup_mode, no_albedo):
     times.sort()
     med = times[len(times) // 2]
     return {"value": rays / med, "unit": "rays/s", "cores": threads, "kind": "port",
-            "sample": f"{steps} timed steps (+1 warm-up) of {rays} rays x (64+64) samples, full train step "
-                      f"(render_rnb + loss + backward + Adam) with oracle/rnb_oracle.py, torch {torch.__version__} "
-                      f"CPU fp32, {threads} threads; median {med:.3f} s/step"}
+            "sample": f"{steps} timed steps (+1 warm-up) of {rays} rays x ({samples // 2}+{samples // 2}) samples, "
+                      f"full train step (render_rnb + loss + backward + Adam) with oracle/rnb_oracle.py, torch "
+                      f"{torch.__version__} CPU fp32, {threads} threads; median {med:.3f} s/step"}
 
 
-def main():
-    args = parse()
+def cpu_baseline_mesh(n_points):
+    """CPU leg of --mode mesh: the oracle's SDF forward (models/fields.py:82-108) on a bounded sample of grid points."""
+    import torch
+    from oracle import rnb_oracle as O
+    mc = O.ModelConf()
+    threads = cpu_threads()
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    p = O.init_params(mc)
+    pts = torch.rand(n_points, 3) * 2 - 1
+    with torch.no_grad():
+        O.sdf_only(p, mc.sdf, pts[:4096])
+        t0 = time.perf_counter()
+        O.sdf_only(p, mc.sdf, pts)
+        dt = time.perf_counter() - t0
+    return {"value": n_points / dt, "unit": "points/s", "cores": threads, "kind": "port",
+            "sample": f"one no-grad SDF forward of {n_points} points with oracle/rnb_oracle.py::sdf_only, torch "
+                      f"{torch.__version__} CPU fp32, {threads} threads: {dt:.2f} s"}
+
+
+def init_distributed(args):
+    import torch
+    import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -129,19 +202,44 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (the renderer has no CPU path)"
     # one process per GPU; RNB_SHARE_GPU=1 (functional rehearsal of the N>1 path on a one-GPU box, with
     # RNB_DIST_BACKEND=gloo) puts every rank on device 0
-    if os.environ.get("RNB_SHARE_GPU"):
+    rehearsal = bool(os.environ.get("RNB_SHARE_GPU"))
+    if rehearsal:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    backend = None
     if world > 1:
         backend = os.environ.get("RNB_DIST_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    n_gpus = world
-    if args.gpus != n_gpus and rank == 0:
+        if dist.get_world_size() != world:
+            raise RuntimeError(f"process group has {dist.get_world_size()} ranks, expected {world}")
+    if args.gpus != world and rank == 0:
         print(f"[bench] --gpus {args.gpus} but WORLD_SIZE {world}: using {world}", file=sys.stderr)
+    return world, rank, dev, backend, rehearsal
+
+
+def build_model(R, dev, samples, dtype, deterministic):
+    import torch
+    # confs/wmask_rnb.conf:53-90, constructed in the order of exp_runner.py:95-100 under seed 0
+    torch.manual_seed(0)
+    sdf = R.SDFNetwork(d_out=257, d_in=3, d_hidden=256, n_layers=8, skip_in=[4], multires=6, bias=0.5, scale=1.0,
+                       geometric_init=True, weight_norm=True).to(dev)
+    devnet = R.SingleVarianceNetwork(init_val=0.3).to(dev)
+    col = R.RenderingNetwork(d_feature=256, mode="no_view_dir", d_in=6, d_out=3, d_hidden=256, n_layers=2,
+                             weight_norm=True, multires_view=4, squeeze_out=True).to(dev)
+    ren = R.NeuSRenderer(None, sdf, devnet, col, n_samples=samples // 2, n_importance=samples // 2, n_outside=0,
+                         up_sample_steps=4, perturb=1.0)
+    ren.set_variant(bf16=(dtype == "bf16"), deterministic=deterministic)
+    return sdf, devnet, col, ren
+
+
+def run_train(args):
+    import torch
+    import torch.distributed as dist
+    world, rank, dev, backend, rehearsal = init_distributed(args)
 
     # the measured leg uses the product only (package + librnbneus_hip.so); oracle/ is touched by
     # cpu_baseline() alone
@@ -150,30 +248,29 @@ def main():
     from rnb_neus_fork_amd.synthetic import synthetic_batch
     lib = R.native.load()
 
-    # confs/wmask_rnb.conf:53-90, constructed in the order of exp_runner.py:95-100 under seed 0
-    torch.manual_seed(0)
-    sdf = R.SDFNetwork(d_out=257, d_in=3, d_hidden=256, n_layers=8, skip_in=[4], multires=6, bias=0.5, scale=1.0,
-                       geometric_init=True, weight_norm=True).to(dev)
-    devnet = R.SingleVarianceNetwork(init_val=0.3).to(dev)
-    col = R.RenderingNetwork(d_feature=256, mode="no_view_dir", d_in=6, d_out=3, d_hidden=256, n_layers=2,
-                             weight_norm=True, multires_view=4, squeeze_out=True).to(dev)
-    ren = R.NeuSRenderer(None, sdf, devnet, col, n_samples=64, n_importance=64, n_outside=0, up_sample_steps=4,
-                         perturb=1.0)
+    S = args.samples
+    sdf, devnet, col, ren = build_model(R, dev, S, args.dtype, args.deterministic)
+    exact_dp = not args.torch_train_ops     # the reference's torch-op loss knows nothing about shards
     if world > 1:
         P.broadcast_parameters([sdf, devnet, col])
-        ren.set_data_parallel()
+        ren.set_data_parallel(exact=exact_dp)
     params = list(sdf.parameters()) + list(devnet.parameters())
     if not args.no_albedo:
         params += list(col.parameters())
     # exp_runner.py:115: Adam, lr 5e-4.  Default: the library's flat single-launch Adam (identical update rule,
-    # tests/test_gpu_parity.py); --torch-train-ops keeps torch.optim.Adam and the reference's chain of torch ops
+    # tests/test_gpu_train_ops.py); --torch-train-ops keeps torch.optim.Adam and the reference's chain of torch ops
     # for the loss, i.e. exactly what exp_runner.py would run around the drop-in renderer.
     if args.torch_train_ops:
         opt = torch.optim.Adam(params, lr=5e-4, fused=True)
     else:
         opt = R.FlatAdam(params, lr=5e-4)
 
-    B = args.rays
+    if args.scaling == "strong":
+        if args.global_rays % world:
+            raise SystemExit(f"--global-rays {args.global_rays} is not divisible by {world} ranks")
+        B = args.global_rays // world
+    else:
+        B = args.rays
     n_batches = 8
     # inputs resident in HBM before the timed region: each rank owns its contiguous shard of a global batch
     batches = []
@@ -182,14 +279,17 @@ def main():
         mine = P.shard_batch(gb, rank, world, n_rays=B * world)
         batches.append({k: v.to(dev) for k, v in mine.items()})
 
-    loss_fn = torch_rnb_loss if args.torch_train_ops else R.rnb_loss
+    group = dist.group.WORLD if (world > 1 and exact_dp) else None
 
     def step(i):
         b = batches[i % n_batches]
         fn = ren.render_rnb_warmup if args.warmup_mode else ren.render_rnb
         out = fn(b["rays_o"], b["rays_d"], b["near"], b["far"], b["lights_dir"], cos_anneal_ratio=1.0,
                  no_albedo=args.no_albedo, t_rand=b["t_rand"])
-        loss, _ = loss_fn(out, b["true_rgb"], b["mask"])
+        if args.torch_train_ops:
+            loss, _ = torch_rnb_loss(out, b["true_rgb"], b["mask"])
+        else:
+            loss, _ = R.rnb_loss(out, b["true_rgb"], b["mask"], group=group)
         opt.zero_grad(set_to_none=True)
         loss.backward()
         opt.step()
@@ -205,19 +305,24 @@ def main():
     torch.cuda.synchronize()
     if rank == 0:
         print(f"[bench] warm-up done ({args.warmup} steps)", file=sys.stderr, flush=True)
-    use_events = not args.no_gemm_events
+    use_events = not args.no_gemm_events and rank == 0
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     barrier()
     if use_events:
         lib.rnb_profile_enable(1)
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(args.steps):
         loss = step(args.warmup + i)
+        marks[i + 1].record()
     barrier()
     elapsed = time.perf_counter() - t0
     gemm_ms, gemm_n, gemm_fl = C.c_double(0), C.c_int64(0), C.c_double(0)
     if use_events:
         R.native.check(lib.rnb_profile_collect(C.byref(gemm_ms), C.byref(gemm_n), C.byref(gemm_fl)))
         lib.rnb_profile_enable(0)
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    median_ms = per_step[len(per_step) // 2]
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -232,46 +337,175 @@ def main():
         R.native.check(lib.rnb_algorithmic_flops(C.byref(ren.desc), B, flags, C.byref(tf), C.byref(ff)))
         ms_per_step = 1e3 * elapsed / args.steps
         value = B * world * args.steps / elapsed
+        bf16 = args.dtype == "bf16"
         roof = None
-        traffic, traffic_detail = measured_traffic(world, B)
+        tr = measured_traffic("hbm_traffic_bf16.json" if bf16 else "hbm_traffic.json", world, B, S)
         if use_events and gemm_n.value > 0:
             ach = gemm_fl.value / (gemm_ms.value * 1e-3) / 1e12
-            roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch",
-                    "traffic_detail": traffic_detail,
-                    "kernel": "fp32-MFMA family: fused_forward/reverse/ra/fb_kernel, gemm_dw_direct_kernel, "
-                              "gemm_rows_kernel<*>",
-                    "launches_per_step": gemm_n.value / args.steps,
-                    "avg_launch_us": round(1e3 * gemm_ms.value / gemm_n.value, 2),
-                    "flop_per_launch": round(gemm_fl.value / gemm_n.value, 1),
-                    "gemm_ms_per_step": round(gemm_ms.value / args.steps, 3),
-                    "step_algorithmic_tflops": round(tf.value / (ms_per_step * 1e-3) / 1e12, 3),
-                    "step_frac": round(tf.value / (ms_per_step * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)}
+            step_tf = tf.value / (ms_per_step * 1e-3) / 1e12
+            common = {"launches_per_step": gemm_n.value / args.steps,
+                      "avg_launch_us": round(1e3 * gemm_ms.value / gemm_n.value, 2),
+                      "flop_per_launch": round(gemm_fl.value / gemm_n.value, 1),
+                      "gemm_ms_per_step": round(gemm_ms.value / args.steps, 3),
+                      "step_algorithmic_tflops": round(step_tf, 3)}
+            if not bf16:
+                roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+                        "traffic": round(tr["hbm_bytes_per_launch"]) if tr else None,
+                        "traffic_unit": "HBM bytes per launch",
+                        "traffic_detail": ({"hbm_bytes_per_step": round(tr["hbm_bytes_per_step"]),
+                                            "launches_per_step": tr["launches_per_step"],
+                                            "source": "profiles/hbm_traffic.json"} if tr else None),
+                        "kernel": "fp32-MFMA family: fused_forward/reverse/ra/fb_kernel, gemm_dw_direct_kernel, "
+                                  "gemm_rows_kernel<*>",
+                        "step_frac": round(step_tf / FP32_MFMA_PEAK_TFLOPS, 4)}
+                roof.update(common)
+            else:
+                # bf16 sweeps: 1/16 of the fp32 matrix time, so the per-point saved state decides: the bound is HBM.
+                # achieved = algorithmic bytes of the MFMA-family launches (each saved-state matrix written once and
+                # read by each consumer once: DESIGN 4b) / their device time.
+                alg = None
+                try:
+                    ab = C.c_double()
+                    R.native.check(lib.rnb_algorithmic_bytes(C.byref(ren.desc), B, flags, C.byref(ab)))
+                    alg = ab.value
+                except Exception:
+                    alg = None
+                gbs = (alg * args.steps / (gemm_ms.value * 1e-3) / 1e9) if alg else None
+                roof = {"bound": "hbm", "achieved": round(gbs, 1) if gbs else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(gbs / HBM_PEAK_GBS, 4) if gbs else None,
+                        "traffic": round(tr["hbm_bytes_per_launch"]) if tr else None,
+                        "traffic_unit": "HBM bytes per launch",
+                        "algorithmic_bytes_per_step": alg,
+                        "kernel": "bf16-MFMA family: bf_forward/reverse/ra/fb_kernel, bf_dw_kernel (+ the fp32 albedo GEMMs)",
+                        "mfma_tflops": round(ach, 2), "mfma_frac_of_bf16_peak": round(ach / BF16_MFMA_PEAK_TFLOPS, 4),
+                        "step_frac_of_bf16_peak": round(step_tf / BF16_MFMA_PEAK_TFLOPS, 4)}
+                roof.update(common)
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(B, args.cpu_steps, args.warmup_mode, args.no_albedo)
+            cpu = cpu_baseline(B, S, args.cpu_steps, args.warmup_mode, args.no_albedo)
         line = {
-            "metric": "training rays/sec at 512 rays x 128 samples/ray",
+            "metric": f"training rays/sec at {B} rays x {S} samples/ray",
             "value": round(value, 1), "unit": "rays/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "ms_per_step_median": round(median_ms, 3), "higher_is_better": True,
+            "scaling": args.scaling, "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "rccl_ranks": world if backend == "nccl" else (1 if world == 1 else 0),
             "config": {"workload": "DiLiGenT-MV-shaped synthetic rays, wmask_rnb.conf networks (8x256 SDF MLP + "
                                    "2x256 albedo MLP), train_rnb step "
                                    f"({'render_rnb_warmup' if args.warmup_mode else 'render_rnb'}), "
-                                   f"{B} rays x (64+64) samples per GPU, 3 lights, geometric init, Adam",
-                       "rays_per_gpu": B, "samples_per_ray": 128, "n_lights": 3,
+                                   f"{B} rays x ({S // 2}+{S // 2}) samples per GPU, 3 lights, geometric init, Adam"
+                                   + (f"; strong scaling of a {args.global_rays}-ray global batch" if args.scaling == "strong" else ""),
+                       "rays_per_gpu": B, "global_rays": B * world, "samples_per_ray": S, "n_lights": 3,
                        "no_albedo": bool(args.no_albedo), "parallelism": f"dp{world}", "final_loss": final_loss,
+                       "dp_loss": ("exact large-batch (3 all-reduced scalars + SUM of gradients)" if (world > 1 and exact_dp)
+                                   else ("DDP mean of per-rank losses" if world > 1 else "single process")),
+                       "backend": backend, "deterministic": bool(args.deterministic),
                        "train_ops": ("torch ops loss + torch.optim.Adam(fused)" if args.torch_train_ops
                                      else "rnb_loss_rnb + rnb_adam_step (one launch each)")},
             "roofline": roof,
             "cpu_baseline": cpu,
         }
+        if rehearsal:
+            line["rehearsal"] = True
+            line["config"]["note"] = ("ranks share ONE GPU over gloo: functional rehearsal of the N > 1 path, not a "
+                                      "scaling measurement")
         if cpu:
             line["gpu_over_cpu"] = round(value / cpu["value"], 1)
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def run_mesh(args):
+    """validate_mesh's SDF grid (models/renderer.py:10-25, exp_runner.py:561-581): resolution^3 forward-only SDF
+    evaluations, x-slabs sharded over the ranks, all-gather of the slabs.  A step = one whole grid."""
+    import torch
+    import torch.distributed as dist
+    world, rank, dev, backend, rehearsal = init_distributed(args)
+    import rnb_neus_fork_amd as R
+    lib = R.native.load()
+    sdf, devnet, col, ren = build_model(R, dev, 128, args.dtype, False)
+    if world > 1:
+        from rnb_neus_fork_amd import parallel as P
+        P.broadcast_parameters([sdf, devnet, col])
+        ren.set_data_parallel()
+    res = args.resolution
+    bmin = torch.tensor([-1.01, -1.01, -1.01])
+    bmax = torch.tensor([1.01, 1.01, 1.01])
+
+    def step():
+        return ren.extract_fields(bmin, bmax, res, to_host=False)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    use_events = not args.no_gemm_events and rank == 0
+    barrier()
+    if use_events:
+        lib.rnb_profile_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        u = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    gemm_ms, gemm_n, gemm_fl = C.c_double(0), C.c_int64(0), C.c_double(0)
+    if use_events:
+        R.native.check(lib.rnb_profile_collect(C.byref(gemm_ms), C.byref(gemm_n), C.byref(gemm_fl)))
+        lib.rnb_profile_enable(0)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    if rank == 0:
+        n = res ** 3
+        ms = 1e3 * elapsed / args.steps
+        roof = None
+        if use_events and gemm_n.value > 0:
+            ach = gemm_fl.value / (gemm_ms.value * 1e-3) / 1e12
+            peak = BF16_MFMA_PEAK_TFLOPS if args.dtype == "bf16" else FP32_MFMA_PEAK_TFLOPS
+            roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(ach / peak, 4), "traffic": None,
+                    "kernel": "fused forward-only SDF sweep with in-kernel grid-point generation",
+                    "launches_per_step": gemm_n.value / args.steps,
+                    "avg_launch_us": round(1e3 * gemm_ms.value / gemm_n.value, 2),
+                    "flop_per_launch": round(gemm_fl.value / gemm_n.value, 1),
+                    "step_frac": round(gemm_fl.value / args.steps / (ms * 1e-3) / 1e12 / peak, 4)}
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline_mesh(1 << 20)
+        line = {"metric": f"SDF grid points/sec of validate_mesh at {res}^3", "value": round(n * args.steps / elapsed, 1),
+                "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                "dtype": args.dtype, "data": "synthetic",
+                "rccl_ranks": world if backend == "nccl" else (1 if world == 1 else 0),
+                "config": {"workload": f"extract_fields: {res}^3 SDF evaluations of the wmask_rnb.conf SDF network "
+                                       "(geometric init), x-slabs sharded over the ranks, volume resident in HBM",
+                           "resolution": res, "parallelism": f"dp{world}", "grid_mean": float(u.mean())},
+                "roofline": roof, "cpu_baseline": cpu}
+        if rehearsal:
+            line["rehearsal"] = True
+        if cpu:
+            line["gpu_over_cpu"] = round(line["value"] / cpu["value"], 1)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main():
+    args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
+    if args.mode == "mesh":
+        run_mesh(args)
+    else:
+        run_train(args)
 
 
 if __name__ == "__main__":

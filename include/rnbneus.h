@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RNB_ABI_VERSION 1
+#define RNB_ABI_VERSION 2
 #define RNB_MAX_LIN 16 /* linear layers per MLP */
 
 enum {
@@ -67,8 +67,31 @@ typedef struct rnb_model_desc {
   int32_t n_samples;      /* 64 */
   int32_t n_importance;   /* 64 */
   int32_t up_sample_steps;/* 4 */
-  int32_t reserved;
+  int32_t variant;        /* RNB_VARIANT_* bits: arithmetic / kernel variant of this model instance (0 = default) */
 } rnb_model_desc;
+
+/* rnb_model_desc.variant.  Every switch is an explicit field of the descriptor that accompanies each call: the
+ * library reads no environment variables and keeps no process-global tuning state.
+ *   RNB_VARIANT_BF16          BASELINE config 5: the SDF-network sweeps (forward, reverse normal, their adjoints and
+ *                             the weight gradients) take bf16 operands on v_mfma_f32_32x32x16_bf16 with fp32
+ *                             accumulators; the per-point saved state is bf16.  Master weights, gradients, sampling,
+ *                             the albedo network and the composite stay fp32.  Needs the 256-wide network shape.
+ *   RNB_VARIANT_DETERMINISTIC split-K partial sums go to workspace slabs and are reduced in a fixed order instead of
+ *                             through fp32 atomics: gradients are bit-reproducible from run to run and across ranks.
+ *   RNB_VARIANT_GENERIC       per-layer GEMM chain for every sweep even when the fused kernels support the shape.
+ *   RNB_VARIANT_DW_LDS        LDS-staged weight-gradient GEMMs instead of the register-direct ones.
+ *   RNB_VARIANT_*_TI/_NW      tile height (1: 32 points, 2: 64 points) / waves per workgroup (4 or 8) of the fused
+ *                             backward sweeps (BWD) and of the fused forward (FWD); 0 = the measured default. */
+enum {
+  RNB_VARIANT_BF16 = 1,
+  RNB_VARIANT_DETERMINISTIC = 2,
+  RNB_VARIANT_GENERIC = 4,
+  RNB_VARIANT_DW_LDS = 8,
+  RNB_VARIANT_BWD_TI_SHIFT = 8,   /* 2 bits: 0 default, 1, 2 */
+  RNB_VARIANT_BWD_NW_SHIFT = 10,  /* 2 bits: 0 default, 1 = 4 waves, 2 = 8 waves */
+  RNB_VARIANT_FWD_TI_SHIFT = 12,
+  RNB_VARIANT_FWD_NW_SHIFT = 14
+};
 
 /* Trainable leaves of one MLP in the reference's state_dict naming (linN.weight_g [out,1],
  * linN.weight_v [out,in], linN.bias [out]).  With weight_norm == 0, v holds linN.weight and g is
@@ -122,6 +145,23 @@ int rnb_sdf_gradient(const rnb_model_desc* desc, const float* packed, const floa
 int rnb_color_forward(const rnb_model_desc* desc, const float* packed, const float* pts,
                       const float* normals, const float* feats, int64_t n, float* out, void* ws,
                       size_t ws_bytes, rnb_stream_t stream);
+
+/* ---- SDF grid of validate_mesh --------------------------------------------------------------------
+ * extract_fields (models/renderer.py:10-25) with query_func = -sdf_network.sdf (models/renderer.py:1219-1224):
+ * volume[ix - x_begin, iy, iz] = out_scale * sdf(X[ix], Y[iy], Z[iz]) for x_begin <= ix < x_end, with
+ * X = torch.linspace(bound_min[0], bound_max[0], resolution) etc. generated INSIDE the forward kernel (no point
+ * buffer, no per-point workspace for the 256-wide network: 512^3 = 1.3e8 evaluations are one launch).  A rank of
+ * a data-parallel job asks for its own x-slab.  volume: device [x_end - x_begin, resolution, resolution]. */
+typedef struct rnb_grid_desc {
+  float bound_min[3];
+  float bound_max[3];
+  int32_t resolution;
+  int32_t x_begin, x_end;
+  float out_scale;        /* -1: the reference negates the SDF */
+} rnb_grid_desc;
+int rnb_sdf_grid_workspace_bytes(const rnb_model_desc* desc, const rnb_grid_desc* grid, int64_t* bytes);
+int rnb_sdf_grid(const rnb_model_desc* desc, const float* packed, const rnb_grid_desc* grid, float* volume,
+                 void* ws, size_t ws_bytes, rnb_stream_t stream);
 
 /* ---- hierarchical sampling ---------------------------------------------------------------------
  * rnb_up_sample_step: one iteration of the loop at models/renderer.py:970-982 WITHOUT the network
@@ -187,6 +227,12 @@ typedef struct rnb_render_args {
   /* optional extra outputs of the cores (may be NULL) */
   float* sdf;             /* [B*S] */
   float* sampled_albedo;  /* [B*S,C] (network output, before the no_albedo override) */
+  /* data parallelism with the exact large-batch loss: the eikonal term of models/renderer.py:538-540 is
+   * a ratio of two batch-global sums.  rnb_render_fwd writes this shard's sums (numerator, count) to
+   * gerr_partial [2] when it is non-NULL; rnb_render_bwd divides by *gerr_den_global (the all-reduced count + 1e-5)
+   * instead of the shard's own denominator when it is non-NULL.  Both NULL: single-process behaviour. */
+  float* gerr_partial;
+  const float* gerr_den_global;
 } rnb_render_args;
 
 typedef struct rnb_render_grads { /* d loss / d <output>; NULL = zero */
@@ -238,6 +284,16 @@ int rnb_loss_rnb(const float* color_fine, const float* true_rgb, const float* ma
                  const float* gradient_error, int32_t n_lights, int64_t B, int32_t color_depth, float igr_weight,
                  float mask_weight, float* loss, float* parts, float* d_color_fine, float* d_weight_sum,
                  float* d_gradient_error, rnb_stream_t stream);
+/* The same loss for one shard of a data-parallel batch, normalised by the GLOBAL batch (exp_runner.py:194
+ * mask_sum and :251 BCE mean): mask_sum_global [1] device = all-reduced sum of (mask > 0.5) (without the 1e-5),
+ * B_global = rays of the whole batch, eik_share = this shard's share of the (global) gradient_error in the returned
+ * loss value (1/world).  loss/parts are this shard's ADDITIVE share: their sum over the shards is the loss of the
+ * whole batch, and the sum over the shards of the gradients is its gradient. */
+int rnb_loss_rnb_shard(const float* color_fine, const float* true_rgb, const float* mask, const float* weight_sum,
+                       const float* gradient_error, int32_t n_lights, int64_t B, int32_t color_depth, float igr_weight,
+                       float mask_weight, const float* mask_sum_global, int64_t B_global, float eik_share,
+                       float* loss, float* parts, float* d_color_fine, float* d_weight_sum, float* d_gradient_error,
+                       rnb_stream_t stream);
 
 /* torch.optim.Adam.step() of exp_runner.py:115/:262 (amsgrad off) over ONE flat buffer of n parameters:
  * exp_avg / exp_avg_sq are the optimizer state, `step` the 1-based step count.  lr..weight_decay are host

@@ -121,7 +121,18 @@ class Tracer:
                 return self.t_rand.clone()
             return o_rand(*a, **k)
 
+        o_core, o_mvps = ren.render_core, ren.render_core_mvps
+
+        def core(rays_o, rays_d, z_vals, *a, **k):
+            self.z_fine = z_vals.detach().clone()
+            return o_core(rays_o, rays_d, z_vals, *a, **k)
+
+        def mvps(rays_o, rays_d, z_vals, *a, **k):
+            self.z_fine = z_vals.detach().clone()
+            return o_mvps(rays_o, rays_d, z_vals, *a, **k)
+
         ren.up_sample, ren.cat_z_vals = up, cat
+        ren.render_core, ren.render_core_mvps = core, mvps
         torch.searchsorted, torch.sort, torch.rand = ss, sort, rand
         return self
 
@@ -131,6 +142,95 @@ class Tracer:
         torch.rand = self._orig["rand"]
         del self.ren.up_sample
         del self.ren.cat_z_vals
+        del self.ren.render_core
+        del self.ren.render_core_mvps
+
+
+class Replay:
+    """Makes the reference's up-sampling loop return the sample positions recorded from an fp32 run (cast to the
+    precision of the replaying modules), so that a second run of the reference in fp64 evaluates exactly the same
+    samples: what follows the loop (render_core / render_core_mvps and the wrappers' composite) is then the
+    reference's own code in fp64 on identical z_vals."""
+
+    def __init__(self, ren, steps, t_rand, dtype, z_fine):
+        self.ren, self.steps, self.t_rand, self.dtype, self.z_fine = ren, steps, t_rand, dtype, z_fine
+        self.i = 0
+
+    def __enter__(self):
+        self._rand = torch.rand
+
+        def up(rays_o, rays_d, z_vals, sdf, n_importance, inv_s):
+            return self.steps[self.i]["new_z"].to(self.dtype)
+
+        def cat(rays_o, rays_d, z_vals, new_z_vals, sdf, last=False):
+            st = self.steps[self.i]
+            self.i += 1
+            return st["z_out"].to(self.dtype), st["sdf_out"].to(self.dtype)
+
+        def rand(*a, **k):
+            return self.t_rand.clone().to(self.dtype)
+
+        o_core, o_mvps = self.ren.render_core, self.ren.render_core_mvps
+
+        def core(rays_o, rays_d, z_vals, *a, **k):     # the fine pass sees exactly the fp32 run's z_vals
+            return o_core(rays_o, rays_d, self.z_fine.to(self.dtype), *a, **k)
+
+        def mvps(rays_o, rays_d, z_vals, *a, **k):
+            return o_mvps(rays_o, rays_d, self.z_fine.to(self.dtype), *a, **k)
+
+        self.ren.up_sample, self.ren.cat_z_vals = up, cat
+        self.ren.render_core, self.ren.render_core_mvps = core, mvps
+        torch.rand = rand
+        return self
+
+    def __exit__(self, *exc):
+        torch.rand = self._rand
+        del self.ren.up_sample
+        del self.ren.cat_z_vals
+        del self.ren.render_core
+        del self.ren.render_core_mvps
+
+
+def reference_fp64(mc, sdf, dev, col, ren, batch, tr_steps, z_fine, *, api, cos_anneal_ratio, no_albedo, perturb_overwrite,
+                   background_rgb, with_grads):
+    """The reference itself in double precision on the fp32 run's sample positions.  Returns (outputs, grads)."""
+    rng = torch.get_rng_state()
+    sdf64, dev64, col64, ren64 = build_reference(mc, seed=0)     # fresh modules (weight-normed ones do not deepcopy)
+    torch.set_rng_state(rng)
+    sdf64.load_state_dict(sdf.state_dict())
+    dev64.load_state_dict(dev.state_dict())
+    col64.load_state_dict(col.state_dict())
+    sdf64, dev64, col64 = sdf64.double(), dev64.double(), col64.double()
+    b = {k: v.double() for k, v in batch.items()}
+    bg = background_rgb.double() if background_rgb is not None else None
+    p64 = named_params(sdf64, dev64, col64)
+    old_default = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)   # the reference creates helper tensors (linspace, ones) in the default dtype
+    try:
+        with Replay(ren64, tr_steps, batch["t_rand"], torch.float64, z_fine):
+            if api == "render":
+                out = ren64.render(b["rays_o"], b["rays_d"], b["near"], b["far"], perturb_overwrite=perturb_overwrite,
+                                   background_rgb=bg, cos_anneal_ratio=cos_anneal_ratio)
+            else:
+                fn = ren64.render_rnb_warmup if api == "render_rnb_warmup" else ren64.render_rnb
+                out = fn(b["rays_o"], b["rays_d"], b["near"], b["far"], b["lights_dir"],
+                         perturb_overwrite=perturb_overwrite, background_rgb=bg, cos_anneal_ratio=cos_anneal_ratio,
+                         no_albedo=no_albedo)
+        grads = {}
+        if with_grads:
+            if api == "render":
+                loss = (out["color_fine"] - b["true_rgb"][0]).abs().mean() + 0.1 * out["gradient_error"] \
+                    + 0.1 * torch.nn.functional.binary_cross_entropy(
+                        out["weight_sum"].clip(1e-3, 1 - 1e-3), (b["mask"] > 0.5).double())
+            else:
+                loss, _ = O.rnb_loss(out, b["true_rgb"], b["mask"])
+            loss.backward()
+            out = dict(out)
+            out["loss"] = loss
+            grads = {k: v.grad.detach() for k, v in p64.items() if v.grad is not None}
+    finally:
+        torch.set_default_dtype(old_default)
+    return {k: v.detach() for k, v in out.items()}, grads
 
 
 def conf_arrays(mc: O.ModelConf):
@@ -149,7 +249,7 @@ def conf_arrays(mc: O.ModelConf):
 
 def run_case(name, mc, sdf, dev, col, ren, batch, *, api, cos_anneal_ratio, no_albedo=False,
              perturb_overwrite=-1, background_rgb=None, store_weights=True, grad_stride=1,
-             with_grads=True):
+             with_grads=True, weights_from=None, grad64_stride=None):
     p = named_params(sdf, dev, col)
     for v in p.values():
         v.grad = None
@@ -179,8 +279,7 @@ def run_case(name, mc, sdf, dev, col, ren, batch, *, api, cos_anneal_ratio, no_a
         for k, v in st.items():
             arrs[f"trace.{i}.{k}"] = np.asarray(v.numpy() if torch.is_tensor(v) else v)
     arrs["trace.n_steps"] = np.array(len(tr.steps))
-    if tr.steps:
-        arrs["trace.z_vals"] = tr.steps[-1]["z_out"].numpy()
+    arrs["trace.z_vals"] = tr.z_fine.numpy()     # what the fine pass (render_core / render_core_mvps) received
     for k, v in out.items():
         arrs["out." + k] = v.detach().numpy()
 
@@ -201,7 +300,28 @@ def run_case(name, mc, sdf, dev, col, ren, batch, *, api, cos_anneal_ratio, no_a
             g = v.grad.detach().reshape(-1)
             arrs["grad." + k] = g[::grad_stride].numpy().copy()
             arrs["gradnorm." + k] = np.array(float(g.double().norm()))
-    if store_weights:
+    # ---- the reference in fp64 on the same samples: calibrates the fp32 tolerances of the GPU tests --------
+    out64, g64 = reference_fp64(mc, sdf, dev, col, ren, batch, tr.steps, tr.z_fine, api=api, cos_anneal_ratio=cos_anneal_ratio,
+                                no_albedo=no_albedo, perturb_overwrite=perturb_overwrite,
+                                background_rgb=background_rgb, with_grads=with_grads)
+    for k, v in out64.items():
+        if k in ("inside_sphere",):
+            continue
+        arrs["out64." + k] = v.numpy().astype(np.float64)
+    # fp64 gradients: every element of the small tensors, every 16th (or grad_stride-th) of the large ones; rel32s is
+    # the fp32 reference's own relative L2 distance from fp64 on exactly that subsample (rel32: whole tensor) — the
+    # conditioning of the tensor, against which the GPU tests bound the HIP path's distance from fp64
+    for k, g in g64.items():
+        g = g.reshape(-1)
+        g64s = 1 if g.numel() <= 4096 else (grad64_stride if grad64_stride is not None else max(grad_stride, 16))
+        g32 = p[k].grad.detach().reshape(-1).double()
+        arrs["grad64." + k] = g[::g64s].numpy().copy()
+        arrs["grad64_stride." + k] = np.array(g64s)
+        arrs["rel32." + k] = np.array(float((g32 - g).norm() / g.norm().clamp_min(1e-300)))
+        arrs["rel32s." + k] = np.array(float((g32[::g64s] - g[::g64s]).norm() / g[::g64s].norm().clamp_min(1e-300)))
+    if weights_from is not None:
+        arrs["meta.weights_from"] = np.array(weights_from)
+    elif store_weights:
         for k, v in p.items():
             arrs["w." + k] = v.detach().numpy().copy()
     else:
@@ -293,6 +413,116 @@ def raygen_case():
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 
 
+def train_step_reference(ren, opt, b, warmup, no_albedo=False):
+    """One train_rnb iteration of the reference (exp_runner.py:174-263) on a prepared batch."""
+    fn = ren.render_rnb_warmup if warmup else ren.render_rnb
+    with Tracer(ren) as tr:       # only to feed the batch's t_rand through torch.rand
+        tr.t_rand = b["t_rand"]
+        out = fn(b["rays_o"], b["rays_d"], b["near"], b["far"], b["lights_dir"], cos_anneal_ratio=1.0,
+                 no_albedo=no_albedo)
+    loss, parts = O.rnb_loss(out, b["true_rgb"], b["mask"])
+    opt.zero_grad()
+    loss.backward()
+    opt.step()
+    return float(loss), out
+
+
+def checkpoint_case():
+    """A checkpoint in the reference's own layout (exp_runner.py:373-386): tiny networks + the reference's NeRF
+    container, torch.optim.Adam over `nerf + sdf + variance + color` (exp_runner.py:105-115) after two train steps,
+    written with torch.save as plain tensors / numbers (loads with weights_only=True).  The companion .npz holds the
+    batch of step 3 and every parameter after the reference's step 3, so a test can load the checkpoint, take one
+    step and compare."""
+    import_reference()
+    from models.fields import NeRF  # type: ignore
+    mc = tiny_conf()
+    sdf, dev, col, ren = build_reference(mc, seed=5)
+    torch.manual_seed(6)
+    nerf = NeRF(D=2, W=16, d_in=4, d_in_view=3, multires=2, multires_view=2, output_ch=4, skips=[1], use_viewdirs=True)
+    params = list(nerf.parameters()) + list(sdf.parameters()) + list(dev.parameters()) + list(col.parameters())
+    opt = torch.optim.Adam(params, lr=5e-4)
+    for it in range(2):
+        b = O.synthetic_batch(8, seed=21, step=it, warmup=(it == 0))
+        train_step_reference(ren, opt, b, warmup=(it == 0))
+    ckpt = {"nerf": nerf.state_dict(), "sdf_network_fine": sdf.state_dict(),
+            "variance_network_fine": dev.state_dict(), "color_network_fine": col.state_dict(),
+            "optimizer": opt.state_dict(), "iter_step": 2}
+    path = os.path.join(OUT, "ref_ckpt_tiny.pth")
+    torch.save(ckpt, path)
+    torch.load(path, weights_only=True)   # must be loadable without executing anything
+    b = O.synthetic_batch(8, seed=21, step=2, warmup=False)
+    for g in opt.param_groups:
+        g["lr"] = 3e-4                  # the schedule changes lr every step (exp_runner.py:327-337)
+    loss, _ = train_step_reference(ren, opt, b, warmup=False)
+    arrs = dict(conf_arrays(mc))
+    for k, v in b.items():
+        arrs["in." + k] = v.numpy()
+    arrs["nerf.conf"] = np.array([2, 16, 4, 3, 2, 2, 4, 1], dtype=np.int64)
+    arrs["n_nerf_params"] = np.array(len(list(nerf.parameters())))
+    arrs["loss3"] = np.array(loss)
+    for k, v in named_params(sdf, dev, col).items():
+        arrs["after3." + k] = v.detach().numpy().copy()
+    sd = opt.state_dict()
+    for i, st in sd["state"].items():
+        arrs[f"opt3.{i}.exp_avg"] = st["exp_avg"].numpy().copy()
+        arrs[f"opt3.{i}.exp_avg_sq"] = st["exp_avg_sq"].numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "ref_ckpt_tiny_step3.npz"), **arrs)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB; loss of step 3:", loss)
+
+
+CONV = dict(B=64, steps=200, warm_steps=100, lr=5e-4, warm_up_end=20, end_iter=200, alpha=0.05, eval_steps=4)
+
+
+def convergence_case():
+    """BASELINE config 1 (64 rays x (64+64) samples, 200 iterations): the REFERENCE trained on the analytic sphere
+    capture of oracle/rnb_oracle.py::sphere_scene_batch with the schedule of exp_runner.py:320-332 (scaled to 200
+    iterations), first half render_rnb_warmup, second half render_rnb.  Stores the loss curve, the final PSNR on
+    held-out batches and parameter checksums."""
+    c = CONV
+    mc = O.ModelConf()
+    sdf, dev, col, ren = build_reference(mc, seed=0)
+    params = list(sdf.parameters()) + list(dev.parameters()) + list(col.parameters())
+    opt = torch.optim.Adam(params, lr=c["lr"])
+    losses = []
+    import time
+    t0 = time.time()
+    for it in range(c["steps"]):
+        for g in opt.param_groups:
+            g["lr"] = c["lr"] * O.lr_factor(it, c["warm_up_end"], c["end_iter"], c["alpha"])
+        warm = it < c["warm_steps"]
+        b = O.sphere_scene_batch(c["B"], seed=31, step=it, warmup=warm)
+        loss, _ = train_step_reference(ren, opt, b, warmup=warm)
+        losses.append(loss)
+        if it % 20 == 0:
+            print(f"  conv it {it}: loss {loss:.5f}  ({time.time() - t0:.0f} s)", flush=True)
+    # held-out evaluation: PSNR of the rendered colours inside the silhouette, main mode, no perturbation
+    se, n = 0.0, 0
+    wsum_err = 0.0
+    with torch.no_grad():
+        pass
+    for k in range(c["eval_steps"]):
+        b = O.sphere_scene_batch(c["B"], seed=31, step=1000 + k, warmup=False)
+        with Tracer(ren) as tr:
+            tr.t_rand = b["t_rand"]
+            out = ren.render_rnb(b["rays_o"], b["rays_d"], b["near"], b["far"], b["lights_dir"], perturb_overwrite=0,
+                                 cos_anneal_ratio=1.0)
+        m = b["mask"][None]
+        se += float((((out["color_fine"].detach() - b["true_rgb"]) * m) ** 2).sum())
+        n += int(m.sum()) * 3 * 3
+        wsum_err += float((out["weight_sum"].detach() - b["mask"]).abs().mean())
+    psnr = -10.0 * np.log10(se / n)
+    arrs = {"losses": np.array(losses, dtype=np.float64), "psnr": np.array(psnr),
+            "mask_l1": np.array(wsum_err / c["eval_steps"]),
+            "conf": np.array([c["B"], c["steps"], c["warm_steps"], c["warm_up_end"], c["end_iter"], c["eval_steps"]]),
+            "conf_f": np.array([c["lr"], c["alpha"]])}
+    for k, v in named_params(sdf, dev, col).items():
+        d = v.detach().double().reshape(-1)
+        arrs["wsum." + k] = np.array([float(d.sum()), float((d * d).sum())])
+    np.savez_compressed(os.path.join(OUT, "convergence_ref.npz"), **arrs)
+    print(f"wrote convergence_ref.npz: first loss {losses[0]:.4f}, last {losses[-1]:.4f}, PSNR {psnr:.2f} dB, "
+          f"mask L1 {wsum_err / c['eval_steps']:.4f}")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -329,13 +559,34 @@ def main():
     b = O.synthetic_batch(B, seed=12, step=1, warmup=False)
     run_case("full_main_sharp", mc, sdf, dev, col, ren, b, api="render_rnb", cos_anneal_ratio=1.0,
              store_weights=True, grad_stride=1)
+    # the same sharpened full-size state (weights read from full_main_sharp.npz) through the other entry points:
+    # R5 `render` (config "render_core" named by the north star), BASELINE config 3 (`no_albedo`: the feature rows of
+    # lin8 and the albedo net get no gradient) and BASELINE config 1's n_importance = 0 shape (S = 64)
+    B = 32
+    b = O.synthetic_batch(B, seed=13, step=2, warmup=False)
+    run_case("full_render_sharp", mc, sdf, dev, col, ren, b, api="render", cos_anneal_ratio=1.0,
+             background_rgb=torch.ones(1, 3), weights_from="full_main_sharp", grad_stride=7)
+    b = O.synthetic_batch(B, seed=14, step=3, warmup=False)
+    run_case("full_main_noalbedo", mc, sdf, dev, col, ren, b, api="render_rnb", cos_anneal_ratio=1.0,
+             no_albedo=True, weights_from="full_main_sharp", grad_stride=7)
+    import dataclasses
+    mc64 = dataclasses.replace(mc, render=dataclasses.replace(mc.render, n_importance=0))
+    _, _, _, NeuSRenderer = import_reference()
+    ren64s = NeuSRenderer(None, sdf, dev, col, n_samples=64, n_importance=0, n_outside=0, up_sample_steps=4, perturb=1.0)
+    ren64s.color_depth = mc.color.d_out
+    b = O.synthetic_batch(B, seed=15, step=4, warmup=True)
+    run_case("full_warmup_s64", mc64, sdf, dev, col, ren64s, b, api="render_rnb_warmup", cos_anneal_ratio=1.0,
+             weights_from="full_main_sharp", grad_stride=7)
 
 
-if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "raygen":
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] in ("raygen", "checkpoint", "convergence"):
     os.makedirs(OUT, exist_ok=True)
-    raygen_case()
+    torch.set_num_threads(8)
+    {"raygen": raygen_case, "checkpoint": checkpoint_case, "convergence": convergence_case}[sys.argv[1]]()
     sys.exit(0)
 
 if __name__ == "__main__":
     main()
     raygen_case()
+    checkpoint_case()
+    convergence_case()

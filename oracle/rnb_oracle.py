@@ -556,6 +556,59 @@ def synthetic_batch(B: int, n_lights: int = 3, seed: int = 0, step: int = 0, n_v
             "lights_dir": lights, "true_rgb": true_rgb, "mask": mask}
 
 
+def sphere_scene_batch(B: int, n_lights: int = 3, seed: int = 0, step: int = 0, n_views: int = 20,
+                       warmup: bool = False, radius: float = 0.5, albedo=(0.7, 0.5, 0.3)):
+    """A learnable synthetic capture for the convergence test (SURVEY 8d has no dataset to lean on): the same
+    ray stream as `synthetic_batch`, but the targets are renderings of an analytic Lambertian sphere of the given
+    radius and constant albedo, `true_rgb[l] = albedo * max(n . l, 0)` inside the silhouette and 0 outside — the
+    image model the reference's photometric-stereo inputs follow (models/dataset.py:255-300 builds `images` from
+    normal and albedo maps this way).  Lights: the three warm-up directions (models/dataset.py:257-266) or, in main
+    mode, per-ray unit vectors in the hemisphere around the true normal."""
+    b = synthetic_batch(B, n_lights=n_lights, seed=seed, step=step, n_views=n_views, warmup=warmup)
+    o, d = b["rays_o"], b["rays_d"]
+    tca = -(o * d).sum(-1, keepdim=True)
+    closest = o + d * tca
+    c2 = (closest * closest).sum(-1, keepdim=True)
+    hit = c2 < radius * radius
+    thc = torch.sqrt(torch.clamp(radius * radius - c2, min=0.0))
+    p_hit = o + d * (tca - thc)
+    n = p_hit / radius
+    g = torch.Generator("cpu").manual_seed(seed * 7919 + step + 17)
+    if warmup:
+        # the three warm-up lights live in CAMERA space (dataset.py:257-266, u = -[sin s cos t, sin s sin t, cos s])
+        # and are rotated into the world by the view's pose: a camera at c looking at the origin
+        fwd = -o[0] / o[0].norm()
+        up0 = torch.tensor([0.0, 0.0, 1.0]) if abs(float(fwd[2])) < 0.9 else torch.tensor([1.0, 0.0, 0.0])
+        right = torch.linalg.cross(up0, fwd)
+        right = right / right.norm()
+        up = torch.linalg.cross(fwd, right)
+        u = b["lights_dir"].reshape(n_lights, 3)                  # camera-space directions
+        lw = u[:, 0:1] * right[None] + u[:, 1:2] * up[None] + u[:, 2:3] * fwd[None]
+        lights = lw.reshape(n_lights, 1, 1, 3).contiguous()
+        ldir = lw.reshape(n_lights, 1, 3).expand(n_lights, B, 3)
+    else:
+        r = torch.randn(n_lights, B, 3, generator=g)
+        r = r / r.norm(dim=-1, keepdim=True)
+        r = torch.where(((r * n[None]).sum(-1, keepdim=True) < 0), -r, r)   # flip into the normal's hemisphere
+        ldir = torch.where(hit[None].expand(n_lights, B, 1), r, -d[None].expand(n_lights, B, 3))
+        ldir = ldir / ldir.norm(dim=-1, keepdim=True)
+        lights = ldir.reshape(n_lights, B, 1, 3).contiguous()
+    shade = torch.clamp((ldir * n[None]).sum(-1, keepdim=True), min=0.0)          # [L,B,1]
+    alb = torch.tensor(albedo, dtype=torch.float32).reshape(1, 1, 3)
+    rgb = torch.where(hit[None], alb * shade, torch.zeros(1))
+    out = dict(b)
+    out.update({"lights_dir": lights, "true_rgb": rgb.contiguous(), "mask": hit.float()})
+    return out
+
+
+def lr_factor(iter_step: int, warm_up_end: int, end_iter: int, alpha: float) -> float:
+    """Learning-rate schedule of exp_runner.py:320-332 (linear warm-up, then cosine decay to alpha)."""
+    if iter_step < warm_up_end:
+        return iter_step / warm_up_end
+    progress = (iter_step - warm_up_end) / (end_iter - warm_up_end)
+    return (math.cos(math.pi * progress) + 1.0) * 0.5 * (1 - alpha) + alpha
+
+
 # --------------------------------------------------------------------------------------
 # 8f-2  per-step ray / target generation — models/dataset.py:351-376, exp_runner.py:214-220
 # --------------------------------------------------------------------------------------

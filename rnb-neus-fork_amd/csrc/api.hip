@@ -65,11 +65,8 @@ static int points_setup(const rnb_model_desc* desc, int64_t n, void* ws, size_t 
 }
 
 // positional encoding + forward sweep: fused single-launch kernel for the 256-wide network, generic
-// per-layer GEMM chain otherwise.  RNB_NO_FUSED=1 in the environment forces the generic path (A/B testing).
-static bool use_fused(const Layout& L) {
-  static const bool disabled = getenv("RNB_NO_FUSED") != nullptr;
-  return !disabled && fused_supported(L);
-}
+// per-layer GEMM chain otherwise.  RNB_VARIANT_GENERIC in the descriptor forces the generic path (A/B testing).
+static bool use_fused(const Layout& L) { return !(L.variant & RNB_VARIANT_GENERIC) && fused_supported(L); }
 static int forward_points(const Layout& L, const float* packed, const float* pts, int64_t n, PointBufs& pb,
                           bool save, bool need_feat, bool need_gz_last, float* feat_dense, hipStream_t s) {
   if (use_fused(L)) {
@@ -136,6 +133,81 @@ RNB_API int rnb_color_forward(const rnb_model_desc* desc, const float* packed, c
   RNB_TRY(launch_fill_cols(feats, L.F, n, pb.Mp, L.Cinp, pb.cin, s));
   RNB_TRY(sweep_color(L, packed, pb, pts, normals, 3, s));
   RNB_TRY(launch_copy_cols(pb.alb, 4, L.Co, n, out, s));
+  return RNB_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// SDF grid (extract_fields)
+// ---------------------------------------------------------------------------------------------------
+constexpr int64_t kGridChunk = 1 << 20;   // points per pass of the generic (per-layer GEMM) path
+
+static int check_grid(const rnb_grid_desc* gd, int64_t* n_points) {
+  RNB_REQUIRE(gd, "grid");
+  if (gd->resolution < 1 || gd->resolution > 4096) RNB_FAIL(RNB_E_INVALID, "grid resolution out of range (%d)", gd->resolution);
+  if (gd->x_begin < 0 || gd->x_end > gd->resolution || gd->x_begin > gd->x_end)
+    RNB_FAIL(RNB_E_INVALID, "bad x-slab [%d, %d) of a %d grid", gd->x_begin, gd->x_end, gd->resolution);
+  *n_points = (int64_t)(gd->x_end - gd->x_begin) * gd->resolution * gd->resolution;
+  return RNB_OK;
+}
+
+static GridGen grid_gen_of(const rnb_grid_desc* gd) {
+  GridGen g;
+  g.on = 1;
+  g.res = gd->resolution;
+  g.x_begin = gd->x_begin;
+  for (int d = 0; d < 3; ++d) { g.bmin[d] = gd->bound_min[d]; g.bmax[d] = gd->bound_max[d]; }
+  g.out_scale = gd->out_scale;
+  return g;
+}
+
+RNB_API int rnb_sdf_grid_workspace_bytes(const rnb_model_desc* desc, const rnb_grid_desc* grid, int64_t* bytes) {
+  RNB_REQUIRE(bytes, "bytes");
+  Layout L;
+  RNB_TRY(make_layout(desc, &L));
+  int64_t n;
+  RNB_TRY(check_grid(grid, &n));
+  if (use_fused(L)) { *bytes = 256; return RNB_OK; }   // the fused sweep keeps everything in LDS
+  Carver c(nullptr, 0);
+  PointBufs pb;
+  c.take<float>(kGridChunk * 3);
+  carve_points(L, c, n < kGridChunk ? n : kGridChunk, PM_SDF_ONLY, &pb);
+  *bytes = (int64_t)c.off;
+  return RNB_OK;
+}
+
+RNB_API int rnb_sdf_grid(const rnb_model_desc* desc, const float* packed, const rnb_grid_desc* grid, float* volume,
+                         void* ws, size_t ws_bytes, rnb_stream_t stream) {
+  RNB_REQUIRE(packed, "packed");
+  RNB_REQUIRE(volume, "volume");
+  hipStream_t s = (hipStream_t)stream;
+  Layout L;
+  RNB_TRY(make_layout(desc, &L));
+  int64_t n;
+  RNB_TRY(check_grid(grid, &n));
+  if (n == 0) return RNB_OK;
+  const GridGen gg = grid_gen_of(grid);
+  if (use_fused(L)) {
+    PointBufs pb;
+    memset(&pb, 0, sizeof(pb));
+    pb.M = n;
+    pb.Mp = pad_rows(n);
+    pb.sdf = volume;   // grid mode writes rows < M only
+    return fused_forward(L, packed, nullptr, n, pb, false, false, false, s, &gg);
+  }
+  RNB_REQUIRE(ws, "workspace");
+  for (int64_t first = 0; first < n; first += kGridChunk) {
+    const int64_t m = n - first < kGridChunk ? n - first : kGridChunk;
+    Carver c(ws, ws_bytes);
+    float* pts = c.take<float>(kGridChunk * 3);
+    PointBufs pb;
+    carve_points(L, c, n < kGridChunk ? n : kGridChunk, PM_SDF_ONLY, &pb);
+    if (!c.ok) RNB_FAIL(RNB_E_WORKSPACE, "workspace too small: need %zu bytes, have %zu", c.off, ws_bytes);
+    pb.M = m;
+    pb.Mp = pad_rows(m);
+    RNB_TRY(launch_grid_points(gg, first, m, pts, s));
+    RNB_TRY(forward_points(L, packed, pts, m, pb, false, false, false, nullptr, s));
+    RNB_TRY(launch_scale_copy(pb.sdf, gg.out_scale, m, volume + first, s));
+  }
   return RNB_OK;
 }
 
@@ -378,7 +450,7 @@ RNB_API int rnb_render_fwd(const rnb_model_desc* desc, const float* packed, cons
   RNB_TRY(reverse_points(L, packed, rb.pb, s));
   if (use_color) RNB_TRY(sweep_color(L, packed, rb.pb, rb.pts, rb.pb.nrm, 4, s));
   CompArgs c = comp_args_of(L, a, rb);
-  RNB_TRY(launch_composite_fwd(c, a->gradient_error, rb.gerr_den, s));
+  RNB_TRY(launch_composite_fwd(c, a->gradient_error, rb.gerr_den, a->gerr_partial, s));
   return RNB_OK;
 }
 
@@ -409,6 +481,7 @@ RNB_API int rnb_render_bwd(const rnb_model_desc* desc, const float* packed, cons
   g.g_s_val = gout->s_val;
   g.g_gerr = gout->gradient_error;
   g.gerr_den = rb.gerr_den;
+  g.gerr_den_global = a->gerr_den_global;
   g.sbar = rb.pb.sbar;
   g.nbar = rb.pb.nbar;
   g.albbar = rb.pb.albbar;

@@ -173,7 +173,8 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(CompArgs a) {
 
 // gradient_error = sum_b num_b / (sum_b den_b + 1e-5); keeps the denominator for the backward.
 __global__ __launch_bounds__(256) void gerr_finalize_kernel(const float* __restrict__ part, int64_t B,
-                                                            float* __restrict__ gerr, float* __restrict__ den_out) {
+                                                            float* __restrict__ gerr, float* __restrict__ den_out,
+                                                            float* __restrict__ partial) {
   __shared__ float rn[4], rd[4];
   float n = 0.f, d = 0.f;
   for (int64_t i = threadIdx.x; i < B; i += 256) { n += part[i * 2]; d += part[i * 2 + 1]; }
@@ -183,9 +184,11 @@ __global__ __launch_bounds__(256) void gerr_finalize_kernel(const float* __restr
   __syncthreads();
   if (threadIdx.x == 0) {
     const float nn = rn[0] + rn[1] + rn[2] + rn[3];
-    const float dd = rd[0] + rd[1] + rd[2] + rd[3] + 1e-5f;
+    const float ds = rd[0] + rd[1] + rd[2] + rd[3];
+    const float dd = ds + 1e-5f;
     gerr[0] = nn / dd;
     den_out[0] = dd;
+    if (partial) { partial[0] = nn; partial[1] = ds; }   // this shard's sums, for the data-parallel exact loss
   }
 }
 
@@ -294,7 +297,7 @@ __global__ __launch_bounds__(64) void composite_bwd_kernel(CompBwdArgs g) {
   }
   __syncthreads();
   // pass 2: back through alpha -> cdfs -> sdf / cos -> normal ; eikonal ; inv_s
-  const float gerr_coef = g.g_gerr ? g.g_gerr[0] / g.gerr_den[0] : 0.f;
+  const float gerr_coef = g.g_gerr ? g.g_gerr[0] / (g.gerr_den_global ? g.gerr_den_global[0] : g.gerr_den[0]) : 0.f;
   float invs_bar = 0.f;
   for (int j0 = 0; j0 < S; j0 += 64) {
     const int j = j0 + lane;
@@ -367,12 +370,12 @@ int launch_fine_points(const float* rays_o, const float* rays_d, const float* z,
   return RNB_OK;
 }
 
-int launch_composite_fwd(const CompArgs& a, float* gerr, float* gerr_den, hipStream_t s) {
+int launch_composite_fwd(const CompArgs& a, float* gerr, float* gerr_den, float* gerr_partial, hipStream_t s) {
   if (a.S > kMaxS) RNB_FAIL(RNB_E_INVALID, "samples per ray %d > %d", a.S, kMaxS);
   if (a.L > kMaxL) RNB_FAIL(RNB_E_INVALID, "n_lights %d > %d", a.L, kMaxL);
   hipLaunchKernelGGL(composite_fwd_kernel, dim3((unsigned)a.B), dim3(64), 0, s, a);
   RNB_CHECK_LAUNCH();
-  hipLaunchKernelGGL(gerr_finalize_kernel, dim3(1), dim3(256), 0, s, a.gerr_part, a.B, gerr, gerr_den);
+  hipLaunchKernelGGL(gerr_finalize_kernel, dim3(1), dim3(256), 0, s, a.gerr_part, a.B, gerr, gerr_den, gerr_partial);
   RNB_CHECK_LAUNCH();
   return RNB_OK;
 }

@@ -31,6 +31,7 @@ struct FusedFwdArgs {
   float* a[RNB_MAX_LIN];
   float* D[RNB_MAX_LIN];
   float* gz_last;       // [Mp,256] seed of the reverse sweep: w_sdf * D_last (optional)
+  GridGen grid;         // on: points come from the regular grid, sdf (scaled) goes to rows < M only
 };
 
 // TI = row tiles per workgroup (64 points for TI = 2; 32 points for TI = 1, used for small batches so that
@@ -62,9 +63,21 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_forward_kernel
     const int64_t row = row0 + p;
     float x[3] = {0.f, 0.f, 0.f};
     if (row < g.M) {
-      x[0] = g.pts[row * 3] * g.scale;
-      x[1] = g.pts[row * 3 + 1] * g.scale;
-      x[2] = g.pts[row * 3 + 2] * g.scale;
+      if (g.grid.on) {   // row = ((ix - x_begin) * res + iy) * res + iz of the slab
+        const int res = g.grid.res;
+        int64_t r = row;
+        const int iz = (int)(r % res);
+        r /= res;
+        const int iy = (int)(r % res);
+        const int ix = (int)(r / res) + g.grid.x_begin;
+        x[0] = linspace_at(g.grid.bmin[0], g.grid.bmax[0], res, ix) * g.scale;
+        x[1] = linspace_at(g.grid.bmin[1], g.grid.bmax[1], res, iy) * g.scale;
+        x[2] = linspace_at(g.grid.bmin[2], g.grid.bmax[2], res, iz) * g.scale;
+      } else {
+        x[0] = g.pts[row * 3] * g.scale;
+        x[1] = g.pts[row * 3 + 1] * g.scale;
+        x[2] = g.pts[row * 3 + 2] * g.scale;
+      }
     }
     float* xr = X + p * FP;
     float* er = E + p * FEP;
@@ -166,7 +179,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_forward_kernel
       for (int u = 0; u < 4; ++u) s = fmaf(X[row * FP + lane + 64 * u], w[u], s);
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-      if (lane == 0) g.sdf[row0 + row] = (s + bs) / g.scale;
+      if (lane == 0) {
+        const float v = (s + bs) / g.scale;
+        if (!g.grid.on) g.sdf[row0 + row] = v;
+        else if (row0 + row < g.M) g.sdf[row0 + row] = v * g.grid.out_scale;   // the volume has exactly M entries
+      }
     }
   }
   // ---- feature head: rows 1.. of the output layer, written into the albedo network's input ------------
@@ -206,9 +223,10 @@ bool fused_supported(const Layout& L) {
 
 // Fused replacement of launch_pe_points + sweep_forward (same outputs; pb.a / pb.D only when `save`).
 int fused_forward(const Layout& L, const float* packed, const float* pts, int64_t M, PointBufs& pb, bool save,
-                  bool need_feat, bool need_gz_last, hipStream_t s) {
+                  bool need_feat, bool need_gz_last, hipStream_t s, const GridGen* grid) {
   FusedFwdArgs g;
   memset(&g, 0, sizeof(g));
+  if (grid) g.grid = *grid;
   g.pts = pts;
   g.M = M;
   g.packed = packed;
@@ -245,12 +263,12 @@ int fused_forward(const Layout& L, const float* packed, const float* pts, int64_
   if (need_feat) fl += 2.0 * (double)M * L.F * L.H;
   ProfScope prof(fl, s);
   // 64-point tiles when that still gives every CU >= 2 workgroups, 32-point tiles for small batches
-  static const char* force_ti = getenv("RNB_FWD_TI");   // tuning knob: "1" or "2" forces the tile height
-  const bool small = force_ti ? (force_ti[0] == '1') : (pb.Mp / 64 < 512);
-  static const char* force_nw = getenv("RNB_FWD_NW");   // tuning knob: "4" or "8" waves for small forward-only batches
+  const int force_ti = L.knob(RNB_VARIANT_FWD_TI_SHIFT);   // tuning knob: 1 or 2 forces the tile height
+  const bool small = force_ti ? (force_ti == 1) : (pb.Mp / 64 < 512);
+  const int force_nw = L.knob(RNB_VARIANT_FWD_NW_SHIFT);   // tuning knob: 1 = 4 waves, 2 = 8 waves (small batches)
   if (small) {
     const unsigned blocks = (unsigned)(pb.Mp / 32);
-    const bool wide = force_nw ? (force_nw[0] == '8') : (blocks <= 256);   // at most one workgroup per CU
+    const bool wide = force_nw ? (force_nw == 2) : (blocks <= 256);   // at most one workgroup per CU
     if (save && wide) hipLaunchKernelGGL((fused_forward_kernel<1, true, 8>), dim3(blocks), dim3(512), 0, s, g);
     else if (save) hipLaunchKernelGGL((fused_forward_kernel<1, true>), dim3(blocks), dim3(256), 0, s, g);
     else if (wide) hipLaunchKernelGGL((fused_forward_kernel<1, false, 8>), dim3(blocks), dim3(512), 0, s, g);

@@ -398,16 +398,14 @@ static void fill_args(const Layout& L, const float* packed, PointBufs& pb, Fused
 //   TI=2 NW=8: 618 / 774 / 702      one workgroup per CU, no spills
 //   TI=1 NW=8: 603 / 671 / 669      two workgroups per CU, 4 waves per SIMD (<= 128 registers)   <- default
 // More resident waves beat larger tiles: what limits these kernels is waiting (operand tiles from HBM, weight
-// fragments from L2), which only other waves' MFMAs can fill.  RNB_BWD_TI / RNB_BWD_NW override all three.
-static int bwd_nw(int dflt) {
-  static const char* e = getenv("RNB_BWD_NW");
-  static const int v = e ? atoi(e) : 0;
-  return v == 4 || v == 8 ? v : dflt;
+// fragments from L2), which only other waves' MFMAs can fill.  RNB_VARIANT_BWD_TI / _NW (rnb_model_desc.variant) override all three.
+static int bwd_nw(const Layout& L, int dflt) {
+  const int v = L.knob(RNB_VARIANT_BWD_NW_SHIFT);
+  return v == 1 ? 4 : v == 2 ? 8 : dflt;
 }
 
-static int bwd_ti(int dflt) {
-  static const char* e = getenv("RNB_BWD_TI");
-  static const int v = e ? atoi(e) : 0;
+static int bwd_ti(const Layout& L, int dflt) {
+  const int v = L.knob(RNB_VARIANT_BWD_TI_SHIFT);
   return v == 1 || v == 2 ? v : dflt;
 }
 
@@ -421,9 +419,9 @@ int fused_reverse(const Layout& L, const float* packed, PointBufs& pb, hipStream
   FusedBwdArgs g;
   fill_args(L, packed, pb, g);
   ProfScope prof(hidden_flops(L, pb.M, 0), s);
-  if (bwd_ti(1) == 2 && bwd_nw(8) == 8) hipLaunchKernelGGL((fused_reverse_kernel<2, 8>), dim3((unsigned)(pb.Mp / 64)), dim3(512), 0, s, g);
-  else if (bwd_ti(1) == 2) hipLaunchKernelGGL(fused_reverse_kernel<2>, dim3((unsigned)(pb.Mp / 64)), dim3(256), 0, s, g);
-  else if (bwd_nw(8) == 8) hipLaunchKernelGGL((fused_reverse_kernel<1, 8>), dim3((unsigned)(pb.Mp / 32)), dim3(512), 0, s, g);
+  if (bwd_ti(L, 1) == 2 && bwd_nw(L, 8) == 8) hipLaunchKernelGGL((fused_reverse_kernel<2, 8>), dim3((unsigned)(pb.Mp / 64)), dim3(512), 0, s, g);
+  else if (bwd_ti(L, 1) == 2) hipLaunchKernelGGL(fused_reverse_kernel<2>, dim3((unsigned)(pb.Mp / 64)), dim3(256), 0, s, g);
+  else if (bwd_nw(L, 8) == 8) hipLaunchKernelGGL((fused_reverse_kernel<1, 8>), dim3((unsigned)(pb.Mp / 32)), dim3(512), 0, s, g);
   else hipLaunchKernelGGL(fused_reverse_kernel<1>, dim3((unsigned)(pb.Mp / 32)), dim3(256), 0, s, g);
   RNB_CHECK_LAUNCH();
   return RNB_OK;
@@ -433,9 +431,9 @@ int fused_ra(const Layout& L, const float* packed, PointBufs& pb, hipStream_t s)
   FusedBwdArgs g;
   fill_args(L, packed, pb, g);
   ProfScope prof(hidden_flops(L, pb.M, 0), s);
-  if (bwd_ti(1) == 2 && bwd_nw(8) == 8) hipLaunchKernelGGL((fused_ra_kernel<2, 8>), dim3((unsigned)(pb.Mp / 64)), dim3(512), 0, s, g);
-  else if (bwd_ti(1) == 2) hipLaunchKernelGGL(fused_ra_kernel<2>, dim3((unsigned)(pb.Mp / 64)), dim3(256), 0, s, g);
-  else if (bwd_nw(8) == 8) hipLaunchKernelGGL((fused_ra_kernel<1, 8>), dim3((unsigned)(pb.Mp / 32)), dim3(512), 0, s, g);
+  if (bwd_ti(L, 1) == 2 && bwd_nw(L, 8) == 8) hipLaunchKernelGGL((fused_ra_kernel<2, 8>), dim3((unsigned)(pb.Mp / 64)), dim3(512), 0, s, g);
+  else if (bwd_ti(L, 1) == 2) hipLaunchKernelGGL(fused_ra_kernel<2>, dim3((unsigned)(pb.Mp / 64)), dim3(256), 0, s, g);
+  else if (bwd_nw(L, 8) == 8) hipLaunchKernelGGL((fused_ra_kernel<1, 8>), dim3((unsigned)(pb.Mp / 32)), dim3(512), 0, s, g);
   else hipLaunchKernelGGL(fused_ra_kernel<1>, dim3((unsigned)(pb.Mp / 32)), dim3(256), 0, s, g);
   RNB_CHECK_LAUNCH();
   return RNB_OK;
@@ -447,9 +445,9 @@ int fused_fb(const Layout& L, const float* packed, PointBufs& pb, bool with_colo
   g.fbar = with_color ? pb.cinb : nullptr;
   g.ld_fbar = L.Cinp;
   ProfScope prof(hidden_flops(L, pb.M, 1) + (with_color ? 2.0 * (double)pb.M * L.F * L.H : 0.0), s);
-  if (bwd_ti(1) == 2 && bwd_nw(8) == 8) hipLaunchKernelGGL((fused_fb_kernel<2, 8>), dim3((unsigned)(pb.Mp / 64)), dim3(512), 0, s, g);
-  else if (bwd_ti(1) == 2) hipLaunchKernelGGL(fused_fb_kernel<2>, dim3((unsigned)(pb.Mp / 64)), dim3(256), 0, s, g);
-  else if (bwd_nw(8) == 8) hipLaunchKernelGGL((fused_fb_kernel<1, 8>), dim3((unsigned)(pb.Mp / 32)), dim3(512), 0, s, g);
+  if (bwd_ti(L, 1) == 2 && bwd_nw(L, 8) == 8) hipLaunchKernelGGL((fused_fb_kernel<2, 8>), dim3((unsigned)(pb.Mp / 64)), dim3(512), 0, s, g);
+  else if (bwd_ti(L, 1) == 2) hipLaunchKernelGGL(fused_fb_kernel<2>, dim3((unsigned)(pb.Mp / 64)), dim3(256), 0, s, g);
+  else if (bwd_nw(L, 8) == 8) hipLaunchKernelGGL((fused_fb_kernel<1, 8>), dim3((unsigned)(pb.Mp / 32)), dim3(512), 0, s, g);
   else hipLaunchKernelGGL(fused_fb_kernel<1>, dim3((unsigned)(pb.Mp / 32)), dim3(256), 0, s, g);
   RNB_CHECK_LAUNCH();
   return RNB_OK;

@@ -317,6 +317,10 @@ struct DwJob {
   DwPair p1, p2;
   float* dW;
   float* db;
+  // RNB_VARIANT_DETERMINISTIC: per-split partial tiles [splits][N][lddw] / column sums [splits][N] written with plain
+  // stores (zero-initialised by the caller) and summed in split order by dw_reduce_kernel; nullptr: fp32 atomics
+  float* part;
+  float* partb;
   int npairs, N, K, lddw, bias_pair, splits, rows_per_split, block_end;
 };
 constexpr int kMaxDwJobs = 12;
@@ -384,6 +388,7 @@ __global__ __launch_bounds__(256, 3) void gemm_dw_kernel(const DwGroup g) {
   }
   // atomics: each register of a 32x32 accumulator is two 128-byte row segments per wave instruction
   const int lddw = J.lddw;
+  float* __restrict__ pdst = J.part ? J.part + (size_t)split * N * lddw : nullptr;
 #pragma unroll
   for (int tj = 0; tj < TN; ++tj) {
     if (!((mask >> tj) & 1u)) continue;
@@ -393,11 +398,17 @@ __global__ __launch_bounds__(256, 3) void gemm_dw_kernel(const DwGroup g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = n_blk + wm * 64 + acc_row(ti, r, lane);
-        if (row < N) atomicAdd(dW + (size_t)row * lddw + col, acc[ti][tj][r]);
+        if (row < N) {
+          if (pdst) pdst[(size_t)row * lddw + col] = acc[ti][tj][r];
+          else atomicAdd(dW + (size_t)row * lddw + col, acc[ti][tj][r]);
+        }
       }
     }
   }
-  if (bias_blk) atomicAdd(db + n_blk + tid, (float)bsum);
+  if (bias_blk) {
+    if (J.partb) J.partb[(size_t)split * N + n_blk + tid] = (float)bsum;
+    else atomicAdd(db + n_blk + tid, (float)bsum);
+  }
 }
 
 // ---- dW without LDS ----------------------------------------------------------------------------------
@@ -506,6 +517,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_dw_direct_kernel(const DwGroup 
   // rho = (r & 3) + 8 * (r >> 2) + 4 * h
   float* __restrict__ dW = J.dW;
   const int lddw = J.lddw;
+  float* __restrict__ pdst = J.part ? J.part + (size_t)split * N * lddw : nullptr;
 #pragma unroll
   for (int tj = 0; tj < TN; ++tj) {
     const int col = k_w + tj * 32 + i;
@@ -514,7 +526,8 @@ __global__ __launch_bounds__(256, OCC) void gemm_dw_direct_kernel(const DwGroup 
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = n_w + 2 * ((r & 3) + 8 * (r >> 2) + 4 * h) + ti;
-        atomicAdd(dW + (size_t)row * lddw + col, acc[ti][tj][r]);
+        if (pdst) pdst[(size_t)row * lddw + col] = acc[ti][tj][r];
+        else atomicAdd(dW + (size_t)row * lddw + col, acc[ti][tj][r]);
       }
     }
   }
@@ -522,8 +535,33 @@ __global__ __launch_bounds__(256, OCC) void gemm_dw_direct_kernel(const DwGroup 
     bs0 += __shfl_xor(bs0, 32, 64);
     bs1 += __shfl_xor(bs1, 32, 64);
     if (h == 0) {
-      atomicAdd(J.db + n_w + 2 * i, (float)bs0);
-      atomicAdd(J.db + n_w + 2 * i + 1, (float)bs1);
+      if (J.partb) {
+        J.partb[(size_t)split * N + n_w + 2 * i] = (float)bs0;
+        J.partb[(size_t)split * N + n_w + 2 * i + 1] = (float)bs1;
+      } else {
+        atomicAdd(J.db + n_w + 2 * i, (float)bs0);
+        atomicAdd(J.db + n_w + 2 * i + 1, (float)bs1);
+      }
+    }
+  }
+}
+
+// RNB_VARIANT_DETERMINISTIC: dW = sum over splits (in split order, fp64 running sum) of the partial tiles; grid =
+// (blocks over N * lddw elements, job).
+template <int DUMMY>
+__global__ __launch_bounds__(256) void dw_reduce_kernel(const DwGroup g) {
+  const DwJob& J = g.job[blockIdx.y];
+  const size_t n = (size_t)J.N * J.lddw;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (size_t)gridDim.x * 256) {
+    double s = 0.0;
+    for (int sp = 0; sp < J.splits; ++sp) s += (double)J.part[(size_t)sp * n + idx];
+    J.dW[idx] = (float)s;
+  }
+  if (J.db != nullptr && J.partb != nullptr) {
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < J.N; r += gridDim.x * 256) {
+      double s = 0.0;
+      for (int sp = 0; sp < J.splits; ++sp) s += (double)J.partb[(size_t)sp * J.N + r];
+      J.db[r] = (float)s;
     }
   }
 }

@@ -43,6 +43,8 @@ int make_layout(const rnb_model_desc* d, Layout* L) {
   if (d->sdf_d_hidden < 1 || d->sdf_d_out < 1) RNB_FAIL(RNB_E_INVALID, "bad sdf widths");
   if (d->sdf_multires < 0 || d->sdf_multires > 16) RNB_FAIL(RNB_E_INVALID, "bad sdf_multires");
   if (!(d->sdf_scale > 0.f)) RNB_FAIL(RNB_E_INVALID, "sdf_scale must be positive");
+  L->variant = d->variant;
+  if (d->variant & ~0xFF0F) RNB_FAIL(RNB_E_INVALID, "unknown bits in rnb_model_desc.variant (0x%x)", d->variant);
   L->nh = d->sdf_n_layers;
   L->multires = d->sdf_multires;
   L->pe = 3 * (1 + 2 * d->sdf_multires);
@@ -137,6 +139,10 @@ void carve_points(const Layout& L, Carver& c, int64_t M, int mode, PointBufs* pb
     if (mode & PM_WITH_COLOR) {
       for (int l = 0; l < L.nc; ++l) pb->zc[l] = c.take<float>(Mp * L.Hcp);
       pb->cinb = c.take<float>(Mp * L.Cinp);
+    }
+    if (L.variant & RNB_VARIANT_DETERMINISTIC) {
+      pb->dw_part_floats = dw_partial_floats(L, M, (mode & PM_WITH_COLOR) != 0);
+      pb->dw_part = c.take<float>(pb->dw_part_floats);
     }
   }
 }

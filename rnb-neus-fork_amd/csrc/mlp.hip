@@ -345,6 +345,24 @@ __global__ __launch_bounds__(512) void sdf_head_bwd_kernel(const float* __restri
   }
 }
 
+// points [first, first + n) of the regular grid of extract_fields (generic path of rnb_sdf_grid)
+__global__ void grid_points_kernel(GridGen g, int64_t first, int64_t n, float* __restrict__ pts) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int64_t r = first + i;
+  const int iz = (int)(r % g.res);
+  r /= g.res;
+  const int iy = (int)(r % g.res);
+  const int ix = (int)(r / g.res) + g.x_begin;
+  pts[i * 3] = linspace_at(g.bmin[0], g.bmax[0], g.res, ix);
+  pts[i * 3 + 1] = linspace_at(g.bmin[1], g.bmax[1], g.res, iy);
+  pts[i * 3 + 2] = linspace_at(g.bmin[2], g.bmax[2], g.res, iz);
+}
+__global__ void scale_copy_kernel(const float* __restrict__ src, float scale, int64_t n, float* __restrict__ dst) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i] * scale;
+}
+
 // strided [rows, ld] (first ncols columns) -> dense [M, ncols]
 __global__ void copy_cols_kernel(const float* __restrict__ src, int ld, int ncols, int64_t M, float* __restrict__ out) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -575,12 +593,38 @@ static int launch_rows(const float* A, int lda, const float* W, int ldw, int64_t
 // Collects the dW jobs of one backward pass and launches them as (at most) three grouped GEMMs, one per kernel
 // variant (K-tile 128 exact / K-tile 64 exact / K-tile 64 guarded).  Every job reads buffers that stay untouched until the end of sweep_backward, so deferring the
 // launch is safe.
+// split-K plan of one dW job: kernel variant v ([0] K % 128 == 0, [1] K % 64 == 0, [2] anything: guarded), number of
+// point splits and points per split.  Shared by DwBatch::add and by the sizing of the deterministic partial slabs.
+static void dw_plan(int64_t M, int N, int K, int* v_out, int* splits_out, int* rows_out) {
+  const bool exact = N % 128 == 0 && M % BK == 0;
+  const int v = (exact && K % 128 == 0) ? 0 : (exact && K % 64 == 0) ? 1 : 2;
+  const int kt = v == 0 ? 128 : 64;                  // tile width along K of the variant (see kernel)
+  const int min_rows = v == 0 ? 1024 : 512;          // points per block (half-size tiles: half the rows)
+  const int tiles = ((N + 127) / 128) * ((K + kt - 1) / kt);
+  int splits = (int)((M + min_rows - 1) / min_rows);
+  const int max_splits = (1024 + tiles - 1) / tiles;  // ~1024 blocks per job
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  if (splits >= 8) splits = splits / 8 * 8;   // multiple of 8: enables the XCD-aware placement in the kernel
+  int rows = (int)((M + splits - 1) / splits);
+  rows = (rows + BK - 1) / BK * BK;
+  // (the kernel tolerates empty splits, so the job keeps the multiple-of-8 split count)
+  if ((int64_t)rows * splits < M) splits = (int)((M + rows - 1) / rows);
+  *v_out = v;
+  *splits_out = splits;
+  *rows_out = rows;
+}
+
 struct DwBatch {
   DwGroup grp[3];     // [0] K % 128 == 0, [1] K % 64 == 0, [2] anything (guarded)
   double flops[3];
   int64_t M;
   hipStream_t s;
-  DwBatch(int64_t M_, hipStream_t s_) : M(M_), s(s_) {
+  bool lds_path;      // RNB_VARIANT_DW_LDS: staged-through-LDS kernels (A/B switch)
+  float* part;        // RNB_VARIANT_DETERMINISTIC: bump allocator over the zeroed partial-slab workspace (or nullptr)
+  int64_t part_left;
+  DwBatch(int64_t M_, hipStream_t s_, bool lds_path_, float* part_, int64_t part_floats)
+      : M(M_), s(s_), lds_path(lds_path_), part(part_), part_left(part_floats) {
     for (int v = 0; v < 3; ++v) { grp[v].njobs = 0; grp[v].M = (int)M_; flops[v] = 0.0; }
   }
   int flush(int v) {
@@ -607,12 +651,15 @@ struct DwBatch {
     const dim3 grid((unsigned)g.job[g.njobs - 1].block_end);
     {
       ProfScope prof(flops[v], s);
-      static const bool lds_path = getenv("RNB_DW_LDS") != nullptr;   // A/B switch: staged-through-LDS kernels
       if (v == 0 && !lds_path) hipLaunchKernelGGL((gemm_dw_direct_kernel<128, 3>), grid, dim3(256), 0, s, g);
       else if (v == 1 && !lds_path) hipLaunchKernelGGL((gemm_dw_direct_kernel<64, 3>), grid, dim3(256), 0, s, g);
       else if (v == 0) hipLaunchKernelGGL((gemm_dw_kernel<false, 128>), grid, dim3(256), 0, s, g);
       else if (v == 1) hipLaunchKernelGGL((gemm_dw_kernel<false, 64>), grid, dim3(256), 0, s, g);
       else hipLaunchKernelGGL((gemm_dw_kernel<true, 64>), grid, dim3(256), 0, s, g);
+      if (part != nullptr) {   // ordered reduction of the partial slabs
+        RNB_CHECK_LAUNCH();
+        hipLaunchKernelGGL(dw_reduce_kernel<0>, dim3(64, g.njobs), dim3(256), 0, s, g);
+      }
     }
     g.njobs = 0;
     flops[v] = 0.0;
@@ -620,24 +667,24 @@ struct DwBatch {
     return RNB_OK;
   }
   int add(DwPair p1, DwPair p2, int npairs, int N, int K, float* dW, int lddw, float* db, int bias_pair, double fl) {
-    const bool exact = N % 128 == 0 && M % BK == 0;
-    const int v = (exact && K % 128 == 0) ? 0 : (exact && K % 64 == 0) ? 1 : 2;
+    int v, splits, rows;
+    dw_plan(M, N, K, &v, &splits, &rows);
     if (grp[v].njobs == kMaxDwJobs) RNB_TRY(flush(v));
-    const int kt = v == 0 ? 128 : 64;                  // tile width along K of the variant (see kernel)
-    const int min_rows = v == 0 ? 1024 : 512;          // points per block (half-size tiles: half the rows)
+    const int kt = v == 0 ? 128 : 64;
     const int tiles = ((N + 127) / 128) * ((K + kt - 1) / kt);
-    int splits = (int)((M + min_rows - 1) / min_rows);
-    const int max_splits = (1024 + tiles - 1) / tiles;  // ~1024 blocks per job
-    if (splits > max_splits) splits = max_splits;
-    if (splits < 1) splits = 1;
-    if (splits >= 8) splits = splits / 8 * 8;   // multiple of 8: enables the XCD-aware placement in the kernel
-    int rows = (int)((M + splits - 1) / splits);
-    rows = (rows + BK - 1) / BK * BK;
-    // (the kernel tolerates empty splits, so the job keeps the multiple-of-8 split count)
-    if ((int64_t)rows * splits < M) splits = (int)((M + rows - 1) / rows);
     DwGroup& g = grp[v];
     DwJob& j = g.job[g.njobs];
     j.p1 = p1; j.p2 = p2; j.dW = dW; j.db = db;
+    j.part = nullptr;
+    j.partb = nullptr;
+    if (part != nullptr) {
+      const int64_t need = (int64_t)splits * N * lddw + (int64_t)splits * N;
+      if (need > part_left) RNB_FAIL(RNB_E_WORKSPACE, "deterministic dW: partial-slab workspace exhausted");
+      j.part = part;
+      j.partb = part + (int64_t)splits * N * lddw;
+      part += need;
+      part_left -= need;
+    }
     j.npairs = npairs; j.N = N; j.K = K; j.lddw = lddw; j.bias_pair = bias_pair;
     j.splits = splits; j.rows_per_split = rows;
     // jobs start on a multiple of 8 blocks so that (block & 7) is the XCD inside every job
@@ -654,8 +701,35 @@ struct DwBatch {
   }
 };
 
+// floats of partial-slab workspace the deterministic variant needs for one backward over M points: the same job list
+// as sweep_backward
+int64_t dw_partial_floats(const Layout& L, int64_t M, bool with_color) {
+  int64_t total = 0;
+  auto job = [&](int N, int K) {
+    int v, splits, rows;
+    dw_plan(M, N, K, &v, &splits, &rows);
+    total += (int64_t)splits * N * K + (int64_t)splits * N;
+  };
+  if (with_color) {
+    for (int l = 0; l < L.nc; ++l) job(L.col[l].Np, L.col[l].Kp);
+    job(L.feat.Np, L.feat.Kp);
+  }
+  for (int l = 0; l < L.nh; ++l) job(L.hid[l].Np, L.hid[l].Kp);
+  return total;
+}
+
 static inline unsigned blocks_for(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
 
+int launch_grid_points(const GridGen& g, int64_t first, int64_t n, float* pts, hipStream_t s) {
+  hipLaunchKernelGGL(grid_points_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, g, first, n, pts);
+  RNB_CHECK_LAUNCH();
+  return RNB_OK;
+}
+int launch_scale_copy(const float* src, float scale, int64_t n, float* dst, hipStream_t s) {
+  hipLaunchKernelGGL(scale_copy_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, src, scale, n, dst);
+  RNB_CHECK_LAUNCH();
+  return RNB_OK;
+}
 int launch_copy_cols(const float* src, int ld, int ncols, int64_t M, float* out, hipStream_t s) {
   hipLaunchKernelGGL(copy_cols_kernel, dim3(blocks_for(M * ncols, 256)), dim3(256), 0, s, src, ld, ncols, M, out);
   RNB_CHECK_LAUNCH();
@@ -744,11 +818,16 @@ int sweep_color(const Layout& L, const float* packed, PointBufs& pb, const float
 int sweep_backward(const Layout& L, const float* packed, PointBufs& pb, bool with_color, float* packed_grad,
                    bool fused, hipStream_t s) {
   const int64_t M = pb.M, Mp = pb.Mp;
-  DwBatch dw(M, s);
+  const bool det = (L.variant & RNB_VARIANT_DETERMINISTIC) != 0;
+  if (det) {
+    if (pb.dw_part == nullptr) RNB_FAIL(RNB_E_WORKSPACE, "deterministic variant: no partial-slab workspace was carved");
+    RNB_CHECK_HIP(hipMemsetAsync(pb.dw_part, 0, (size_t)pb.dw_part_floats * sizeof(float), s));
+  }
+  DwBatch dw(M, s, (L.variant & RNB_VARIANT_DW_LDS) != 0, det ? pb.dw_part : nullptr, det ? pb.dw_part_floats : 0);
   // ---- C': albedo network backward ---------------------------------------------------------------
   if (with_color) {
     const int chunks = L.Hcp / 32;   // 32-column chunks x row slabs, ~256 workgroups, slabs a multiple of 64 rows
-    int64_t slabs = (256 + chunks - 1) / chunks;
+    int64_t slabs = det ? 1 : (256 + chunks - 1) / chunks;   // deterministic: ONE slab, i.e. one add per address onto zero
     int rows_per_blk = (int)((M + slabs - 1) / slabs);
     rows_per_blk = (rows_per_blk + 63) / 64 * 64;
     hipLaunchKernelGGL(color_out_bwd_kernel, dim3(blocks_for(M, rows_per_blk), chunks), dim3(512), 0, s, pb.albbar, pb.alb,
@@ -795,7 +874,7 @@ int sweep_backward(const Layout& L, const float* packed, PointBufs& pb, bool wit
   {
     // Hp / 32 column chunks x row slabs, ~256 workgroups in total, slabs a multiple of the 64 row phases
     const int chunks = L.Hp / 32;
-    int64_t slabs = (256 + chunks - 1) / chunks;
+    int64_t slabs = det ? 1 : (256 + chunks - 1) / chunks;
     int rows_per_blk = (int)((M + slabs - 1) / slabs);
     rows_per_blk = (rows_per_blk + 63) / 64 * 64;
     hipLaunchKernelGGL(sdf_head_bwd_kernel, dim3(blocks_for(M, rows_per_blk), chunks), dim3(512), 0, s, pb.a[L.nh - 1],

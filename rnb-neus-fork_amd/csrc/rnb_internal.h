@@ -68,9 +68,30 @@ struct Layout {
   int multires_view;
   int squeeze;
   int64_t total;          // floats in the packed buffer
+  int variant;            // rnb_model_desc.variant (RNB_VARIANT_* bits)
+  int knob(int shift) const { return (variant >> shift) & 3; }
 };
 
 int make_layout(const rnb_model_desc* d, Layout* L);
+
+#if defined(__HIPCC__)
+// torch.linspace(start, end, steps)[i] as ATen's CPU kernel computes it: step = (end-start)/(steps-1); first half
+// start + step*i, second half end - step*(steps-1-i), each as one fused multiply-add (explicit fmaf: independent of
+// the translation unit's contraction mode).
+__device__ inline float linspace_at(float start, float end, int steps, int i) {
+  if (steps == 1) return start;
+  const float step = (end - start) / (float)(steps - 1);
+  return i < steps / 2 ? fmaf(step, (float)i, start) : fmaf(-step, (float)(steps - 1 - i), end);
+}
+#endif
+
+// regular grid of extract_fields, generated inside the forward kernel (rnb_sdf_grid)
+struct GridGen {
+  int on;
+  int res, x_begin;
+  float bmin[3], bmax[3];
+  float out_scale;
+};
 
 // ---- workspace carving ------------------------------------------------------------------------
 struct Carver {
@@ -114,6 +135,8 @@ struct PointBufs {
   float* sbar;    // [Mp]
   float* nbar;    // [Mp,4]
   float* albbar;  // [Mp,4]
+  float* dw_part;           // RNB_VARIANT_DETERMINISTIC: partial slabs of the split-K weight-gradient GEMMs
+  int64_t dw_part_floats;
 };
 
 enum PointMode { PM_SDF_ONLY = 0, PM_WITH_NORMAL = 1, PM_WITH_COLOR = 2, PM_WITH_BACKWARD = 4 };
@@ -128,6 +151,7 @@ int sweep_color(const Layout& L, const float* packed, PointBufs& pb, const float
                 hipStream_t s);
 int launch_copy_cols(const float* src, int ld, int ncols, int64_t M, float* out, hipStream_t s);
 int launch_fill_cols(const float* src, int ncols, int64_t M, int64_t Mp, int ld, float* dst, hipStream_t s);
+int64_t dw_partial_floats(const Layout& L, int64_t M, bool with_color);
 int sweep_backward(const Layout& L, const float* packed, PointBufs& pb, bool with_color, float* packed_grad,
                    bool fused, hipStream_t s);
 int fused_reverse(const Layout& L, const float* packed, PointBufs& pb, hipStream_t s);
@@ -137,7 +161,9 @@ int fused_fb(const Layout& L, const float* packed, PointBufs& pb, bool with_colo
 // ---- fused sweeps for hidden width 256 (fused.hip) ---------------------------------------------------
 bool fused_supported(const Layout& L);
 int fused_forward(const Layout& L, const float* packed, const float* pts, int64_t M, PointBufs& pb, bool save,
-                  bool need_feat, bool need_gz_last, hipStream_t s);
+                  bool need_feat, bool need_gz_last, hipStream_t s, const GridGen* grid = nullptr);
+int launch_grid_points(const GridGen& g, int64_t first, int64_t n, float* pts, hipStream_t s);
+int launch_scale_copy(const float* src, float scale, int64_t n, float* dst, hipStream_t s);
 
 // ---- sampling / composite ------------------------------------------------------------------------
 int launch_up_sample_step(const float* rays_o, const float* rays_d, const float* z_in, const float* sdf_old,
@@ -187,6 +213,7 @@ struct CompBwdArgs {
   const float* g_s_val;
   const float* g_gerr;
   const float* gerr_den;     // [1]
+  const float* gerr_den_global;   // [1] or nullptr: denominator of the whole data-parallel batch
   float* sbar;               // [Mp]
   float* nbar;               // [Mp,4]
   float* albbar;             // [Mp,4]
@@ -195,7 +222,7 @@ struct CompBwdArgs {
 
 int launch_fine_points(const float* rays_o, const float* rays_d, const float* z, int64_t B, int S, float sample_dist,
                        float* pts, float* dists, hipStream_t s);
-int launch_composite_fwd(const CompArgs& a, float* gerr, float* gerr_den, hipStream_t s);
+int launch_composite_fwd(const CompArgs& a, float* gerr, float* gerr_den, float* gerr_partial, hipStream_t s);
 int launch_composite_bwd(const CompBwdArgs& g, float* dvar, hipStream_t s);
 
 // ---- sampling (sampling.hip) ---------------------------------------------------------------------

@@ -17,13 +17,6 @@ namespace rnb {
 constexpr int kMaxZ = 512;    // n + n_new upper bound
 constexpr int kMaxNew = 64;
 
-__device__ inline float linspace_at(float start, float end, int steps, int i) {
-  // ATen's CPU linspace: step = (end-start)/(steps-1); first half start + step*i, second half
-  // end - step*(steps-1-i), each as one fused multiply-add.
-  if (steps == 1) return start;
-  const float step = (end - start) / (float)(steps - 1);
-  return i < steps / 2 ? fmaf(step, (float)i, start) : fmaf(-step, (float)(steps - 1 - i), end);
-}
 
 __device__ inline float sigmoidf_ref(float x) { return 1.0f / (1.0f + expf(-x)); }
 

@@ -7,7 +7,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librnbneus_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_LIN = 16
 
 MODE_CORE = 0
@@ -16,6 +16,13 @@ FLAG_RELU_SHADING = 2
 FLAG_NO_ALBEDO = 4
 FLAG_LIGHT_PER_RAY = 8
 FLAG_FORWARD_ONLY = 16
+
+# rnb_model_desc.variant bits (include/rnbneus.h)
+VARIANT_BF16 = 1
+VARIANT_DETERMINISTIC = 2
+VARIANT_GENERIC = 4
+VARIANT_DW_LDS = 8
+VARIANT_BWD_TI_SHIFT, VARIANT_BWD_NW_SHIFT, VARIANT_FWD_TI_SHIFT, VARIANT_FWD_NW_SHIFT = 8, 10, 12, 14
 
 c_float_p = C.c_void_p  # device pointers are passed as integers
 
@@ -29,7 +36,7 @@ class ModelDesc(C.Structure):
         ("col_d_hidden", C.c_int32), ("col_n_layers", C.c_int32), ("col_multires_view", C.c_int32),
         ("col_squeeze_out", C.c_int32), ("col_weight_norm", C.c_int32),
         ("n_samples", C.c_int32), ("n_importance", C.c_int32), ("up_sample_steps", C.c_int32),
-        ("reserved", C.c_int32),
+        ("variant", C.c_int32),
     ]
 
 
@@ -51,7 +58,13 @@ class RenderArgs(C.Structure):
         ("gradients", C.c_void_p), ("inside_sphere", C.c_void_p), ("weight_sum", C.c_void_p),
         ("weight_max", C.c_void_p), ("s_val", C.c_void_p), ("gradient_error", C.c_void_p),
         ("sdf", C.c_void_p), ("sampled_albedo", C.c_void_p),
+        ("gerr_partial", C.c_void_p), ("gerr_den_global", C.c_void_p),
     ]
+
+
+class GridDesc(C.Structure):
+    _fields_ = [("bound_min", C.c_float * 3), ("bound_max", C.c_float * 3), ("resolution", C.c_int32),
+                ("x_begin", C.c_int32), ("x_end", C.c_int32), ("out_scale", C.c_float)]
 
 
 class RenderGrads(C.Structure):
@@ -75,6 +88,9 @@ _SIGNATURES = {
                                    C.c_void_p, C.c_size_t, C.c_void_p]),
     "rnb_color_forward": (C.c_int, [_P(ModelDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                     C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rnb_sdf_grid_workspace_bytes": (C.c_int, [_P(ModelDesc), _P(GridDesc), _P(C.c_int64)]),
+    "rnb_sdf_grid": (C.c_int, [_P(ModelDesc), C.c_void_p, _P(GridDesc), C.c_void_p, C.c_void_p, C.c_size_t,
+                               C.c_void_p]),
     "rnb_up_sample_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
                                      C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p]),
@@ -95,6 +111,9 @@ _SIGNATURES = {
     "rnb_loss_rnb": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64,
                                C.c_int32, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                C.c_void_p, C.c_void_p]),
+    "rnb_loss_rnb_shard": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64,
+                                     C.c_int32, C.c_float, C.c_float, C.c_void_p, C.c_int64, C.c_float, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rnb_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double,
                                 C.c_double, C.c_double, C.c_double, C.c_int64, C.c_void_p]),
     "rnb_profile_enable": (C.c_int, [C.c_int]),
@@ -138,6 +157,55 @@ def check(rc: int):
     if rc != 0:
         msg = load().rnb_last_error_string()
         raise NativeError(f"librnbneus_hip error {rc}: {msg.decode() if msg else '?'}")
+
+
+def variant_bits(bf16=False, deterministic=False, generic=False, dw_lds=False, bwd_ti=0, bwd_nw=0, fwd_ti=0,
+                 fwd_nw=0) -> int:
+    """rnb_model_desc.variant from keyword switches (tile heights: 0/1/2; waves: 0/4/8)."""
+    nw = {0: 0, 4: 1, 8: 2}
+    return ((VARIANT_BF16 if bf16 else 0) | (VARIANT_DETERMINISTIC if deterministic else 0)
+            | (VARIANT_GENERIC if generic else 0) | (VARIANT_DW_LDS if dw_lds else 0)
+            | (int(bwd_ti) << VARIANT_BWD_TI_SHIFT) | (nw[int(bwd_nw)] << VARIANT_BWD_NW_SHIFT)
+            | (int(fwd_ti) << VARIANT_FWD_TI_SHIFT) | (nw[int(fwd_nw)] << VARIANT_FWD_NW_SHIFT))
+
+
+class on_device:
+    """Context for one native call: makes the tensors' device the current HIP device (the library launches on
+    the stream it is given and never calls hipSetDevice) and yields that device's current torch stream as the
+    `rnb_stream_t` argument.  Without it a model on cuda:k with another current device would have its kernels
+    enqueued on the wrong device's stream."""
+
+    def __init__(self, device):
+        import torch
+        if isinstance(device, torch.Tensor):
+            device = device.device
+        if device.type != "cuda":
+            raise RuntimeError("librnbneus_hip.so works on GPU tensors only (there is no CPU path)")
+        self._torch = torch
+        self.device = device
+        self._ctx = torch.cuda.device(device)
+
+    def __enter__(self):
+        self._ctx.__enter__()
+        return C.c_void_p(self._torch.cuda.current_stream(self.device).cuda_stream)
+
+    def __exit__(self, *exc):
+        return self._ctx.__exit__(*exc)
+
+
+def same_device(*tensors):
+    """Raises unless every given tensor (None skipped) lives on one GPU; returns that device."""
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("librnbneus_hip.so works on GPU tensors only (there is no CPU path)")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError(f"tensors of one native call live on different devices ({dev} and {t.device})")
+    return dev
 
 
 def ptr(t):

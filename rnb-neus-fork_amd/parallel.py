@@ -39,6 +39,23 @@ def allreduce_mean_(flat: torch.Tensor, group=None):
     return flat
 
 
+def allreduce_sum_(flat: torch.Tensor, group=None):
+    """In-place sum over ranks (the exact large-batch gradient when every rank's loss is its additive share)."""
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    return flat
+
+
+def global_mask_count(mask: torch.Tensor, use_mask: bool, group=None) -> torch.Tensor:
+    """[sum(mask > 0.5), rays] of the WHOLE data-parallel batch as a 2-float tensor on the mask's device: the
+    normalisers of the colour term (exp_runner.py:194, mask_sum) and of the BCE mean (exp_runner.py:251).  With
+    `use_mask` False (mask_weight == 0, exp_runner.py:233-236) every ray counts.  One tiny all-reduce."""
+    mk = mask.reshape(-1)
+    n = torch.tensor(float(mk.numel()), device=mk.device)
+    cnt = torch.stack([(mk > 0.5).sum().to(torch.float32) if use_mask else n, n])
+    dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=group)
+    return cnt
+
+
 def broadcast_parameters(modules, src=0, group=None):
     for m in modules:
         for p in m.parameters():

@@ -18,10 +18,6 @@ import torch
 from . import native
 
 
-def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
-
-
 class DeviceRays:
     def __init__(self, images, images_warmup, masks, light_directions, light_directions_warmup, intrinsics_all_inv,
                  pose_all, device):
@@ -91,14 +87,15 @@ class DeviceRays:
             raise ValueError("DeviceRays was built without images_warmup")
         if want_lights and self.light_directions is None:
             raise ValueError("DeviceRays was built without light_directions")
-        native.check(native.load().rnb_gen_rays_at_view(
-            native.ptr(self.intrinsics_all_inv[v]), native.ptr(self.pose_all[v]),
-            native.ptr(self.images[v]) if want_rgb else None,
-            native.ptr(self.images_warmup[v]) if want_warmup else None,
-            native.ptr(self.masks[v]), self.masks.shape[-1],
-            native.ptr(self.light_directions[v]) if want_lights else None,
-            native.ptr(pixels_x), native.ptr(pixels_y), B, L, self.H, self.W, native.ptr(data), native.ptr(rgb),
-            native.ptr(rgb_wu), native.ptr(lights), native.ptr(near), native.ptr(far), _stream()))
+        with native.on_device(data) as stream:
+            native.check(native.load().rnb_gen_rays_at_view(
+                native.ptr(self.intrinsics_all_inv[v]), native.ptr(self.pose_all[v]),
+                native.ptr(self.images[v]) if want_rgb else None,
+                native.ptr(self.images_warmup[v]) if want_warmup else None,
+                native.ptr(self.masks[v]), self.masks.shape[-1],
+                native.ptr(self.light_directions[v]) if want_lights else None,
+                native.ptr(pixels_x), native.ptr(pixels_y), B, L, self.H, self.W, native.ptr(data), native.ptr(rgb),
+                native.ptr(rgb_wu), native.ptr(lights), native.ptr(near), native.ptr(far), stream))
         return data, rgb, rgb_wu, lights, near, far
 
     # ------------------------------------------------------------------ the reference's Dataset methods

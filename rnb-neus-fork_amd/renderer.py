@@ -11,7 +11,13 @@ Differences that are deliberate and documented in DESIGN.md:
   * the [B,1] perturbation draw (renderer.py:572) is made here with torch.rand on the rays' device and
     may be supplied explicitly (`t_rand=`) so that tests can feed the oracle the same randomness.
   * with data parallelism enabled (`set_data_parallel`) the backward all-reduces the flat gradient
-    buffer over RCCL before returning (mean over ranks).
+    buffer over RCCL before returning.  Default `exact=True`: the ranks hold contiguous shards of ONE global
+    batch; the eikonal term's two batch-global sums (models/renderer.py:538-540) are all-reduced in the
+    forward, `rnb_loss(..., group=)` does the same for `mask_sum` / the BCE mean, and the gradient
+    all-reduce is a SUM, so a G-rank step equals the single-process step on the whole batch.  `exact=False`
+    is the DDP convention (per-rank normalisers, mean of the per-rank gradients).
+  * kernel / arithmetic variants (`set_variant`): explicit bits of the model descriptor, no environment
+    variables (bf16 sweeps for BASELINE config 5, deterministic reductions, A/B tuning knobs).
 """
 from __future__ import annotations
 
@@ -23,14 +29,10 @@ import torch.distributed as dist
 
 from . import native, runtime
 from .fields import _mlp_struct, model_desc
-from .parallel import allreduce_mean_
+from .parallel import allreduce_mean_, allreduce_sum_
 
 _OUT_KEYS = ("color_fine", "s_val", "cdf_fine", "weight_sum", "weight_max", "gradients", "weights",
              "gradient_error", "inside_sphere")
-
-
-def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
 class _FinePass(torch.autograd.Function):
@@ -82,8 +84,20 @@ class _FinePass(torch.autograd.Function):
             setattr(args, k, out[k].data_ptr())
         args.sdf = extras["sdf"].data_ptr() if "sdf" in extras else None
         args.sampled_albedo = extras["sampled_albedo"].data_ptr() if "sampled_albedo" in extras else None
-        native.check(lib.rnb_render_fwd(C.byref(desc), native.ptr(call["packed"]), C.byref(args), native.ptr(ws),
-                                        ws.numel(), _stream()))
+        exact_dp = renderer.dp_group is not None and renderer.dp_exact
+        if exact_dp:
+            keep["gerr_partial"] = torch.empty(2, **f32)
+            args.gerr_partial = keep["gerr_partial"].data_ptr()
+        with native.on_device(dev) as stream:
+            native.check(lib.rnb_render_fwd(C.byref(desc), native.ptr(call["packed"]), C.byref(args), native.ptr(ws),
+                                            ws.numel(), stream))
+        if exact_dp:
+            # eikonal term of the WHOLE batch (renderer.py:538-540): all-reduce this shard's (numerator, count)
+            part = keep["gerr_partial"]
+            dist.all_reduce(part, op=dist.ReduceOp.SUM, group=renderer.dp_group)
+            keep["gerr_den_global"] = (part[1:2] + 1e-5).contiguous()
+            out["gradient_error"].copy_((part[0:1] / keep["gerr_den_global"]).reshape(()))
+            args.gerr_den_global = keep["gerr_den_global"].data_ptr()
         ctx.renderer, ctx.call, ctx.args, ctx.keep, ctx.ws, ctx.out = renderer, call, args, keep, ws, out
         ctx.n_leaves = len(leaves)
         ctx.mark_non_differentiable(out["inside_sphere"])
@@ -97,6 +111,10 @@ class _FinePass(torch.autograd.Function):
     def backward(ctx, *gouts):
         lib = native.load()
         renderer, call, desc = ctx.renderer, ctx.call, ctx.renderer.desc
+        if ctx.ws is None:
+            raise RuntimeError("NeuSRenderer: backward called a second time on the same render (the saved per-point "
+                               "state is released after the first backward, retain_graph is not supported); re-run "
+                               "the forward")
         dev = ctx.ws.device
         g = dict(zip(_OUT_KEYS, gouts))
         keepalive = []
@@ -116,21 +134,27 @@ class _FinePass(torch.autograd.Function):
         packed_grad = torch.empty_like(call["packed"])
         flat, views, order = renderer._alloc_flat_grads(call["train_color"], dev)
         dvar = views[id(renderer.deviation_network.variance)]
-        native.check(lib.rnb_render_bwd(C.byref(desc), native.ptr(call["packed"]), C.byref(ctx.args), C.byref(rg),
-                                        native.ptr(packed_grad), C.c_void_p(dvar.data_ptr()), native.ptr(ctx.ws),
-                                        ctx.ws.numel(), _stream()))
+        with native.on_device(dev) as stream:
+            native.check(lib.rnb_render_bwd(C.byref(desc), native.ptr(call["packed"]), C.byref(ctx.args), C.byref(rg),
+                                            native.ptr(packed_grad), C.c_void_p(dvar.data_ptr()), native.ptr(ctx.ws),
+                                            ctx.ws.numel(), stream))
         sdf_net, col_net = renderer.sdf_network, renderer.color_network
         sp = _mlp_struct(sdf_net.lins(), sdf_net.weight_norm)
         sg = _mlp_struct(sdf_net.lins(), sdf_net.weight_norm, grads=views)
         use_col = call["train_color"]
         cp = _mlp_struct(col_net.lins(), col_net.weight_norm) if use_col else None
         cg = _mlp_struct(col_net.lins(), col_net.weight_norm, grads=views) if use_col else None
-        native.check(lib.rnb_weightnorm_bwd(C.byref(desc), C.byref(sp), C.byref(cp) if cp is not None else None,
-                                            native.ptr(packed_grad), C.byref(sg),
-                                            C.byref(cg) if cg is not None else None, _stream()))
+        with native.on_device(dev) as stream:
+            native.check(lib.rnb_weightnorm_bwd(C.byref(desc), C.byref(sp), C.byref(cp) if cp is not None else None,
+                                                native.ptr(packed_grad), C.byref(sg),
+                                                C.byref(cg) if cg is not None else None, stream))
         if renderer.dp_group is not None:
-            # the one exchange step of the path: sum of the flat gradient buffer over xGMI (RCCL)
-            allreduce_mean_(flat, renderer.dp_group)
+            # the one exchange step of the path: the flat gradient buffer over xGMI (RCCL).  exact: the per-rank
+            # losses are additive shares of the whole batch's loss -> SUM; otherwise the DDP mean.
+            if renderer.dp_exact:
+                allreduce_sum_(flat, renderer.dp_group)
+            else:
+                allreduce_mean_(flat, renderer.dp_group)
         ctx.ws = None
         grads = []
         for leaf in call["leaves"]:
@@ -159,14 +183,24 @@ class NeuSRenderer:
         self.color_depth = color_network.d_out
         self.desc = model_desc(sdf_network, color_network, n_samples, n_importance, up_sample_steps)
         self.dp_group = None
+        self.dp_exact = True
         self.last_z_vals = None
         self.last_extras = {}
         self.want_extras = False
 
     # ------------------------------------------------------------------ data parallel
-    def set_data_parallel(self, group=None, enabled=True):
-        """One process per GPU; the backward all-reduces (mean) the flat gradient buffer over `group`."""
+    def set_data_parallel(self, group=None, enabled=True, exact=True):
+        """One process per GPU, each rendering its contiguous shard of a global ray batch; the backward
+        all-reduces the flat gradient buffer over `group`.  exact=True (default): large-batch semantics, see the
+        module docstring (pair it with `rnb_loss(..., group=group)`); exact=False: DDP mean of per-rank losses."""
         self.dp_group = (group if group is not None else dist.group.WORLD) if enabled else None
+        self.dp_exact = bool(exact)
+
+    def set_variant(self, **kw):
+        """Kernel / arithmetic variant bits of the model descriptor (include/rnbneus.h RNB_VARIANT_*):
+        bf16=, deterministic=, generic=, dw_lds=, bwd_ti=, bwd_nw=, fwd_ti=, fwd_nw=.  Returns self."""
+        self.desc.variant = native.variant_bits(**kw)
+        return self
 
     # ------------------------------------------------------------------ helpers
     def _leaves(self, train_color):
@@ -207,9 +241,11 @@ class NeuSRenderer:
         ws = torch.empty(max(nbytes.value, 256), dtype=torch.uint8, device=dev)
         near = near.to(torch.float32).reshape(B).contiguous()
         far = far.to(torch.float32).reshape(B).contiguous()
-        native.check(lib.rnb_sample_rays(C.byref(self.desc), native.ptr(packed), native.ptr(rays_o), native.ptr(rays_d),
-                                         native.ptr(near), native.ptr(far), native.ptr(t_rand), B, native.ptr(z),
-                                         native.ptr(ws), ws.numel(), _stream()))
+        native.same_device(packed, rays_o, rays_d, near, far, t_rand)
+        with native.on_device(dev) as stream:
+            native.check(lib.rnb_sample_rays(C.byref(self.desc), native.ptr(packed), native.ptr(rays_o),
+                                             native.ptr(rays_d), native.ptr(near), native.ptr(far), native.ptr(t_rand),
+                                             B, native.ptr(z), native.ptr(ws), ws.numel(), stream))
         return z
 
     def _run(self, rays_o, rays_d, near, far, lights_dir, perturb_overwrite, background_rgb, cos_anneal_ratio,
@@ -217,6 +253,9 @@ class NeuSRenderer:
         if not rays_o.is_cuda:
             raise RuntimeError("NeuSRenderer: rays must be on the GPU (no CPU path; librnbneus_hip.so only)")
         dev = rays_o.device
+        if self.sdf_network.lin0.bias.device != dev:
+            raise RuntimeError(f"NeuSRenderer: rays live on {dev} but the networks on "
+                               f"{self.sdf_network.lin0.bias.device}")
         B = rays_o.shape[0]
         rays_o = rays_o.detach().to(torch.float32).contiguous()
         rays_d = rays_d.detach().to(torch.float32).contiguous()
@@ -282,33 +321,45 @@ class NeuSRenderer:
         packed = self._pack(True)
         return runtime.color_forward(self.desc, packed, points, normals, feature_vectors)
 
-    def extract_fields(self, bound_min, bound_max, resolution, chunk=64, group=None):
+    def extract_fields(self, bound_min, bound_max, resolution, chunk=64, group=None, to_host=True):
         """SDF grid query of models/renderer.py:10-25 (values negated as at :1224): `resolution`^3 forward-only
-        evaluations in chunk^3 blocks (the reference's N = 64).  The volume is assembled on the device and
-        copied to the host once.  With data parallelism enabled (`set_data_parallel`) or a `group` given, the
-        x-slabs are dealt round-robin to the ranks and summed with one all-reduce (512^3: 512 MB)."""
+        evaluations.  The grid points are generated inside the forward kernel (`rnb_sdf_grid`), the volume is
+        assembled on the device and copied to the host once (`to_host=False` returns the device tensor).  With data
+        parallelism enabled (`set_data_parallel`) or a `group` given, every rank evaluates one contiguous x-slab and
+        the slabs are exchanged with one all-gather (512^3: 512 MB in total).  `chunk` is accepted for signature
+        compatibility with the reference's block size N = 64 and has no effect: every point is evaluated once,
+        whatever the blocking."""
         dev = self.sdf_network.lin0.bias.device
         packed = self._pack(False)
-        X = torch.linspace(float(bound_min[0]), float(bound_max[0]), resolution, device=dev).split(chunk)
-        Y = torch.linspace(float(bound_min[1]), float(bound_max[1]), resolution, device=dev).split(chunk)
-        Z = torch.linspace(float(bound_min[2]), float(bound_max[2]), resolution, device=dev).split(chunk)
+        lib = native.load()
+        res = int(resolution)
         group = group if group is not None else self.dp_group
         rank, world = (dist.get_rank(group), dist.get_world_size(group)) if group is not None else (0, 1)
-        u = torch.zeros(resolution, resolution, resolution, dtype=torch.float32, device=dev)
+        per = (res + world - 1) // world                  # x-planes per rank (the last slab may be shorter)
+        x0, x1 = min(rank * per, res), min((rank + 1) * per, res)
+        gd = native.GridDesc()
+        for d in range(3):
+            gd.bound_min[d] = float(bound_min[d])
+            gd.bound_max[d] = float(bound_max[d])
+        gd.resolution, gd.x_begin, gd.x_end, gd.out_scale = res, x0, x1, -1.0
+        slab = torch.empty(per, res, res, dtype=torch.float32, device=dev)     # padded to `per` planes for the gather
         with torch.no_grad():
-            for xi, xs in enumerate(X):
-                if xi % world != rank:
-                    continue
-                for yi, ys in enumerate(Y):
-                    for zi, zs in enumerate(Z):
-                        xx, yy, zz = torch.meshgrid(xs, ys, zs, indexing="ij")
-                        pts = torch.stack([xx.reshape(-1), yy.reshape(-1), zz.reshape(-1)], dim=-1)
-                        val = -runtime.sdf_forward(self.desc, packed, pts, False)
-                        u[xi * chunk: xi * chunk + len(xs), yi * chunk: yi * chunk + len(ys),
-                          zi * chunk: zi * chunk + len(zs)] = val.reshape(len(xs), len(ys), len(zs))
+            if x1 > x0:
+                nbytes = C.c_int64()
+                native.check(lib.rnb_sdf_grid_workspace_bytes(C.byref(self.desc), C.byref(gd), C.byref(nbytes)))
+                ws = torch.empty(max(nbytes.value, 256), dtype=torch.uint8, device=dev)
+                with native.on_device(dev) as stream:
+                    native.check(lib.rnb_sdf_grid(C.byref(self.desc), native.ptr(packed), C.byref(gd), native.ptr(slab),
+                                                  native.ptr(ws), ws.numel(), stream))
+            if x1 - x0 < per:
+                slab[x1 - x0:].zero_()
             if world > 1:
-                dist.all_reduce(u, op=dist.ReduceOp.SUM, group=group)
-        return u.cpu().numpy()
+                full = torch.empty(world * per, res, res, dtype=torch.float32, device=dev)
+                dist.all_gather_into_tensor(full, slab, group=group)
+                u = full[:res]
+            else:
+                u = slab[:res]
+        return u.cpu().numpy() if to_host else u
 
     def extract_geometry(self, bound_min, bound_max, resolution, threshold=0.0):
         """models/renderer.py:1219-1224 / :27-36.  Marching cubes itself is PyMCubes (third party, not

@@ -10,10 +10,6 @@ from . import native
 from .fields import RenderingNetwork, SDFNetwork, _mlp_struct, model_desc
 
 
-def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
-
-
 def _require_cuda(t, name):
     if not t.is_cuda:
         raise RuntimeError(f"{name} must live on the GPU: the renderer has no CPU path "
@@ -36,8 +32,9 @@ def pack_weights(desc, sdf: SDFNetwork | None, color: RenderingNetwork | None, d
     packed = torch.empty(packed_floats(desc), dtype=torch.float32, device=device)
     sp = _mlp_struct(sdf.lins(), sdf.weight_norm) if sdf is not None else None
     cp = _mlp_struct(color.lins(), color.weight_norm) if color is not None else None
-    native.check(lib.rnb_weightnorm_fwd(C.byref(desc), C.byref(sp) if sp is not None else None,
-                                        C.byref(cp) if cp is not None else None, native.ptr(packed), _stream()))
+    with native.on_device(packed) as stream:
+        native.check(lib.rnb_weightnorm_fwd(C.byref(desc), C.byref(sp) if sp is not None else None,
+                                            C.byref(cp) if cp is not None else None, native.ptr(packed), stream))
     return packed
 
 
@@ -54,10 +51,12 @@ def sdf_forward(desc, packed, pts, with_feature):
     sdf = torch.empty(n, 1, dtype=torch.float32, device=pts.device)
     feat = torch.empty(n, desc.sdf_d_out - 1, dtype=torch.float32, device=pts.device) if with_feature else None
     if n > 0:
+        native.same_device(packed, pts)
         ws = points_workspace(desc, n, pts.device)
-        native.check(native.load().rnb_sdf_forward(C.byref(desc), native.ptr(packed), native.ptr(pts), n,
-                                                   native.ptr(sdf), native.ptr(feat), native.ptr(ws), ws.numel(),
-                                                   _stream()))
+        with native.on_device(pts) as stream:
+            native.check(native.load().rnb_sdf_forward(C.byref(desc), native.ptr(packed), native.ptr(pts), n,
+                                                       native.ptr(sdf), native.ptr(feat), native.ptr(ws), ws.numel(),
+                                                       stream))
     return torch.cat([sdf, feat], dim=-1) if with_feature else sdf
 
 
@@ -67,9 +66,11 @@ def sdf_gradient(desc, packed, pts):
     n = pts.shape[0]
     grad = torch.empty(n, 3, dtype=torch.float32, device=pts.device)
     if n > 0:
+        native.same_device(packed, pts)
         ws = points_workspace(desc, n, pts.device)
-        native.check(native.load().rnb_sdf_gradient(C.byref(desc), native.ptr(packed), native.ptr(pts), n,
-                                                    native.ptr(grad), None, native.ptr(ws), ws.numel(), _stream()))
+        with native.on_device(pts) as stream:
+            native.check(native.load().rnb_sdf_gradient(C.byref(desc), native.ptr(packed), native.ptr(pts), n,
+                                                        native.ptr(grad), None, native.ptr(ws), ws.numel(), stream))
     return grad
 
 
@@ -81,10 +82,12 @@ def color_forward(desc, packed, pts, normals, feats):
     n = pts.shape[0]
     out = torch.empty(n, desc.col_d_out, dtype=torch.float32, device=pts.device)
     if n > 0:
+        native.same_device(packed, pts, normals, feats)
         ws = points_workspace(desc, n, pts.device)
-        native.check(native.load().rnb_color_forward(C.byref(desc), native.ptr(packed), native.ptr(pts),
-                                                     native.ptr(normals), native.ptr(feats), n, native.ptr(out),
-                                                     native.ptr(ws), ws.numel(), _stream()))
+        with native.on_device(pts) as stream:
+            native.check(native.load().rnb_color_forward(C.byref(desc), native.ptr(packed), native.ptr(pts),
+                                                         native.ptr(normals), native.ptr(feats), n, native.ptr(out),
+                                                         native.ptr(ws), ws.numel(), stream))
     return out
 
 

@@ -13,7 +13,7 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 def case_names():
     """Renderer fixtures (tiny_* / full_*); raygen_* fixtures have their own loader below."""
     names = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
-    return [n for n in names if not n.startswith("raygen")]
+    return [n for n in names if n.startswith("tiny_") or n.startswith("full_")]
 
 
 def load_raygen(name="raygen_small"):
@@ -66,13 +66,25 @@ class Golden:
             pre = f"trace.{i}."
             self.steps.append({k[len(pre):]: torch.from_numpy(np.asarray(z[k])) for k in z.files
                                if k.startswith(pre)})
-        self.has_weights = any(k.startswith("w.") for k in z.files)
+        # the sample positions the fine pass received (== steps[-1]["z_out"] when there is an up-sampling loop)
+        self.z_fine = torch.from_numpy(z["trace.z_vals"])
+        # the reference in fp64 on the same samples, and the fp32 reference's distance from it (gen_golden.py)
+        self.out64 = {k[6:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("out64.")}
+        self.grad64 = {k[7:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("grad64.")}
+        self.grad64_stride = {k[14:]: int(z[k]) for k in z.files if k.startswith("grad64_stride.")}
+        self.rel32 = {k[6:]: float(z[k]) for k in z.files if k.startswith("rel32.")}
+        self.rel32s = {k[7:]: float(z[k]) for k in z.files if k.startswith("rel32s.")}
+        self.weights_from = str(z["meta.weights_from"]) if "meta.weights_from" in z.files else None
+        self.has_weights = any(k.startswith("w.") for k in z.files) or self.weights_from is not None
         self.wsum = {k[5:]: z[k] for k in z.files if k.startswith("wsum.")}
 
     def params(self, requires_grad=False):
         """Named parameters: stored arrays, or (full_*_geo) regenerated from seed 0 and verified
         against the stored checksums."""
-        if self.has_weights:
+        if self.weights_from is not None:     # same network state as another fixture (stored once)
+            zw = np.load(os.path.join(GOLDEN_DIR, self.weights_from + ".npz"), allow_pickle=False)
+            p = {k[2:]: torch.from_numpy(zw[k]).clone() for k in zw.files if k.startswith("w.")}
+        elif self.has_weights:
             p = {k[2:]: torch.from_numpy(self.z[k]).clone() for k in self.z.files if k.startswith("w.")}
         else:
             torch.manual_seed(0)

@@ -1,7 +1,9 @@
 """Data-parallel path on the device: two ranks (sharing the one GPU of the test box, gloo transport) render
-their shards of one ray batch with `set_data_parallel()`; the gradients every rank ends up with must equal
-the mean of the two ranks' local (non-DP) gradients.  On the 8-GPU node the same code runs one rank per GPU
-over RCCL (bench.py)."""
+their shards of one ray batch with `set_data_parallel()`.  exact=True (default): every rank ends up with the
+gradient — and the loss value — of the SINGLE-PROCESS step on the whole batch (the three batch-global normalisers of
+SURVEY 8e are all-reduced: mask_sum, the BCE mean's B, the eikonal ratio's two sums).  exact=False: the DDP
+convention, mean of the ranks' local gradients.  On the 8-GPU node the same code runs one rank per GPU over RCCL
+(bench.py)."""
 import os
 import socket
 
@@ -38,7 +40,7 @@ def _worker(rank, world, port, q):
     leaves = list(sdf.parameters()) + list(devn.parameters()) + list(col.parameters())
 
     def grads(dp):
-        ren.set_data_parallel(enabled=dp)
+        ren.set_data_parallel(enabled=dp, exact=False)
         for x in leaves:
             x.grad = None
         out = ren.render_rnb(mine["rays_o"], mine["rays_d"], mine["near"], mine["far"], mine["lights_dir"],
@@ -72,6 +74,78 @@ def test_two_rank_gradients_are_the_mean_of_local_gradients():
     for rank, rel, differs in res:
         assert rel < 1e-5, f"rank {rank}: DP gradient differs from the mean of local gradients by {rel:.2e}"
         assert differs > 1e-3, "the two shards should produce different local gradients"
+
+
+def _exact_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import rnb_neus_fork_amd as R
+    from rnb_neus_fork_amd import parallel as P
+    from oracle import rnb_oracle as O
+    dev = torch.device("cuda:0")
+    mc = O.ModelConf(sdf=O.SDFConf(d_out=65, d_hidden=64), color=O.ColorConf(d_feature=64, d_hidden=64),
+                     render=O.RenderConf(n_samples=16, n_importance=16))
+    torch.manual_seed(0)
+    p = O.init_params(mc)
+    sdf, devn, col, ren = R.build_from_named_params(mc, p, dev)
+    P.broadcast_parameters([sdf, devn, col])
+    # a batch whose shards have DIFFERENT mask counts and eikonal counts (otherwise per-shard normalisers would do)
+    batch = O.synthetic_batch(24, seed=9, step=2, warmup=False)
+    batch["mask"][:9] = 1.0
+    batch["mask"][9:] = (torch.arange(15) % 4 == 0).float()[:, None]
+    full = {k: v.to(dev) for k, v in batch.items()}
+    mine = {k: v.to(dev) for k, v in P.shard_batch(batch, rank, world).items()}
+    leaves = list(sdf.parameters()) + list(devn.parameters()) + list(col.parameters())
+
+    def run(b, dp, loss_group):
+        ren.set_data_parallel(enabled=dp, exact=True)
+        ren.set_variant(deterministic=True)       # ordered reductions: no atomic noise in the comparison
+        for x in leaves:
+            x.grad = None
+        out = ren.render_rnb(b["rays_o"], b["rays_d"], b["near"], b["far"], b["lights_dir"], cos_anneal_ratio=1.0,
+                             t_rand=b["t_rand"])
+        loss, parts = R.rnb_loss(out, b["true_rgb"], b["mask"], group=loss_group)
+        loss.backward()
+        torch.cuda.synchronize()
+        return (torch.cat([x.grad.reshape(-1) for x in leaves]).clone(), float(loss), float(out["gradient_error"]),
+                ren.last_z_vals.clone())
+
+    g_single, l_single, ge_single, z_single = run(full, False, None)         # the whole batch in one process
+    g_dp, l_dp, ge_dp, z_dp = run(mine, True, dist.group.WORLD)            # my shard, exact data parallel
+    lo = rank * (24 // world)
+    same_samples = bool(torch.equal(z_dp, z_single[lo:lo + 24 // world]))
+    rel = float((g_dp - g_single).norm() / g_single.norm())
+    # the DDP convention on the same shards differs visibly (unequal mask counts)
+    ren.set_data_parallel(enabled=True, exact=False)
+    for x in leaves:
+        x.grad = None
+    out = ren.render_rnb(mine["rays_o"], mine["rays_d"], mine["near"], mine["far"], mine["lights_dir"],
+                         cos_anneal_ratio=1.0, t_rand=mine["t_rand"])
+    R.rnb_loss(out, mine["true_rgb"], mine["mask"])[0].backward()
+    g_ddp = torch.cat([x.grad.reshape(-1) for x in leaves])
+    rel_ddp = float((g_ddp - g_single).norm() / g_single.norm())
+    q.put((rank, rel, abs(l_dp - l_single), abs(ge_dp - ge_single), same_samples, rel_ddp))
+    dist.destroy_process_group()
+
+
+def test_exact_data_parallel_step_equals_the_single_process_step():
+    """"so that G-GPU results equal the 1-GPU result on the same rays" — gradient rel-L2 <= 1e-5."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_exact_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    for rank, rel, dl, dge, same_samples, rel_ddp in res:
+        assert same_samples, "a shard must sample exactly the depths the whole batch samples for those rays"
+        assert rel <= 1e-5, f"rank {rank}: exact-DP gradient differs from the whole-batch gradient by {rel:.2e}"
+        assert dl <= 2e-6 and dge <= 1e-7, f"rank {rank}: loss / gradient_error differ ({dl:.2e}, {dge:.2e})"
+        assert rel_ddp > 1e-3, "with unequal mask counts the DDP mean must differ from the whole-batch gradient"
+    print(f"exact DP vs single process: gradient rel-L2 {max(r[1] for r in res):.2e}; DDP-mean convention: {res[0][5]:.2e}")
 
 
 def _grid_worker(rank, world, port, q):

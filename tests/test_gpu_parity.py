@@ -1,7 +1,15 @@
 """GPU parity tests: the HIP path (through the C ABI, via the drop-in classes) against the pinned CPU
-oracle and the committed golden vectors.  Tolerances: integer sample indices bit-exact
-given identical inputs; fp32 outputs |d| <= 1e-5 + 1e-4*|ref|; parameter gradients rel-L2 <= 1e-3 per
-tensor here (fp32 MFMA vs. CPU GEMM summation order; typically ~1e-6)."""
+oracle and the committed golden vectors.
+
+Tolerances.  Integer sample indices: bit-exact given identical inputs.  Floating point: SURVEY.md 8c states
+|d| <= 1e-5 + 1e-4 |ref| for outputs and rel-L2 <= 1e-4 for parameter gradients — but the fixtures show that the
+fp32 REFERENCE itself is further than that from the exact result wherever the quantity is ill-conditioned (cdf_fine
+4.9e-5 at inv_s = 403; d loss / d lin8.weight_g 1.4e-3).  Every fixture therefore also holds the reference's own code
+run in fp64 on the same samples (oracle/gen_golden.py::reference_fp64), and the fine-pass tests bound the HIP path's
+distance from fp64 by the fp32 reference's distance from fp64:
+    outputs:    max|hip - ref64| <= K_OUT * max|ref32 - ref64| + FLOOR_OUT * max(1, max|ref64|)
+    gradients:  relL2(hip, ref64) <= max(1e-4, K_GRAD * relL2(ref32, ref64))          per tensor
+i.e. "as accurate as the reference's fp32, up to a stated factor", instead of hand-set absolute bounds."""
 import ctypes as C
 import zlib
 
@@ -13,6 +21,9 @@ from oracle import rnb_oracle as O
 from tests.golden_util import Golden, case_names
 
 pytestmark = pytest.mark.gpu
+
+K_OUT, FLOOR_OUT = 3.0, 2e-6     # outputs: factor over the fp32 reference's own max error + a few fp32 ulps
+K_GRAD = 3.0                     # gradients: factor over the fp32 reference's own relative L2 error
 
 CASES = case_names()
 TINY = [c for c in CASES if c.startswith("tiny")]
@@ -37,7 +48,7 @@ def _build(R, g: Golden):
 
 
 def _fine_points(g: Golden):
-    z = g.steps[-1]["z_out"]
+    z = g.z_fine
     b = g.batch
     sd = 2.0 / g.mc.render.n_samples
     dists = torch.cat([z[:, 1:] - z[:, :-1], torch.full_like(z[:, :1], sd)], -1)
@@ -144,32 +155,85 @@ def test_gather_sdf(R):
     assert torch.equal(out.cpu(), ref)
 
 
+def _device_sampling_trace(R, g, sdf, b, z0):
+    """The up-sampling loop of rnb_sample_rays composed from the public per-step entry points (rnb_up_sample_step,
+    rnb_sdf_forward, rnb_gather_sdf), so that the integer outputs of every step are visible."""
+    lib = R.native.load()
+    d = _dev()
+    rc = g.mc.render
+    ro, rd = b["rays_o"].contiguous(), b["rays_d"].contiguous()
+    B = ro.shape[0]
+    n_new = rc.n_importance // rc.up_sample_steps
+    z = z0.contiguous()
+    pts = ro[:, None, :] + rd[:, None, :] * z[..., None]
+    sdfv = sdf.sdf(pts.reshape(-1, 3)).reshape(B, -1).contiguous()
+    inds_all = []
+    for i in range(rc.up_sample_steps):
+        n = z.shape[1]
+        new_z = torch.empty(B, n_new, device=d)
+        inds = torch.empty(B, n_new, dtype=torch.int32, device=d)
+        z_out = torch.empty(B, n + n_new, device=d)
+        sidx = torch.empty(B, n + n_new, dtype=torch.int32, device=d)
+        R.native.check(lib.rnb_up_sample_step(R.native.ptr(ro), R.native.ptr(rd), R.native.ptr(z), R.native.ptr(sdfv),
+                                              B, n, n_new, float(64 * 2 ** i), R.native.ptr(new_z), R.native.ptr(inds),
+                                              R.native.ptr(z_out), R.native.ptr(sidx), None))
+        inds_all.append(inds.cpu().long())
+        if i + 1 < rc.up_sample_steps:
+            npts = ro[:, None, :] + rd[:, None, :] * new_z[..., None]
+            new_sdf = sdf.sdf(npts.reshape(-1, 3)).reshape(B, n_new).contiguous()
+            merged = torch.empty(B, n + n_new, device=d)
+            R.native.check(lib.rnb_gather_sdf(R.native.ptr(sdfv), R.native.ptr(new_sdf), R.native.ptr(sidx), B, n,
+                                              n_new, R.native.ptr(merged), None))
+            sdfv = merged
+        z = z_out
+    return inds_all, z
+
+
+# measured on MI355X (round 2; `pytest -s` prints them): fraction of z_vals within 1e-4 of the reference's and
+# fraction of rays whose four searchsorted index rows ALL equal the reference's, per fixture; the thresholds sit just
+# under the measurements.  (The CPU oracle itself drops to 0.984 / 232 of 240 rays when only its weight-norm
+# expression is re-associated: tests/test_oracle_golden.py::test_weight_norm_rounding_is_amplified...)
+E2E_MIN = {}   # name -> (min frac of z within 1e-4, min frac of rays with identical indices); default below
+E2E_DEFAULT = (0.99, 0.90)
+
+
 @pytest.mark.parametrize("name", CASES)
 def test_sample_rays_end_to_end(R, name):
     """Whole prologue on the device.  1-ulp differences of the coarse SDF are amplified by the sharp
     sigmoids of the up-sampling loop (the CPU oracle shows the same when its weight-norm rounding is
-    changed), so z_vals are compared statistically, not bit-wise."""
+    changed), so end to end the z_vals are compared statistically, with thresholds at the measured level."""
     g = Golden(name)
     p, sdf, dev, col, ren = _build(R, g)
     b = {k: v.to(_dev()) for k, v in g.batch.items()}
     perturb = g.mc.render.perturb if g.perturb_overwrite < 0 else g.perturb_overwrite
     packed = ren._pack(False)
-    z = ren.sample_z_vals(b["rays_o"], b["rays_d"], b["near"], b["far"], packed, perturb, b["t_rand"]).cpu()
-    ref = g.steps[-1]["z_out"]
+    z = ren.sample_z_vals(b["rays_o"], b["rays_d"], b["near"], b["far"], packed, perturb, b["t_rand"])
+    ref = g.z_fine
     assert z.shape == ref.shape
     assert bool((z[:, 1:] >= z[:, :-1]).all())
-    diff = (z - ref).abs()
-    frac_close = (diff < 1e-4).float().mean().item()
-    print(f"{name}: z_vals within 1e-4 of the reference: {100 * frac_close:.1f}%  (max diff {diff.max():.3e})")
-    assert diff.mean().item() < 2e-3
-    assert frac_close > 0.80
-    # coarse depths (before any up-sampling) must agree to rounding
-    z0_ref = g.steps[0]["z_in"]
-    lib = R.native.load()
+    # coarse depths (before any up-sampling) must be bit-exact
     ren0 = R.NeuSRenderer(None, sdf, dev, col, n_samples=g.mc.render.n_samples, n_importance=0, n_outside=0,
                           up_sample_steps=1, perturb=g.mc.render.perturb)
-    z0 = ren0.sample_z_vals(b["rays_o"], b["rays_d"], b["near"], b["far"], packed, perturb, b["t_rand"]).cpu()
-    assert torch.equal(z0, z0_ref), "initial depths must be bit-exact"
+    z0 = ren0.sample_z_vals(b["rays_o"], b["rays_d"], b["near"], b["far"], packed, perturb, b["t_rand"])
+    z0_ref = g.steps[0]["z_in"] if g.n_steps else g.z_fine
+    assert torch.equal(z0.cpu(), z0_ref), "initial depths must be bit-exact"
+    if g.n_steps == 0:
+        assert torch.equal(z.cpu(), ref)
+        return
+    inds_all, z_composed = _device_sampling_trace(R, g, sdf, b, z0)
+    assert torch.equal(z_composed, z), "rnb_sample_rays must equal the loop composed from the per-step entry points"
+    same = torch.ones(z.shape[0], dtype=torch.bool)
+    for mine, st in zip(inds_all, g.steps):
+        same &= (mine == st["inds"]).all(dim=1)
+    frac_rays = same.float().mean().item()
+    diff = (z.cpu() - ref).abs()
+    frac_close = (diff < 1e-4).float().mean().item()
+    print(f"E2E {name}: z_vals within 1e-4: {frac_close:.4f}; rays with all {g.n_steps} index rows identical: "
+          f"{frac_rays:.4f} ({int(same.sum())}/{same.numel()}); max |dz| {diff.max():.3e}")
+    lo_close, lo_rays = E2E_MIN.get(name, E2E_DEFAULT)
+    assert frac_close >= lo_close
+    assert frac_rays >= lo_rays
+    assert diff.mean().item() < 5e-4
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -192,44 +256,69 @@ def _loss(g, out, b):
     return O.rnb_loss(out, b["true_rgb"], b["mask"])[0]
 
 
-@pytest.mark.parametrize("name", CASES)
-def test_fine_pass_golden(R, name):
-    g = Golden(name)
-    p, sdf, dev, col, ren = _build(R, g)
-    b = {k: v.to(_dev()) for k, v in g.batch.items()}
-    z_vals = g.steps[-1]["z_out"].to(_dev())
-    out = _render(ren, g, b, z_vals)
-    # cdf = sigmoid(inv_s * sdf) turns an fp32-rounding-level SDF difference d into up to inv_s*d/4, so
-    # the absolute tolerance of everything downstream of the CDFs scales with inv_s (403 when sharpened)
-    inv_s = float(torch.exp(p["dev.variance"] * 10.0))
-    atol = 1e-5 + 2.5e-7 * inv_s
-    for k, ref in g.out.items():
-        if k == "loss":
-            continue
-        got = out[k].detach().cpu()
-        assert got.shape == ref.shape, k
-        torch.testing.assert_close(got, ref, rtol=1e-4, atol=atol, msg=lambda m: f"{k}: {m}")
-    loss = _loss(g, out, b)
-    torch.testing.assert_close(loss.detach().cpu(), g.out["loss"], rtol=1e-4, atol=atol)
-    loss.backward()
-    torch.cuda.synchronize()
+def _named(sdf, dev, col):
     named = {("sdf." + k): v for k, v in sdf.named_parameters()}
     named["dev.variance"] = dev.variance
     named.update({("color." + k): v for k, v in col.named_parameters()})
+    return named
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_fine_pass_golden(R, name):
+    """Fine pass forward + loss + backward on the reference's own z_vals, bounded by the fp32 reference's own
+    distance from the fp64 reference (module docstring)."""
+    g = Golden(name)
+    p, sdf, dev, col, ren = _build(R, g)
+    b = {k: v.to(_dev()) for k, v in g.batch.items()}
+    z_vals = g.z_fine.to(_dev())
+    out = _render(ren, g, b, z_vals)
+    loss = _loss(g, out, b)
+    got_all = {k: out[k].detach().cpu().double() for k in g.out if k != "loss"}
+    got_all["loss"] = loss.detach().cpu().double()
+    worst_out = ("", 0.0)
+    for k, ref32 in g.out.items():
+        got = got_all[k]
+        assert got.shape == ref32.shape, k
+        if k == "inside_sphere":
+            assert torch.equal(got.float(), ref32), "inside_sphere is an exact predicate of the inputs"
+            continue
+        ref64 = g.out64[k]
+        e_hip = float((got - ref64).abs().max())
+        e_ref = float((ref32.double() - ref64).abs().max())
+        bound = K_OUT * e_ref + FLOOR_OUT * max(1.0, float(ref64.abs().max()))
+        ratio = e_hip / max(e_ref, 1e-30)
+        if ratio > worst_out[1] and e_hip > FLOOR_OUT:
+            worst_out = (k, ratio)
+        assert e_hip <= bound, f"{k}: |hip - fp64| {e_hip:.3e} > {bound:.3e} (fp32 reference: {e_ref:.3e})"
+    loss.backward()
+    torch.cuda.synchronize()
+    named = _named(sdf, dev, col)
     with_grad = {k for k, v in named.items() if v.grad is not None}
     assert with_grad == set(g.grads.keys())
-    worst = ("", 0.0)
+    worst = ("", 0.0, 0.0)
+    for k, g64 in g.grad64.items():
+        st = g.grad64_stride[k]
+        mine = named[k].grad.detach().cpu().reshape(-1)[::st].double()
+        n64 = float(g64.norm())
+        if n64 < 1e-12:
+            assert float(mine.abs().max()) < 1e-8, k
+            continue
+        rel = float((mine - g64).norm()) / n64
+        bound = max(1e-4, K_GRAD * g.rel32s[k])
+        if rel / bound > worst[1]:
+            worst = (k, rel / bound, rel)
+        assert rel <= bound, f"{k}: rel-L2 vs fp64 {rel:.3e} > {bound:.3e} (fp32 reference: {g.rel32s[k]:.3e})"
+    # and directly against the fp32 reference's gradients (every stored element)
     for k, ref in g.grads.items():
         mine = named[k].grad.detach().cpu().reshape(-1)[:: g.grad_stride]
-        denom = max(g.gradnorm[k] / np.sqrt(g.grad_stride), 1e-12)
-        rel = float((mine - ref).double().norm()) / denom
-        if rel > worst[1]:
-            worst = (k, rel)
+        denom = g.gradnorm[k] / np.sqrt(g.grad_stride)
         if g.gradnorm[k] < 1e-10:
             assert float(mine.abs().max()) < 1e-8, k
-        else:
-            assert rel < 1e-3, f"{k}: rel-L2 {rel:.3e}"
-    print(f"{name}: worst gradient rel-L2 = {worst[1]:.2e} ({worst[0]})")
+            continue
+        rel = float((mine - ref).double().norm()) / denom
+        assert rel <= max(1e-4, (1.0 + K_GRAD) * g.rel32.get(k, 0.0)) * 1.5, f"{k}: rel-L2 vs the fp32 reference {rel:.3e}"
+    print(f"FINE {name}: worst output error ratio hip/ref32 = {worst_out[1]:.2f} ({worst_out[0]}); worst gradient: "
+          f"{worst[0]} rel-L2 vs fp64 {worst[2]:.2e} = {worst[1]:.2f} of its bound")
 
 
 def test_full_batch_512_matches_oracle(R):
@@ -353,47 +442,99 @@ def test_256_samples_per_ray_matches_oracle(R):
 
 
 def test_fused_and_generic_paths_agree(R):
-    """The 256-wide network runs through the fused sweep kernels; RNB_NO_FUSED=1 forces the per-layer GEMM
-    path (the one other widths use).  Both must produce the same step (a child process runs the generic
-    path: the switch is read once per process)."""
-    import json
-    import subprocess
-    import sys
-    code = r'''
-import json, torch, sys
-sys.path.insert(0, ".")
-import rnb_neus_fork_amd as R
-from oracle import rnb_oracle as O
-mc = O.ModelConf()
-torch.manual_seed(1)
-p = O.init_params(mc)
-dev = torch.device("cuda:0")
-sdf, devn, col, ren = R.build_from_named_params(mc, p, dev)
-b = {k: v.to(dev) for k, v in O.synthetic_batch(128, seed=5, step=1).items()}
-out = ren.render_rnb(b["rays_o"], b["rays_d"], b["near"], b["far"], b["lights_dir"], cos_anneal_ratio=1.0,
-                     t_rand=b["t_rand"])
-loss = O.rnb_loss(out, b["true_rgb"], b["mask"])[0]
-loss.backward()
-res = {"loss": float(loss), "wsum": float(out["weight_sum"].sum()),
-       "g": [float(x.grad.double().norm()) for x in list(sdf.parameters()) + list(devn.parameters()) + list(col.parameters())]}
-print("RESULT" + json.dumps(res))
-'''
-    import os
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    """The 256-wide network runs through the fused sweep kernels; RNB_VARIANT_GENERIC (rnb_model_desc.variant) forces
+    the per-layer GEMM path (the one other widths use), RNB_VARIANT_DW_LDS the LDS-staged weight-gradient GEMMs, the
+    BWD_TI / BWD_NW bits the other tile shapes of the backward sweeps.  All must produce the same step."""
+    mc = O.ModelConf()
+    torch.manual_seed(1)
+    p = O.init_params(mc)
+    sdf, devn, col, ren = R.build_from_named_params(mc, p, _dev())
+    b = {k: v.to(_dev()) for k, v in O.synthetic_batch(128, seed=5, step=1).items()}
+    params = list(sdf.parameters()) + list(devn.parameters()) + list(col.parameters())
     res = {}
-    # RNB_DW_LDS=1: the dW GEMMs staged through LDS instead of the direct-fragment kernel
-    # RNB_BWD_TI: 32- / 64-point tiles in all three backward sweeps (the default mixes them)
-    for tag, env in (("fused", {}), ("generic", {"RNB_NO_FUSED": "1"}), ("dw_lds", {"RNB_DW_LDS": "1"}),
-                     ("bwd_ti1", {"RNB_BWD_TI": "1", "RNB_BWD_NW": "4"}), ("bwd_ti2", {"RNB_BWD_TI": "2", "RNB_BWD_NW": "4"}),
-                     ("bwd_ti2_nw8", {"RNB_BWD_TI": "2", "RNB_BWD_NW": "8"})):
-        e = dict(os.environ)
-        e.update(env)
-        r = subprocess.run([sys.executable, "-c", code], cwd=root, env=e, capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stderr[-2000:]
-        line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")][-1]
-        res[tag] = json.loads(line[len("RESULT"):])
-    assert abs(res["fused"]["loss"] - res["generic"]["loss"]) < 1e-5
-    assert abs(res["fused"]["wsum"] - res["generic"]["wsum"]) < 1e-3
-    for other in ("generic", "dw_lds", "bwd_ti1", "bwd_ti2", "bwd_ti2_nw8"):
-        for a, c in zip(res["fused"]["g"], res[other]["g"]):
-            assert abs(a - c) <= 1e-3 * max(abs(c), 1e-8) + 1e-9, other
+    z = None
+    for tag, kw in (("fused", {}), ("generic", dict(generic=True)), ("dw_lds", dict(dw_lds=True)),
+                    ("bwd_ti1", dict(bwd_ti=1, bwd_nw=4)), ("bwd_ti2", dict(bwd_ti=2, bwd_nw=4)),
+                    ("bwd_ti2_nw8", dict(bwd_ti=2, bwd_nw=8)), ("fwd_ti1", dict(fwd_ti=1, fwd_nw=4)),
+                    ("deterministic", dict(deterministic=True))):
+        ren.set_variant(**kw)
+        for q in params:
+            q.grad = None
+        out = ren.render_rnb(b["rays_o"], b["rays_d"], b["near"], b["far"], b["lights_dir"], cos_anneal_ratio=1.0,
+                             t_rand=b["t_rand"], z_vals=z)
+        if z is None:
+            z = ren.last_z_vals     # every variant renders the same samples
+        loss = O.rnb_loss(out, b["true_rgb"], b["mask"])[0]
+        loss.backward()
+        res[tag] = {"loss": float(loss), "wsum": float(out["weight_sum"].sum()),
+                    "g": [q.grad.double().clone() for q in params]}
+    ren.set_variant()
+    for other in res:
+        if other == "fused":
+            continue
+        assert abs(res["fused"]["loss"] - res[other]["loss"]) < 1e-5, other
+        assert abs(res["fused"]["wsum"] - res[other]["wsum"]) < 1e-3, other
+        for a_, c_ in zip(res["fused"]["g"], res[other]["g"]):
+            rel = float((a_ - c_).norm() / c_.norm().clamp_min(1e-12))
+            assert rel < 2e-4, f"{other}: gradient rel-L2 {rel:.2e}"
+
+
+def test_deterministic_variant_is_bit_reproducible(R):
+    """RNB_VARIANT_DETERMINISTIC: ordered reductions instead of fp32 atomics -> two runs give identical bits."""
+    mc = O.ModelConf()
+    torch.manual_seed(2)
+    p = O.init_params(mc)
+    sdf, devn, col, ren = R.build_from_named_params(mc, p, _dev())
+    ren.set_variant(deterministic=True)
+    b = {k: v.to(_dev()) for k, v in O.synthetic_batch(96, seed=6, step=2).items()}
+    params = list(sdf.parameters()) + list(devn.parameters()) + list(col.parameters())
+    runs = []
+    z = None
+    for _ in range(3):
+        for q in params:
+            q.grad = None
+        out = ren.render_rnb(b["rays_o"], b["rays_d"], b["near"], b["far"], b["lights_dir"], cos_anneal_ratio=1.0,
+                             t_rand=b["t_rand"], z_vals=z)
+        z = ren.last_z_vals
+        O.rnb_loss(out, b["true_rgb"], b["mask"])[0].backward()
+        runs.append([q.grad.clone() for q in params])
+    for r in runs[1:]:
+        for a_, c_ in zip(runs[0], r):
+            assert torch.equal(a_, c_), "deterministic variant must be bit-reproducible"
+
+
+def test_second_backward_raises_clearly(R):
+    mc = O.ModelConf(sdf=O.SDFConf(d_out=65, d_hidden=64), color=O.ColorConf(d_feature=64, d_hidden=64),
+                     render=O.RenderConf(n_samples=16, n_importance=16))
+    torch.manual_seed(0)
+    p = O.init_params(mc)
+    sdf, devn, col, ren = R.build_from_named_params(mc, p, _dev())
+    b = {k: v.to(_dev()) for k, v in O.synthetic_batch(8, seed=3, step=0).items()}
+    out = ren.render_rnb(b["rays_o"], b["rays_d"], b["near"], b["far"], b["lights_dir"], t_rand=b["t_rand"])
+    loss = out["color_fine"].sum()
+    loss.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="second time"):
+        loss.backward()
+
+
+def test_wrong_device_is_rejected(R):
+    """Tensors of one call must live on one GPU, and a model on cuda:k works whatever the current device is."""
+    mc = O.ModelConf(sdf=O.SDFConf(d_out=65, d_hidden=64), color=O.ColorConf(d_feature=64, d_hidden=64),
+                     render=O.RenderConf(n_samples=16, n_importance=16))
+    torch.manual_seed(0)
+    p = O.init_params(mc)
+    sdf, devn, col, ren = R.build_from_named_params(mc, p, _dev())
+    b = O.synthetic_batch(8, seed=3, step=0)
+    with pytest.raises(RuntimeError):
+        ren.render_rnb(b["rays_o"], b["rays_d"], b["near"], b["far"], b["lights_dir"], t_rand=b["t_rand"])   # CPU rays
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs for the cross-device part")
+    d1 = torch.device("cuda:1")
+    b1 = {k: v.to(d1) for k, v in b.items()}
+    with pytest.raises(RuntimeError, match="live on"):
+        ren.render_rnb(b1["rays_o"], b1["rays_d"], b1["near"], b1["far"], b1["lights_dir"], t_rand=b1["t_rand"])
+    sdf1, devn1, col1, ren1 = R.build_from_named_params(mc, p, d1)
+    torch.cuda.set_device(0)     # current device != the model's device: the guard must switch
+    o0 = ren.render_rnb(*(b[k].to(_dev()) for k in ("rays_o", "rays_d", "near", "far", "lights_dir")), t_rand=b["t_rand"].to(_dev()))
+    o1 = ren1.render_rnb(b1["rays_o"], b1["rays_d"], b1["near"], b1["far"], b1["lights_dir"], t_rand=b1["t_rand"])
+    torch.testing.assert_close(o0["color_fine"].cpu(), o1["color_fine"].cpu(), rtol=1e-5, atol=1e-6)

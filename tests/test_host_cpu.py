@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/rnbneus.h but not exported"
     assert set(declared) == set(R.native.EXPORTED_SYMBOLS)
-    assert lib.rnb_abi_version() == 1
+    assert lib.rnb_abi_version() == 2
 
 
 def _desc(**over):
@@ -162,6 +162,88 @@ def test_checkpoint_layout_round_trip(tmp_path):
     assert CK.latest_checkpoint(str(tmp_path / "checkpoints"), end_iter=100) is None
 
 
+def _ref_layout_modules(seed):
+    torch.manual_seed(seed)
+    nerf = R.NeRF(D=2, d_in=4, d_in_view=3, W=16, multires=2, multires_view=2, output_ch=4, skips=[1],
+                  use_viewdirs=True)
+    sdf = R.SDFNetwork(d_in=3, d_out=65, d_hidden=64, n_layers=8, skip_in=[4], multires=6)
+    dev = R.SingleVarianceNetwork(0.3)
+    col = R.RenderingNetwork(d_feature=64, mode="no_view_dir", d_in=6, d_out=3, d_hidden=64, n_layers=2,
+                             multires_view=4)
+    return nerf, sdf, dev, col
+
+
+def test_flat_adam_state_interchanges_with_torch_adam_over_the_reference_list():
+    """exp_runner.py:105-115 builds Adam over nerf + sdf + variance + color; the NeRF parameters never get a
+    gradient (n_outside = 0), so torch keeps no state for them and the trained parameters' state keys start at
+    len(nerf.parameters()).  FlatAdam built from the same list must read and write exactly that layout."""
+    nerf, sdf, dev, col = _ref_layout_modules(0)
+    params = list(nerf.parameters()) + list(sdf.parameters()) + list(dev.parameters()) + list(col.parameters())
+    n_nerf = len(list(nerf.parameters()))
+    trained = params[n_nerf:]
+    opt = torch.optim.Adam(params, lr=5e-4)
+    g = torch.Generator().manual_seed(1)
+    for _ in range(2):
+        for p in trained:
+            p.grad = torch.randn(p.shape, generator=g)
+        opt.step()
+    sd = opt.state_dict()
+    assert min(sd["state"].keys()) == n_nerf and len(sd["state"]) == len(trained)
+
+    nerf2, sdf2, dev2, col2 = _ref_layout_modules(0)
+    params2 = list(nerf2.parameters()) + list(sdf2.parameters()) + list(dev2.parameters()) + list(col2.parameters())
+    fa = R.FlatAdam(params2, lr=1e-3)
+    fa.load_state_dict(sd)
+    assert fa.active == list(range(n_nerf, len(params2))) and fa.step_count == 2
+    assert fa.param_groups[0]["lr"] == 5e-4
+    out = fa.state_dict()
+    assert out["param_groups"][0]["params"] == list(range(len(params2)))
+    assert set(out["state"].keys()) == set(sd["state"].keys())
+    for i, st in sd["state"].items():
+        assert torch.equal(out["state"][i]["exp_avg"], st["exp_avg"]), i
+        assert torch.equal(out["state"][i]["exp_avg_sq"], st["exp_avg_sq"]), i
+        assert float(out["state"][i]["step"]) == float(st["step"]) == 2.0
+    # ... and torch's Adam over the same list accepts FlatAdam's dict and continues from it
+    opt3 = torch.optim.Adam(params2, lr=1.0)
+    opt3.load_state_dict(out)
+    for p in params2[n_nerf:]:
+        p.grad = torch.zeros_like(p)
+    opt3.step()
+    assert opt3.param_groups[0]["lr"] == 5e-4
+    assert float(opt3.state_dict()["state"][n_nerf]["step"]) == 3.0
+
+    # mismatching lists are refused with a clear message instead of loading shifted
+    with pytest.raises(ValueError, match="same list"):
+        R.FlatAdam(params2[n_nerf:]).load_state_dict(sd)
+    swapped = list(params2)
+    swapped[n_nerf], swapped[n_nerf + 2] = swapped[n_nerf + 2], swapped[n_nerf]
+    with pytest.raises(ValueError, match="shape"):
+        R.FlatAdam(swapped).load_state_dict(sd)
+
+
+def test_reference_layout_checkpoint_fixture_loads():
+    """tests/golden/ref_ckpt_tiny.pth was written by the REFERENCE's modules and torch.optim.Adam in the reference's
+    layout (oracle/gen_golden.py::checkpoint_case).  It must load (weights_only) into the drop-in modules and FlatAdam."""
+    from rnb_neus_fork_amd import checkpoint as CK
+    import numpy as np
+    path = os.path.join(ROOT, "tests", "golden", "ref_ckpt_tiny.pth")
+    nerf, sdf, dev, col = _ref_layout_modules(123)
+    params = list(nerf.parameters()) + list(sdf.parameters()) + list(dev.parameters()) + list(col.parameters())
+    fa = R.FlatAdam(params, lr=1.0)
+    it = CK.load_checkpoint(path, nerf, sdf, dev, col, fa)
+    assert it == 2 and fa.step_count == 2 and fa.param_groups[0]["lr"] == 5e-4
+    raw = torch.load(path, weights_only=True)
+    assert list(raw["sdf_network_fine"].keys()) == list(sdf.state_dict().keys())
+    assert all(torch.equal(raw["sdf_network_fine"][k], v) for k, v in sdf.state_dict().items())
+    assert all(torch.equal(raw["nerf"][k], v) for k, v in nerf.state_dict().items())
+    n_nerf = len(list(nerf.parameters()))
+    assert fa.active == list(range(n_nerf, len(params)))
+    st = raw["optimizer"]["state"]
+    mine = fa.state_dict()["state"]
+    assert set(mine.keys()) == set(st.keys())
+    assert all(torch.equal(mine[i]["exp_avg_sq"], st[i]["exp_avg_sq"]) for i in st)
+
+
 def test_package_synthetic_batches_equal_the_oracle_generator():
     """bench.py's measured leg draws its rays from the package, the CPU baseline from the oracle: same workload."""
     from rnb_neus_fork_amd import synthetic as S
@@ -176,8 +258,10 @@ def test_package_synthetic_batches_equal_the_oracle_generator():
 
 def test_cpu_tensors_are_rejected_by_the_train_helpers():
     """No CPU path anywhere: the loss, the flat optimizer and the ray generator refuse host tensors."""
+    q = torch.nn.Parameter(torch.zeros(3))
+    q.grad = torch.ones(3)
     with pytest.raises(RuntimeError, match="GPU"):
-        R.FlatAdam([torch.nn.Parameter(torch.zeros(3))])
+        R.FlatAdam([q]).step()
     with pytest.raises(RuntimeError, match="GPU"):
         R.rnb_loss({"color_fine": torch.zeros(3, 4, 3), "weight_sum": torch.zeros(4, 1),
                     "gradient_error": torch.zeros(())}, torch.zeros(3, 4, 3), torch.zeros(4, 1))

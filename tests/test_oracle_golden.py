@@ -34,13 +34,51 @@ def test_sampling_indices_bit_exact(name):
     trace = {}
     perturb = g.mc.render.perturb if g.perturb_overwrite < 0 else g.perturb_overwrite
     z = O.sample_rays(p, g.mc, b["rays_o"], b["rays_d"], b["near"], b["far"], b["t_rand"], perturb, trace)
-    assert len(trace["steps"]) == g.n_steps
-    for i, (mine, ref) in enumerate(zip(trace["steps"], g.steps)):
+    assert len(trace.get("steps", [])) == g.n_steps
+    for i, (mine, ref) in enumerate(zip(trace.get("steps", []), g.steps)):
         assert torch.equal(mine["inds"], ref["inds"]), f"step {i} searchsorted indices"
         assert torch.equal(mine["sort_index"], ref["sort_index"]), f"step {i} sort index"
         assert torch.equal(mine["new_z"], ref["new_z"]), f"step {i} new z"
         assert torch.equal(mine["z_out"], ref["z_out"]), f"step {i} merged z"
-    assert torch.equal(z, g.steps[-1]["z_out"])
+    assert torch.equal(z, g.z_fine)
+
+
+def test_weight_norm_rounding_is_amplified_by_the_up_sampling_loop():
+    """DESIGN.md 2, Finding: end-to-end sample indices cannot be bit-exact across implementations.  The oracle with
+    the reference's own weight-norm primitive reproduces every index of the fixtures (test above); the SAME oracle
+    with the mathematically equal expression g * v / ||v|| (a different summation order of the row norm: last-bit
+    differences of the effective weights) already lands on different searchsorted results in some rays, while its
+    depths stay statistically on top of the reference's.  Hence the GPU path is held to: indices bit-exact per step on
+    identical inputs, and end-to-end z_vals statistically (tests/test_gpu_parity.py::test_sample_rays_end_to_end)."""
+    flipped_rays, total_rays, within = 0, 0, []
+    orig = O.effective_weight
+    for name in [c for c in CASES if Golden(c).n_steps > 0]:
+        g = Golden(name)
+        p, b = g.params(), g.batch
+        perturb = g.mc.render.perturb if g.perturb_overwrite < 0 else g.perturb_overwrite
+
+        def alt(pp, prefix):
+            if prefix + ".weight" in pp:
+                return pp[prefix + ".weight"]
+            v = pp[prefix + ".weight_v"]
+            return pp[prefix + ".weight_g"] * (v / torch.sqrt((v.double() ** 2).sum(dim=1, keepdim=True)).float())
+
+        O.effective_weight = alt
+        try:
+            trace = {}
+            z = O.sample_rays(p, g.mc, b["rays_o"], b["rays_d"], b["near"], b["far"], b["t_rand"], perturb, trace)
+        finally:
+            O.effective_weight = orig
+        same = torch.ones(z.shape[0], dtype=torch.bool)
+        for mine, ref in zip(trace["steps"], g.steps):
+            same &= (mine["inds"] == ref["inds"]).all(dim=1)
+        flipped_rays += int((~same).sum())
+        total_rays += z.shape[0]
+        within.append(float(((z - g.z_fine).abs() < 1e-4).float().mean()))
+    print(f"re-expressed weight norm: {flipped_rays} of {total_rays} rays change at least one searchsorted index; "
+          f"z within 1e-4: min {min(within):.4f}")
+    assert flipped_rays > 0, "the perturbation was expected to flip at least one index (the amplification exists)"
+    assert min(within) > 0.97, "the depths must stay statistically on the reference's"
 
 
 @pytest.mark.parametrize("name", CASES)

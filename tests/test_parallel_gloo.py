@@ -34,6 +34,25 @@ def _worker(rank, world, port, q):
     ref = 0.5 * torch.stack([batch["rays_d"].sum(), batch["near"].sum(), batch["true_rgb"].sum()]).float()
     P.allreduce_mean_(flat)
     ok = ok and torch.allclose(flat, ref, rtol=1e-5, atol=1e-5)
+    # exact large-batch semantics: the global normalisers every rank divides by, and the SUM of the
+    # per-rank additive shares of the loss == the single-process loss of the whole batch (checked with the oracle's
+    # loss terms: shard numerators over global denominators)
+    cnt = P.global_mask_count(mine["mask"], True)
+    ok = ok and float(cnt[0]) == float((batch["mask"] > 0.5).sum()) and float(cnt[1]) == 16.0
+    cnt1 = P.global_mask_count(mine["mask"], False)
+    ok = ok and float(cnt1[0]) == 16.0
+    g = torch.Generator().manual_seed(5)
+    color = torch.rand(3, 16, 3, generator=g)
+    wsum = torch.rand(16, 1, generator=g)
+    full_out = {"color_fine": color, "weight_sum": wsum, "gradient_error": torch.tensor(0.25)}
+    full_loss = O.rnb_loss(full_out, batch["true_rgb"], batch["mask"])[0]
+    m = (mine["mask"] > 0.5).float()
+    share = ((color[:, lo:hi] - mine["true_rgb"]) * m[None]).abs().sum() / ((cnt[0] + 1e-5) * 3) \
+        + 0.1 * 0.25 / world \
+        + 0.1 * torch.nn.functional.binary_cross_entropy(wsum[lo:hi].clip(1e-3, 1 - 1e-3), m, reduction="sum") / cnt[1]
+    tot = share.reshape(1).clone()
+    P.allreduce_sum_(tot)
+    ok = ok and torch.allclose(tot[0], full_loss, rtol=1e-5, atol=1e-6)
     w = torch.nn.Linear(4, 4)
     if rank == 1:
         with torch.no_grad():
