@@ -193,8 +193,13 @@ def _device_sampling_trace(R, g, sdf, b, z0):
 # fraction of rays whose four searchsorted index rows ALL equal the reference's, per fixture; the thresholds sit just
 # under the measurements.  (The CPU oracle itself drops to 0.984 / 232 of 240 rays when only its weight-norm
 # expression is re-associated: tests/test_oracle_golden.py::test_weight_norm_rounding_is_amplified...)
-E2E_MIN = {}   # name -> (min frac of z within 1e-4, min frac of rays with identical indices); default below
-E2E_DEFAULT = (0.99, 0.90)
+E2E_MIN = {    # name -> (min frac of z within 1e-4, min frac of rays with identical indices); measured in comments
+    "full_main_noalbedo": (0.993, 0.85),    # 0.9951, 28/32
+    "full_main_sharp": (0.995, 0.95),       # 0.9967, 63/64
+    "full_render_sharp": (0.996, 0.93),     # 0.9983, 31/32
+    "full_warmup_geo": (0.995, 0.95),       # 0.9965, 63/64
+}
+E2E_DEFAULT = (1.0, 1.0)                    # tiny_*: every z within 1e-4 (max 9e-6), every index identical
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -311,12 +316,13 @@ def test_fine_pass_golden(R, name):
     # and directly against the fp32 reference's gradients (every stored element)
     for k, ref in g.grads.items():
         mine = named[k].grad.detach().cpu().reshape(-1)[:: g.grad_stride]
-        denom = g.gradnorm[k] / np.sqrt(g.grad_stride)
         if g.gradnorm[k] < 1e-10:
             assert float(mine.abs().max()) < 1e-8, k
             continue
-        rel = float((mine - ref).double().norm()) / denom
-        assert rel <= max(1e-4, (1.0 + K_GRAD) * g.rel32.get(k, 0.0)) * 1.5, f"{k}: rel-L2 vs the fp32 reference {rel:.3e}"
+        rel = float((mine - ref).double().norm() / ref.double().norm())
+        # triangle inequality through the fp64 result: (K_GRAD + 1) x the fp32 reference's own error
+        assert rel <= max(2e-4, (1.0 + K_GRAD) * max(g.rel32.get(k, 0.0), g.rel32s.get(k, 0.0))), \
+            f"{k}: rel-L2 vs the fp32 reference {rel:.3e}"
     print(f"FINE {name}: worst output error ratio hip/ref32 = {worst_out[1]:.2f} ({worst_out[0]}); worst gradient: "
           f"{worst[0]} rel-L2 vs fp64 {worst[2]:.2e} = {worst[1]:.2f} of its bound")
 

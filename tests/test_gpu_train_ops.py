@@ -99,12 +99,27 @@ def test_flat_adam_matches_torch_adam(R, flat_grads):
     assert torch.equal(opt2.exp_avg, opt.exp_avg)
 
 
-def test_flat_adam_needs_all_grads(R):
+def test_flat_adam_skips_gradless_parameters_like_torch(R):
+    """exp_runner.py:105-115 hands Adam the NeRF parameters too; they never get a gradient.  Like torch's Adam,
+    FlatAdam carries them by position and trains the rest; a later change of the trained set is an error."""
     dev = torch.device("cuda:0")
     ps = _param_set(dev, 2)
-    opt = R.FlatAdam(ps)
+    before = [p.detach().clone() for p in ps]
+    opt = R.FlatAdam(ps, lr=1e-2)
+    ref = torch.optim.Adam([p.detach().clone().requires_grad_(True) for p in ps], lr=1e-2)
+    rp = ref.param_groups[0]["params"]
+    for i in (1, 3):
+        ps[i].grad = torch.ones_like(ps[i])
+        rp[i].grad = torch.ones_like(rp[i])
+    opt.step()
+    ref.step()
+    assert opt.active == [1, 3]
+    for i, p in enumerate(ps):
+        torch.testing.assert_close(p.detach(), rp[i].detach(), rtol=1e-6, atol=1e-7)
+        assert torch.equal(p.detach(), before[i]) == (i not in (1, 3))
+    assert set(opt.state_dict()["state"].keys()) == set(ref.state_dict()["state"].keys()) == {1, 3}
     ps[0].grad = torch.zeros_like(ps[0])
-    with pytest.raises(RuntimeError, match="every parameter"):
+    with pytest.raises(RuntimeError, match="changed"):
         opt.step()
 
 
