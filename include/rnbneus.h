@@ -259,6 +259,13 @@ int rnb_render_bwd(const rnb_model_desc* desc, const float* packed, const rnb_re
 int rnb_algorithmic_flops(const rnb_model_desc* desc, int64_t B, int32_t flags, double* train_flops,
                           double* forward_flops);
 
+/* Algorithmic HBM bytes of the per-point saved state one training step (rnb_render_fwd + rnb_render_bwd) moves when
+ * every saved matrix is written once and read once by each kernel that consumes it — the traffic floor of the
+ * "store, don't recompute" design, which is what bounds the RNB_VARIANT_BF16 step.  Per point:
+ * SDF sweeps 15 * n_layers * d_hidden elements (6 matrices written, 9 matrix reads per layer; 2 bytes each with
+ * RNB_VARIANT_BF16, else 4) + the albedo network's fp32 activations. */
+int rnb_algorithmic_bytes(const rnb_model_desc* desc, int64_t B, int32_t flags, double* train_bytes);
+
 /* Ray / target generation of one train_rnb step on the device: what Dataset.ps_gen_random_rays_at_view_on_all_lights
  * (models/dataset.py:351-376), the per-pixel light gather (exp_runner.py:214-220) and near_far_from_sphere
  * (models/dataset.py:448-458) compute on the host, for one view whose tensors are resident in device memory.

@@ -17,7 +17,7 @@ RNB_API int rnb_packed_floats(const rnb_model_desc* desc, int64_t* n_floats) {
   RNB_REQUIRE(n_floats, "n_floats");
   Layout L;
   RNB_TRY(make_layout(desc, &L));
-  *n_floats = L.total;
+  *n_floats = L.total_all;
   return RNB_OK;
 }
 
@@ -26,7 +26,9 @@ RNB_API int rnb_weightnorm_fwd(const rnb_model_desc* desc, const rnb_mlp_params*
   RNB_REQUIRE(packed, "packed");
   Layout L;
   RNB_TRY(make_layout(desc, &L));
-  return weightnorm_fwd(desc, L, sdf, color, packed, (hipStream_t)stream);
+  RNB_TRY(weightnorm_fwd(desc, L, sdf, color, packed, (hipStream_t)stream));
+  if (is_bf16(L)) RNB_TRY(bf16_pack_weights(L, packed, (hipStream_t)stream));   // bf16 mirror behind the fp32 weights
+  return RNB_OK;
 }
 
 RNB_API int rnb_weightnorm_bwd(const rnb_model_desc* desc, const rnb_mlp_params* sdf, const rnb_mlp_params* color,
@@ -69,6 +71,11 @@ static int points_setup(const rnb_model_desc* desc, int64_t n, void* ws, size_t 
 static bool use_fused(const Layout& L) { return !(L.variant & RNB_VARIANT_GENERIC) && fused_supported(L); }
 static int forward_points(const Layout& L, const float* packed, const float* pts, int64_t n, PointBufs& pb,
                           bool save, bool need_feat, bool need_gz_last, float* feat_dense, hipStream_t s) {
+  if (is_bf16(L)) {
+    RNB_TRY(bf16_forward(L, packed, pts, n, pb, save, need_feat, s));
+    if (need_feat && feat_dense) RNB_TRY(launch_copy_cols(pb.cin, L.Cinp, L.F, n, feat_dense, s));
+    return RNB_OK;
+  }
   if (use_fused(L)) {
     RNB_TRY(fused_forward(L, packed, pts, n, pb, save, need_feat, need_gz_last, s));
     if (need_feat && feat_dense) RNB_TRY(launch_copy_cols(pb.cin, L.Cinp, L.F, n, feat_dense, s));
@@ -80,6 +87,7 @@ static int forward_points(const Layout& L, const float* packed, const float* pts
 
 // reverse-mode normal: fused sweep (seeds itself from D_last) or the generic chain (seeded by the forward)
 static int reverse_points(const Layout& L, const float* packed, PointBufs& pb, hipStream_t s) {
+  if (is_bf16(L)) return bf16_reverse(L, packed, pb, s);
   if (use_fused(L)) return fused_reverse(L, packed, pb, s);
   return sweep_reverse(L, packed, pb, s);
 }
@@ -109,7 +117,7 @@ RNB_API int rnb_sdf_gradient(const rnb_model_desc* desc, const float* packed, co
   Layout L;
   PointBufs pb;
   RNB_TRY(points_setup(desc, n, ws, ws_bytes, &L, &pb));
-  RNB_TRY(forward_points(L, packed, pts, n, pb, true, false, !use_fused(L), nullptr, s));
+  RNB_TRY(forward_points(L, packed, pts, n, pb, true, false, !use_fused(L) && !is_bf16(L), nullptr, s));
   RNB_TRY(reverse_points(L, packed, pb, s));
   RNB_TRY(launch_copy_cols(pb.nrm, 4, 3, n, grad_out, s));
   if (sdf_out) RNB_CHECK_HIP(hipMemcpyAsync(sdf_out, pb.sdf, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -166,7 +174,7 @@ RNB_API int rnb_sdf_grid_workspace_bytes(const rnb_model_desc* desc, const rnb_g
   RNB_TRY(make_layout(desc, &L));
   int64_t n;
   RNB_TRY(check_grid(grid, &n));
-  if (use_fused(L)) { *bytes = 256; return RNB_OK; }   // the fused sweep keeps everything in LDS
+  if (use_fused(L) || is_bf16(L)) { *bytes = 256; return RNB_OK; }   // the fused sweep keeps everything in LDS
   Carver c(nullptr, 0);
   PointBufs pb;
   c.take<float>(kGridChunk * 3);
@@ -186,12 +194,13 @@ RNB_API int rnb_sdf_grid(const rnb_model_desc* desc, const float* packed, const 
   RNB_TRY(check_grid(grid, &n));
   if (n == 0) return RNB_OK;
   const GridGen gg = grid_gen_of(grid);
-  if (use_fused(L)) {
+  if (use_fused(L) || is_bf16(L)) {
     PointBufs pb;
     memset(&pb, 0, sizeof(pb));
     pb.M = n;
     pb.Mp = pad_rows(n);
     pb.sdf = volume;   // grid mode writes rows < M only
+    if (is_bf16(L)) return bf16_forward(L, packed, nullptr, n, pb, false, false, s, &gg);
     return fused_forward(L, packed, nullptr, n, pb, false, false, false, s, &gg);
   }
   RNB_REQUIRE(ws, "workspace");
@@ -446,7 +455,7 @@ RNB_API int rnb_render_fwd(const rnb_model_desc* desc, const float* packed, cons
   const bool use_color = (mode & PM_WITH_COLOR) != 0;
   RNB_TRY(launch_fine_points(a->rays_o, a->rays_d, a->z_vals, a->B, a->S, 2.0f / (float)desc->n_samples, rb.pts,
                              rb.dists, s));
-  RNB_TRY(forward_points(L, packed, rb.pts, a->B * a->S, rb.pb, true, use_color, !use_fused(L), nullptr, s));
+  RNB_TRY(forward_points(L, packed, rb.pts, a->B * a->S, rb.pb, true, use_color, !use_fused(L) && !is_bf16(L), nullptr, s));
   RNB_TRY(reverse_points(L, packed, rb.pb, s));
   if (use_color) RNB_TRY(sweep_color(L, packed, rb.pb, rb.pts, rb.pb.nrm, 4, s));
   CompArgs c = comp_args_of(L, a, rb);
@@ -495,6 +504,26 @@ RNB_API int rnb_render_bwd(const rnb_model_desc* desc, const float* packed, cons
 RNB_API int rnb_profile_enable(int on) { return profile_enable(on); }
 RNB_API int rnb_profile_collect(double* gemm_ms, int64_t* gemm_launches, double* gemm_flops) {
   return profile_collect(gemm_ms, gemm_launches, gemm_flops);
+}
+
+RNB_API int rnb_algorithmic_bytes(const rnb_model_desc* desc, int64_t B, int32_t flags, double* train_bytes) {
+  RNB_REQUIRE(train_bytes, "train_bytes");
+  Layout L;
+  RNB_TRY(make_layout(desc, &L));
+  const bool use_color = !((flags & RNB_MODE_MVPS) && (flags & RNB_FLAG_NO_ALBEDO));
+  const double e = is_bf16(L) ? 2.0 : 4.0;
+  const int S = desc->n_samples + desc->n_importance;
+  // SDF sweeps: a, D, gz, u, zR, zb written once; D read by R, RA, FB; gz by RA, dW; zR by FB; u, zb, a by dW
+  double per_pt = 15.0 * L.nh * L.Hp * e;
+  per_pt += 2.0 * L.Ep * e * 2.0;   // e and u_0: written once, read once (layer 0's weight gradient)
+  if (use_color) {
+    // fp32 in both variants: cin (1 write, 2 reads), ac_l (1 write, reads: next layer, relu mask, dW), zc_l (1 write,
+    // 2 reads), cinb (1 write, read by FB and by the normal's adjoint)
+    per_pt += 4.0 * (3.0 * L.Cinp + 4.0 * L.Hcp + 3.0 * L.Hcp * (L.nc - 1) + 3.0 * L.Hcp * L.nc + 2.0 * L.Cinp);
+    per_pt += e * 2.0 * L.Hp;         // feature head's weight gradient: fbar and a_last
+  }
+  *train_bytes = per_pt * (double)B * S;
+  return RNB_OK;
 }
 
 // Algorithmic MLP FLOPs: multiply-accumulate counts of the real (unpadded) layer shapes.

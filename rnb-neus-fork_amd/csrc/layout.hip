@@ -104,7 +104,14 @@ int make_layout(const rnb_model_desc* d, Layout* L) {
     }
     place(L->colo, L->Co, L->Hc, 1.f, off);
   }
-  L->total = off;
+  L->total = (off + 31) / 32 * 32;
+  L->total_all = L->total;
+  if (d->variant & RNB_VARIANT_BF16) {
+    if (!fused_supported(*L))
+      RNB_FAIL(RNB_E_INVALID, "RNB_VARIANT_BF16 needs the 256-wide SDF network shape (d_hidden 256, feature width <= 256)");
+    if (d->variant & RNB_VARIANT_GENERIC) RNB_FAIL(RNB_E_INVALID, "RNB_VARIANT_BF16 and RNB_VARIANT_GENERIC exclude each other");
+    L->total_all = L->total + L->total / 2;   // bf16 mirror of the weights behind the fp32 ones
+  }
   return RNB_OK;
 }
 
@@ -113,13 +120,16 @@ void carve_points(const Layout& L, Carver& c, int64_t M, int mode, PointBufs* pb
   pb->M = M;
   pb->Mp = pad_rows(M);
   const int64_t Mp = pb->Mp;
+  const bool bf = (L.variant & RNB_VARIANT_BF16) != 0;
+  // RNB_VARIANT_BF16: the per-point state of the SDF sweeps is bf16 (K8 layout, bf16.hip): half the bytes
+  auto take_state = [&](int64_t n) { return bf ? reinterpret_cast<float*>(c.take<uint16_t>(n)) : c.take<float>(n); };
   pb->x = c.take<float>(Mp * 4);
   pb->e = c.take<float>(Mp * L.Ep);
-  for (int l = 0; l < L.nh; ++l) pb->a[l] = c.take<float>(Mp * L.Hp);
+  for (int l = 0; l < L.nh; ++l) pb->a[l] = take_state(Mp * L.Hp);
   pb->sdf = c.take<float>(Mp);
   if (mode & (PM_WITH_NORMAL | PM_WITH_COLOR | PM_WITH_BACKWARD)) {
-    for (int l = 0; l < L.nh; ++l) pb->gz[l] = c.take<float>(Mp * L.Hp);
-    for (int l = 0; l < L.nh; ++l) pb->D[l] = c.take<float>(Mp * L.Hp);
+    for (int l = 0; l < L.nh; ++l) pb->gz[l] = take_state(Mp * L.Hp);
+    for (int l = 0; l < L.nh; ++l) pb->D[l] = take_state(Mp * L.Hp);
     pb->ge = c.take<float>(Mp * L.Ep);
     pb->nrm = c.take<float>(Mp * 4);
   }
@@ -129,9 +139,13 @@ void carve_points(const Layout& L, Carver& c, int64_t M, int mode, PointBufs* pb
     pb->alb = c.take<float>(Mp * 4);
   }
   if (mode & PM_WITH_BACKWARD) {
-    for (int l = 1; l <= L.nh; ++l) pb->u[l] = c.take<float>(Mp * L.Hp);
-    for (int l = 0; l < L.nh; ++l) pb->zR[l] = c.take<float>(Mp * L.Hp);
-    for (int l = 0; l < L.nh; ++l) pb->zb[l] = c.take<float>(Mp * L.Hp);
+    for (int l = 1; l <= L.nh; ++l) pb->u[l] = take_state(Mp * L.Hp);
+    for (int l = 0; l < L.nh; ++l) pb->zR[l] = take_state(Mp * L.Hp);
+    for (int l = 0; l < L.nh; ++l) pb->zb[l] = take_state(Mp * L.Hp);
+    if (bf) {
+      pb->u0_k8 = c.take<uint16_t>(Mp * L.Ep);
+      pb->fbar_k8 = c.take<uint16_t>(Mp * L.Hp);
+    }
     pb->geb = c.take<float>(Mp * L.Ep);
     pb->sbar = c.take<float>(Mp);
     pb->nbar = c.take<float>(Mp * 4);
@@ -141,7 +155,8 @@ void carve_points(const Layout& L, Carver& c, int64_t M, int mode, PointBufs* pb
       pb->cinb = c.take<float>(Mp * L.Cinp);
     }
     if (L.variant & RNB_VARIANT_DETERMINISTIC) {
-      pb->dw_part_floats = dw_partial_floats(L, M, (mode & PM_WITH_COLOR) != 0);
+      pb->dw_part_floats = dw_partial_floats(L, M, (mode & PM_WITH_COLOR) != 0) +
+                           (bf ? bf16_dw_partial_floats(L, M, (mode & PM_WITH_COLOR) != 0) : 0);
       pb->dw_part = c.take<float>(pb->dw_part_floats);
     }
   }

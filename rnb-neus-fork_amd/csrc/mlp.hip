@@ -858,6 +858,12 @@ int sweep_backward(const Layout& L, const float* packed, PointBufs& pb, bool wit
                        L.multires, L.Ep, M, Mp, pb.geb);
   }
   RNB_CHECK_LAUNCH();
+  if (is_bf16(L)) {
+    // RNB_VARIANT_BF16: RA, the sdf-head row, FB and every weight gradient of the SDF network (+ feature head) run as
+    // bf16 sweeps on the bf16 saved state; the albedo net's own (fp32) weight-gradient jobs were queued above
+    RNB_TRY(dw.flush_all());
+    return bf16_backward(L, packed, pb, with_color, packed_grad, s);
+  }
   // ---- RA: adjoint of the reverse sweep, forward layer order -----------------------------------------
   if (fused) {
     RNB_TRY(fused_ra(L, packed, pb, s));

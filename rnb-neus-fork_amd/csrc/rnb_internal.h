@@ -67,7 +67,8 @@ struct Layout {
   Lin colo;               // output layer
   int multires_view;
   int squeeze;
-  int64_t total;          // floats in the packed buffer
+  int64_t total;          // floats of fp32 packed weights (also the length of a gradient buffer)
+  int64_t total_all;      // floats of the packed buffer = total (+ total / 2 for the bf16 mirror, RNB_VARIANT_BF16)
   int variant;            // rnb_model_desc.variant (RNB_VARIANT_* bits)
   int knob(int shift) const { return (variant >> shift) & 3; }
 };
@@ -135,6 +136,8 @@ struct PointBufs {
   float* sbar;    // [Mp]
   float* nbar;    // [Mp,4]
   float* albbar;  // [Mp,4]
+  void* u0_k8;              // RNB_VARIANT_BF16: u_0 = J_pe nbar as bf16 K8 [Mp,Ep]   (written by the RA sweep)
+  void* fbar_k8;            // RNB_VARIANT_BF16: feature part of cinb as bf16 K8 [Mp,256] (written by the FB sweep)
   float* dw_part;           // RNB_VARIANT_DETERMINISTIC: partial slabs of the split-K weight-gradient GEMMs
   int64_t dw_part_floats;
 };
@@ -164,6 +167,15 @@ int fused_forward(const Layout& L, const float* packed, const float* pts, int64_
                   bool need_feat, bool need_gz_last, hipStream_t s, const GridGen* grid = nullptr);
 int launch_grid_points(const GridGen& g, int64_t first, int64_t n, float* pts, hipStream_t s);
 int launch_scale_copy(const float* src, float scale, int64_t n, float* dst, hipStream_t s);
+
+// ---- RNB_VARIANT_BF16 (bf16.hip): bf16-operand sweeps of the 256-wide network, saved state in bf16 "K8" layout ----
+inline bool is_bf16(const Layout& L) { return (L.variant & RNB_VARIANT_BF16) != 0; }
+int bf16_pack_weights(const Layout& L, float* packed, hipStream_t s);
+int bf16_forward(const Layout& L, const float* packed, const float* pts, int64_t M, PointBufs& pb, bool save, bool need_feat,
+                 hipStream_t s, const GridGen* grid = nullptr);
+int bf16_reverse(const Layout& L, const float* packed, PointBufs& pb, hipStream_t s);
+int bf16_backward(const Layout& L, const float* packed, PointBufs& pb, bool with_color, float* packed_grad, hipStream_t s);
+int64_t bf16_dw_partial_floats(const Layout& L, int64_t M, bool with_color);
 
 // ---- sampling / composite ------------------------------------------------------------------------
 int launch_up_sample_step(const float* rays_o, const float* rays_d, const float* z_in, const float* sdf_old,

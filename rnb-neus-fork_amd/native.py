@@ -104,6 +104,7 @@ _SIGNATURES = {
     "rnb_render_bwd": (C.c_int, [_P(ModelDesc), C.c_void_p, _P(RenderArgs), _P(RenderGrads), C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "rnb_algorithmic_flops": (C.c_int, [_P(ModelDesc), C.c_int64, C.c_int32, _P(C.c_double), _P(C.c_double)]),
+    "rnb_algorithmic_bytes": (C.c_int, [_P(ModelDesc), C.c_int64, C.c_int32, _P(C.c_double)]),
     "rnb_gen_rays_at_view": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                        C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

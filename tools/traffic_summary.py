@@ -1,5 +1,6 @@
 """Builds profiles/hbm_traffic.json from two rocprofv3 PMC passes (development / evidence tool).
-usage: python tools/traffic_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <steps> <rays>"""
+usage: python tools/traffic_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <steps> <rays>
+           [<samples per ray> [<output json under profiles/>]]"""
 import collections
 import csv
 import json
@@ -18,7 +19,9 @@ def load(path, counter):
 f = load(sys.argv[1], "FETCH_SIZE")
 w = load(sys.argv[2], "WRITE_SIZE")
 steps, rays = int(sys.argv[3]), int(sys.argv[4])
-fam = [k for k in set(f) | set(w) if "gemm_" in k or "fused_" in k]
+samples = int(sys.argv[5]) if len(sys.argv) > 5 else 128
+out_name = sys.argv[6] if len(sys.argv) > 6 else "hbm_traffic.json"
+fam = [k for k in set(f) | set(w) if "gemm_" in k or "fused_" in k or "bf_" in k]
 per_kernel = {}
 tot_f = tot_w = n = 0
 for k in sorted(fam):
@@ -29,7 +32,7 @@ for k in sorted(fam):
     tot_f += sum(f.get(k, [0]))
     tot_w += sum(w.get(k, [0]))
     n += nf
-out = {"rays": rays, "steps": steps, "launches_per_step": n / steps,
+out = {"rays": rays, "samples": samples, "steps": steps, "launches_per_step": n / steps,
        "fetch_size_raw_bytes_per_step": tot_f / steps * 1024,
        "fetch_bytes_per_step_corrected_x2": 2 * tot_f / steps * 1024,
        "write_bytes_per_step": tot_w / steps * 1024,
@@ -37,7 +40,7 @@ out = {"rays": rays, "steps": steps, "launches_per_step": n / steps,
        "hbm_bytes_per_launch": (2 * tot_f + tot_w) / steps * 1024 / (n / steps),
        "per_kernel": per_kernel,
        "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over bench.py; MFMA-family "
-               "kernels only (gemm_*, fused_*). FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B "
+               "kernels only (gemm_*, fused_*, bf_*). FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B "
                "requests at 64 B); WRITE_SIZE taken as is. Infinity-Cache hits are included in FETCH_SIZE."}
-json.dump(out, open("profiles/hbm_traffic.json", "w"), indent=1)
+json.dump(out, open("profiles/" + out_name, "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if k != "per_kernel"}, indent=1))
