@@ -71,6 +71,8 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--no-gemm-events", action="store_true")
     ap.add_argument("--deterministic", action="store_true", help="ordered reductions instead of fp32 atomics")
+    ap.add_argument("--fwd-ti", type=int, default=0, help="A/B knob: tile rows per wave of the forward sweep (1 | 2)")
+    ap.add_argument("--bwd-ti", type=int, default=0, help="A/B knob: tile rows per wave of the backward sweeps (1 | 2)")
     ap.add_argument("--torch-train-ops", action="store_true",
                     help="loss as the reference's chain of torch ops and torch.optim.Adam(fused=True) instead of "
                          "the library's one-launch loss and flat Adam")
@@ -221,7 +223,7 @@ def init_distributed(args):
     return world, rank, dev, backend, rehearsal
 
 
-def build_model(R, dev, samples, dtype, deterministic):
+def build_model(R, dev, samples, dtype, deterministic, fwd_ti=0, bwd_ti=0):
     import torch
     # confs/wmask_rnb.conf:53-90, constructed in the order of exp_runner.py:95-100 under seed 0
     torch.manual_seed(0)
@@ -232,7 +234,7 @@ def build_model(R, dev, samples, dtype, deterministic):
                              weight_norm=True, multires_view=4, squeeze_out=True).to(dev)
     ren = R.NeuSRenderer(None, sdf, devnet, col, n_samples=samples // 2, n_importance=samples // 2, n_outside=0,
                          up_sample_steps=4, perturb=1.0)
-    ren.set_variant(bf16=(dtype == "bf16"), deterministic=deterministic)
+    ren.set_variant(bf16=(dtype == "bf16"), deterministic=deterministic, fwd_ti=fwd_ti, bwd_ti=bwd_ti)
     return sdf, devnet, col, ren
 
 
@@ -249,7 +251,7 @@ def run_train(args):
     lib = R.native.load()
 
     S = args.samples
-    sdf, devnet, col, ren = build_model(R, dev, S, args.dtype, args.deterministic)
+    sdf, devnet, col, ren = build_model(R, dev, S, args.dtype, args.deterministic, args.fwd_ti, args.bwd_ti)
     exact_dp = not args.torch_train_ops     # the reference's torch-op loss knows nothing about shards
     if world > 1:
         P.broadcast_parameters([sdf, devnet, col])

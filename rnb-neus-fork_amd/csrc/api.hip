@@ -455,9 +455,15 @@ RNB_API int rnb_render_fwd(const rnb_model_desc* desc, const float* packed, cons
   const bool use_color = (mode & PM_WITH_COLOR) != 0;
   RNB_TRY(launch_fine_points(a->rays_o, a->rays_d, a->z_vals, a->B, a->S, 2.0f / (float)desc->n_samples, rb.pts,
                              rb.dists, s));
-  RNB_TRY(forward_points(L, packed, rb.pts, a->B * a->S, rb.pb, true, use_color, !use_fused(L) && !is_bf16(L), nullptr, s));
+  const bool color_bf16 = is_bf16(L) && use_color && bf16_color_supported(L);
+  if (color_bf16) {   // the feature head writes bf16 K8 straight into the albedo net's input
+    RNB_TRY(bf16_forward(L, packed, rb.pts, a->B * a->S, rb.pb, true, true, s, nullptr, true));
+  } else {
+    RNB_TRY(forward_points(L, packed, rb.pts, a->B * a->S, rb.pb, true, use_color, !use_fused(L) && !is_bf16(L), nullptr, s));
+  }
   RNB_TRY(reverse_points(L, packed, rb.pb, s));
-  if (use_color) RNB_TRY(sweep_color(L, packed, rb.pb, rb.pts, rb.pb.nrm, 4, s));
+  if (color_bf16) RNB_TRY(bf16_color_forward(L, packed, rb.pb, rb.pts, s));
+  else if (use_color) RNB_TRY(sweep_color(L, packed, rb.pb, rb.pts, rb.pb.nrm, 4, s));
   CompArgs c = comp_args_of(L, a, rb);
   RNB_TRY(launch_composite_fwd(c, a->gradient_error, rb.gerr_den, a->gerr_partial, s));
   return RNB_OK;
@@ -517,9 +523,11 @@ RNB_API int rnb_algorithmic_bytes(const rnb_model_desc* desc, int64_t B, int32_t
   double per_pt = 15.0 * L.nh * L.Hp * e;
   per_pt += 2.0 * L.Ep * e * 2.0;   // e and u_0: written once, read once (layer 0's weight gradient)
   if (use_color) {
-    // fp32 in both variants: cin (1 write, 2 reads), ac_l (1 write, reads: next layer, relu mask, dW), zc_l (1 write,
-    // 2 reads), cinb (1 write, read by FB and by the normal's adjoint)
-    per_pt += 4.0 * (3.0 * L.Cinp + 4.0 * L.Hcp + 3.0 * L.Hcp * (L.nc - 1) + 3.0 * L.Hcp * L.nc + 2.0 * L.Cinp);
+    // albedo network: cin (1 write, 2 reads), ac_l (1 write; read by the next layer, the relu mask and a dW), zc_l
+    // (1 write, 2 reads), cinb (1 write; read by FB and by the normal's adjoint).  bf16 too when the bf16 albedo
+    // kernels apply (RNB_VARIANT_BF16 with the shipped shape), else fp32.
+    const double ec = (is_bf16(L) && bf16_color_supported(L)) ? 2.0 : 4.0;
+    per_pt += ec * (3.0 * L.Cinp + 4.0 * L.Hcp + 3.0 * L.Hcp * (L.nc - 1) + 3.0 * L.Hcp * L.nc + 2.0 * L.Cinp);
     per_pt += e * 2.0 * L.Hp;         // feature head's weight gradient: fbar and a_last
   }
   *train_bytes = per_pt * (double)B * S;

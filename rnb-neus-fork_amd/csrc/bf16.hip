@@ -31,7 +31,11 @@ typedef unsigned short bfraw;   // storage type of one bf16 (no arithmetic on it
 
 constexpr int BP = 264;    // LDS pitch (bf16 elements) of an activation row: 528 bytes
 constexpr int BT = 64;     // points per workgroup
-constexpr int BNW = 4;     // waves per workgroup, each 64 rows x 64 columns (2 x 2 MFMA tiles)
+// Every sweep kernel is templated on TI = 32-row MFMA tiles per wave.  TI = 2: 4 waves per workgroup, each all 64 rows x
+// 64 columns.  TI = 1: 8 waves, wave = (row half, column group), 32 rows x 64 columns each: half the accumulator and
+// prefetch registers (<= 128), so two workgroups per CU are 4 waves per SIMD instead of 2.  (Kept as an A/B variant:
+// although the TI = 2 sweeps are parked 46-69 % of the time (SQ_WAIT_ANY), TI = 1 is slower — see bf_ti below.)
+template <int TI> struct BfCfg { static constexpr int NW = 8 / TI; static constexpr int NT = 64 * NW; };
 
 __device__ inline unsigned pack2(float a, float b) {
   bf2 p = {(__bf16)a, (__bf16)b};   // v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN
@@ -50,50 +54,58 @@ __device__ inline size_t k8(int64_t row, int col, int C) { return ((size_t)(row 
 // X: LDS, row-major bf16, pitch BP.  W: global bf16 [N][K] row-major; lane (i, h) streams 16 bytes (k = 8h .. 8h+7 of
 // the 16-k step) of weight row n0 + 32 tj + i per step.  Weight fragments run one 64-k block ahead in a second
 // register set (two alternating sets, no copies).
-__device__ inline void bf_load_b(const bfraw* __restrict__ W, int K, int n0, int Q, int lane, vu4 (&b)[4][2]) {
+// KS = 16-k steps per prefetched weight block: 4 (two register sets of 32) at TI = 2, 2 (two sets of 16) at TI = 1,
+// where four resident waves per SIMD cover the L2 latency instead of a deeper per-wave prefetch.
+template <int KS>
+__device__ inline void bf_load_b(const bfraw* __restrict__ W, int K, int n0, int Q, int lane, vu4 (&b)[KS][2]) {
   const int i = lane & 31, h = lane >> 5;
 #pragma unroll
   for (int tj = 0; tj < 2; ++tj) {
-    const bfraw* p = W + (size_t)(n0 + tj * 32 + i) * K + Q * 64 + h * 8;
+    const bfraw* p = W + (size_t)(n0 + tj * 32 + i) * K + Q * (16 * KS) + h * 8;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) b[s][tj] = *reinterpret_cast<const vu4*>(p + s * 16);
+    for (int s = 0; s < KS; ++s) b[s][tj] = *reinterpret_cast<const vu4*>(p + s * 16);
   }
 }
-__device__ inline void bf_mma_block(const bfraw* __restrict__ X, int Q, int lane, const vu4 (&b)[4][2], v16f (&acc)[2][2]) {
+template <int TI, int KS, int PITCH>
+__device__ inline void bf_mma_block(const bfraw* __restrict__ X, int Q, int lane, const vu4 (&b)[KS][2], v16f (&acc)[TI][2]) {
   const int i = lane & 31, h = lane >> 5;
 #pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    vu4 a[2];
+  for (int s = 0; s < KS; ++s) {
+    vu4 a[TI];
 #pragma unroll
-    for (int ti = 0; ti < 2; ++ti) a[ti] = *reinterpret_cast<const vu4*>(X + (ti * 32 + i) * BP + Q * 64 + s * 16 + h * 8);
+    for (int ti = 0; ti < TI; ++ti) a[ti] = *reinterpret_cast<const vu4*>(X + (ti * 32 + i) * PITCH + Q * (16 * KS) + s * 16 + h * 8);
 #pragma unroll
     for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
-      for (int ti = 0; ti < 2; ++ti)
+      for (int ti = 0; ti < TI; ++ti)
         acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, a[ti]), __builtin_bit_cast(bf8, b[s][tj]),
                                                               acc[ti][tj], 0, 0, 0);
   }
 }
-__device__ inline void bf_zero(v16f (&acc)[2][2]) {
+template <int TI>
+__device__ inline void bf_zero(v16f (&acc)[TI][2]) {
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < TI; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 }
+// X points at the first of the wave's 32 TI rows
+template <int TI, int PITCH = BP>
 __device__ inline void bf_layer_mma(const bfraw* __restrict__ X, const bfraw* __restrict__ W, int K, int n0, int lane,
-                                    v16f (&acc)[2][2]) {
-  bf_zero(acc);
-  const int nQ = K / 64;
-  vu4 b0[4][2], b1[4][2];
-  bf_load_b(W, K, n0, 0, lane, b0);
+                                    v16f (&acc)[TI][2]) {
+  constexpr int KS = TI == 1 ? 2 : 4;
+  bf_zero<TI>(acc);
+  const int nQ = K / (16 * KS);   // (K is a multiple of 64)
+  vu4 b0[KS][2], b1[KS][2];
+  bf_load_b<KS>(W, K, n0, 0, lane, b0);
   for (int Q = 0; Q < nQ; Q += 2) {
-    if (Q + 1 < nQ) bf_load_b(W, K, n0, Q + 1, lane, b1);
-    bf_mma_block(X, Q, lane, b0, acc);
+    if (Q + 1 < nQ) bf_load_b<KS>(W, K, n0, Q + 1, lane, b1);
+    bf_mma_block<TI, KS, PITCH>(X, Q, lane, b0, acc);
     if (Q + 1 < nQ) {
-      if (Q + 2 < nQ) bf_load_b(W, K, n0, Q + 2, lane, b0);
-      bf_mma_block(X, Q + 1, lane, b1, acc);
+      if (Q + 2 < nQ) bf_load_b<KS>(W, K, n0, Q + 2, lane, b0);
+      bf_mma_block<TI, KS, PITCH>(X, Q + 1, lane, b1, acc);
     }
   }
 }
@@ -106,23 +118,41 @@ __device__ inline Quad k8_load_quad(const bfraw* __restrict__ base, int64_t row0
   return Quad{{bf_lo(u.x), bf_hi(u.x), bf_lo(u.y), bf_hi(u.y)}};
 }
 __device__ inline void k8_store_quad(bfraw* __restrict__ base, int64_t row0, int ti, int g, int col, int h, float a, float b,
-                                     float c, float d) {
+                                     float c, float d, int C = FH) {
   const vu2 u = {pack2(a, b), pack2(c, d)};
-  *reinterpret_cast<vu2*>(base + (((size_t)((row0 + ti * 32) >> 3) + g) * FH + col) * 8 + 4 * h) = u;
+  *reinterpret_cast<vu2*>(base + (((size_t)((row0 + ti * 32) >> 3) + g) * C + col) * 8 + 4 * h) = u;
+}
+// 8 rows of one column of an LDS tile (row-major, pitch P) -> one 16-byte K8 unit
+template <int P>
+__device__ inline vu4 lds_gather8(const bfraw* __restrict__ X, int blk, int c) {
+  bfraw v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = X[(blk * 8 + j) * P + c];
+  return vu4{(unsigned)v[0] | ((unsigned)v[1] << 16), (unsigned)v[2] | ((unsigned)v[3] << 16),
+             (unsigned)v[4] | ((unsigned)v[5] << 16), (unsigned)v[6] | ((unsigned)v[7] << 16)};
+}
+// one 16-byte K8 unit -> 8 rows of one column of an LDS tile
+template <int P>
+__device__ inline void lds_scatter8(bfraw* __restrict__ X, int blk, int c, vu4 u) {
+  const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+  for (int j = 0; j < 8; ++j) X[(blk * 8 + j) * P + c] = (bfraw)((j & 1) ? (w[j >> 1] >> 16) : (w[j >> 1] & 0xffffu));
 }
 // a whole [64 x 256] tile of a K8 matrix in accumulator layout (issued early, consumed after the matrix loop)
-struct AuxBf { vu2 q[2][2][4]; };
-__device__ inline void k8_prefetch(const bfraw* __restrict__ base, int64_t row0, int n0, int lane, AuxBf& t) {
+template <int TI> struct AuxBf { vu2 q[TI][2][4]; };
+template <int TI>
+__device__ inline void k8_prefetch(const bfraw* __restrict__ base, int64_t row0, int n0, int lane, AuxBf<TI>& t) {
   const int c = lane & 31, h = lane >> 5;
 #pragma unroll
-  for (int ti = 0; ti < 2; ++ti)
+  for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
     for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
       for (int g = 0; g < 4; ++g)
         t.q[ti][tj][g] = *reinterpret_cast<const vu2*>(base + (((size_t)((row0 + ti * 32) >> 3) + g) * FH + n0 + tj * 32 + c) * 8 + 4 * h);
 }
-__device__ inline float aux_at(const AuxBf& t, int ti, int tj, int r) {
+template <int TI>
+__device__ inline float aux_at(const AuxBf<TI>& t, int ti, int tj, int r) {
   const vu2 u = t.q[ti][tj][r >> 2];
   const unsigned w = (r & 2) ? u.y : u.x;
   return (r & 1) ? bf_hi(w) : bf_lo(w);
@@ -156,7 +186,8 @@ struct BfFwdArgs {
   long long wsdf_off, bsdf_off;
   int with_feat, F, Cinp;
   long long wf_off, bf_off;
-  float* cin;              // [Mp,Cinp] fp32 feature block destination (with_feat)
+  float* cin;              // [Mp,Cinp] fp32 feature block destination (with_feat, cin8 == nullptr)
+  bfraw* cin8;             // [Mp,Cinp] K8 bf16 feature block destination (bf16 albedo path) or nullptr
   float* sdf;              // [Mp]
   float* x4;               // [Mp,4]            (SAVE)
   bfraw* e;                // [Mp,64]  K8       (SAVE) positional encoding = input of layer 0
@@ -165,19 +196,23 @@ struct BfFwdArgs {
   GridGen grid;
 };
 
-template <bool SAVE>
-__global__ __launch_bounds__(64 * BNW, 2) void bf_forward_kernel(BfFwdArgs g) {
+template <bool SAVE, int TI>
+__global__ __launch_bounds__(BfCfg<TI>::NT, TI == 1 ? 4 : 2) void bf_forward_kernel(BfFwdArgs g) {
+  constexpr int NW = BfCfg<TI>::NW, NT = BfCfg<TI>::NT;
   __shared__ __attribute__((aligned(16))) bfraw X[BT * BP];
   __shared__ float E[BT * FEP];     // fp32 copy of the positional encoding for the skip connection
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = wave_id();
   const int64_t row0 = (int64_t)blockIdx.x * BT;
-  const int n0 = wave * 64;
+  const int n0 = (wave & 3) * 64;          // column group of the wave
+  const int rb = (wave >> 2) * 32;         // first row of the wave inside the tile (TI == 1: two row halves)
+  const int64_t rowW = row0 + rb;
+  const bfraw* Xw = X + rb * BP;
   const int h = lane >> 5, cl = lane & 31;
 
   // ---- positional encoding of the tile (fp32 math, models/embedder.py:40-46) ---------------------------------
   {
-    constexpr int PARTS = 64 * BNW / BT;   // 4 threads per point
+    constexpr int PARTS = NT / BT;   // 4 or 8 threads per point
     const int p = tid % BT, part = tid / BT;
     const int64_t row = row0 + p;
     float x[3] = {0.f, 0.f, 0.f};
@@ -222,7 +257,7 @@ __global__ __launch_bounds__(64 * BNW, 2) void bf_forward_kernel(BfFwdArgs g) {
   }
   __syncthreads();
   if (SAVE) {   // e (bf16, K8, 64 columns): the Y operand of layer 0's weight gradient
-    for (int u = tid; u < (BT / 8) * g.Ep; u += 64 * BNW) {
+    for (int u = tid; u < (BT / 8) * g.Ep; u += NT) {
       const int blk = u / g.Ep, c = u - blk * g.Ep;
       bfraw v[8];
 #pragma unroll
@@ -233,9 +268,9 @@ __global__ __launch_bounds__(64 * BNW, 2) void bf_forward_kernel(BfFwdArgs g) {
     }
   }
 
-  v16f acc[2][2];
+  v16f acc[TI][2];
   for (int l = 0; l < g.nh; ++l) {
-    bf_layer_mma(X, g.wbf + g.w_off[l], g.Kp[l], n0, lane, acc);
+    bf_layer_mma<TI>(Xw, g.wbf + g.w_off[l], g.Kp[l], n0, lane, acc);
     lds_barrier();   // every wave has finished reading the input activations (the tile is updated in place)
     const float* bias = g.packed + g.b_off[l];
     const int n_real = g.n_real[l];
@@ -248,7 +283,7 @@ __global__ __launch_bounds__(64 * BNW, 2) void bf_forward_kernel(BfFwdArgs g) {
       const bool real = col < n_real;
       const bool pe_col = pe_tail && !real && col < n_real + g.pe;
 #pragma unroll
-      for (int ti = 0; ti < 2; ++ti) {
+      for (int ti = 0; ti < TI; ++ti) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           float a[4], D[4];
@@ -258,16 +293,16 @@ __global__ __launch_bounds__(64 * BNW, 2) void bf_forward_kernel(BfFwdArgs g) {
           } else {   // only the tile straddling the skip connection's PE columns
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              const int row = ti * 32 + 8 * q + 4 * h + j;
+              const int row = rb + ti * 32 + 8 * q + 4 * h + j;
               if (real) softplus_aD_fast(acc[ti][tj][4 * q + j] + bc, a[j], D[j]);
               else { a[j] = pe_col ? E[row * FEP + (col - n_real)] : 0.f; D[j] = 0.f; }
             }
           }
 #pragma unroll
-          for (int j = 0; j < 4; ++j) X[(ti * 32 + 8 * q + 4 * h + j) * BP + col] = to_bf(a[j]);
+          for (int j = 0; j < 4; ++j) X[(rb + ti * 32 + 8 * q + 4 * h + j) * BP + col] = to_bf(a[j]);
           if (SAVE) {
-            k8_store_quad(g.a[l], row0, ti, q, col, h, a[0], a[1], a[2], a[3]);
-            k8_store_quad(g.D[l], row0, ti, q, col, h, D[0], D[1], D[2], D[3]);
+            k8_store_quad(g.a[l], rowW, ti, q, col, h, a[0], a[1], a[2], a[3]);
+            k8_store_quad(g.D[l], rowW, ti, q, col, h, D[0], D[1], D[2], D[3]);
           }
         }
       }
@@ -282,8 +317,8 @@ __global__ __launch_bounds__(64 * BNW, 2) void bf_forward_kernel(BfFwdArgs g) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) w[u] = ws[lane + 64 * u];
     const float bs = g.packed[g.bsdf_off];
-    for (int rr = 0; rr < BT / BNW; ++rr) {
-      const int row = wave * (BT / BNW) + rr;
+    for (int rr = 0; rr < BT / NW; ++rr) {
+      const int row = wave * (BT / NW) + rr;
       float s = 0.f;
 #pragma unroll
       for (int u = 0; u < 4; ++u) s = fmaf(bf_f(X[row * BP + lane + 64 * u]), w[u], s);
@@ -298,20 +333,29 @@ __global__ __launch_bounds__(64 * BNW, 2) void bf_forward_kernel(BfFwdArgs g) {
   }
   // ---- feature head: rows 1.. of the output layer, written (fp32) into the albedo network's input -------------------
   if (g.with_feat) {
-    bf_layer_mma(X, g.wbf + g.wf_off, FH, n0, lane, acc);
+    bf_layer_mma<TI>(Xw, g.wbf + g.wf_off, FH, n0, lane, acc);
     const float* bias = g.packed + g.bf_off;
 #pragma unroll
     for (int tj = 0; tj < 2; ++tj) {
       const int col = n0 + tj * 32 + cl;
       if (col < g.F) {
         const float bc = bias[col];
+        if (g.cin8 != nullptr) {
 #pragma unroll
-        for (int ti = 0; ti < 2; ++ti)
+          for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            g.cin[(size_t)(row0 + row) * g.Cinp + col] = acc[ti][tj][r] + bc;
-          }
+            for (int q = 0; q < 4; ++q)
+              k8_store_quad(g.cin8, rowW, ti, q, col, h, acc[ti][tj][4 * q] + bc, acc[ti][tj][4 * q + 1] + bc,
+                            acc[ti][tj][4 * q + 2] + bc, acc[ti][tj][4 * q + 3] + bc, g.Cinp);
+        } else {
+#pragma unroll
+          for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int row = rb + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+              g.cin[(size_t)(row0 + row) * g.Cinp + col] = acc[ti][tj][r] + bc;
+            }
+        }
       }
     }
   }
@@ -340,18 +384,24 @@ struct BfBwdArgs {
   float* nrm;           // [Mp,4]      (R)
   const float* geb;     // [Mp,Ep] fp32 row-major (RA)
   const float* sbar;    // [Mp]        (FB)
-  const float* fbar;    // [Mp,ld_fbar] fp32 row-major, first 256 columns, or nullptr (FB, no_albedo)
+  const float* fbar;    // [Mp,ld_fbar] fp32 row-major, first 256 columns, or nullptr (FB; fp32 albedo path)
   int ld_fbar;
+  int fbar_in_k8;       // 1: fbar8 already holds the feature adjoint (bf16 albedo path), read it instead of `fbar`
 };
 
 // R: gz_l = g_l * D_l, g_{l-1} = gz_l W_l, normal = J_pe^T g_e
-__global__ __launch_bounds__(64 * BNW, 2) void bf_reverse_kernel(BfBwdArgs g) {
+template <int TI>
+__global__ __launch_bounds__(BfCfg<TI>::NT, TI == 1 ? 4 : 2) void bf_reverse_kernel(BfBwdArgs g) {
+  constexpr int NW = BfCfg<TI>::NW, NT = BfCfg<TI>::NT;
   __shared__ __attribute__((aligned(16))) bfraw X[BT * BP];
   __shared__ float GE[BT * FEP];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = wave_id();
   const int64_t row0 = (int64_t)blockIdx.x * BT;
-  const int n0 = wave * 64;
+  const int n0 = (wave & 3) * 64;          // column group of the wave
+  const int rb = (wave >> 2) * 32;         // first row of the wave inside the tile (TI == 1: two row halves)
+  const int64_t rowW = row0 + rb;
+  const bfraw* Xw = X + rb * BP;
   const int h = lane >> 5, cl = lane & 31;
 
   // seed: gz_{nh-1} = w_sdf * D_{nh-1}; one K8 unit (8 points of one column) per thread and step
@@ -359,7 +409,7 @@ __global__ __launch_bounds__(64 * BNW, 2) void bf_reverse_kernel(BfBwdArgs g) {
     const bfraw* Dl = g.D[g.nh - 1] + (size_t)(row0 >> 3) * FH * 8;
     bfraw* gzl = g.gz[g.nh - 1] + (size_t)(row0 >> 3) * FH * 8;
     const float* ws = g.packed + g.wsdf_off;
-    for (int u = tid; u < (BT / 8) * FH; u += 64 * BNW) {
+    for (int u = tid; u < (BT / 8) * FH; u += NT) {
       const int blk = u / FH, c = u - blk * FH;
       const vu4 d = *reinterpret_cast<const vu4*>(Dl + (size_t)u * 8);
       const float w = ws[c];
@@ -370,15 +420,15 @@ __global__ __launch_bounds__(64 * BNW, 2) void bf_reverse_kernel(BfBwdArgs g) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) X[(blk * 8 + j) * BP + c] = to_bf(v[j]);
     }
-    for (int idx = tid; idx < BT * FEP; idx += 64 * BNW) GE[idx] = 0.f;
+    for (int idx = tid; idx < BT * FEP; idx += NT) GE[idx] = 0.f;
   }
   __syncthreads();
 
-  v16f acc[2][2];
-  AuxBf aD;
+  v16f acc[TI][2];
+  AuxBf<TI> aD;
   for (int l = g.nh - 1; l >= 1; --l) {
-    k8_prefetch(g.D[l - 1], row0, n0, lane, aD);
-    bf_layer_mma(X, g.wbf + g.wT_off[l], FH, n0, lane, acc);   // g = gz_l W_l  (columns = inputs of layer l)
+    k8_prefetch<TI>(g.D[l - 1], rowW, n0, lane, aD);
+    bf_layer_mma<TI>(Xw, g.wbf + g.wT_off[l], FH, n0, lane, acc);   // g = gz_l W_l  (columns = inputs of layer l)
     lds_barrier();
     const bool is_skip = (l == g.skip);
     const int ksplit = is_skip ? FH - g.pe : FH;   // columns that belong to layer l-1's output
@@ -386,14 +436,14 @@ __global__ __launch_bounds__(64 * BNW, 2) void bf_reverse_kernel(BfBwdArgs g) {
     for (int tj = 0; tj < 2; ++tj) {
       const int col = n0 + tj * 32 + cl;
 #pragma unroll
-      for (int ti = 0; ti < 2; ++ti)
+      for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           float o[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int r = 4 * q + j;
-            const int row = ti * 32 + 8 * q + 4 * h + j;
+            const int row = rb + ti * 32 + 8 * q + 4 * h + j;
             const float v = acc[ti][tj][r];
             if (col < ksplit) o[j] = v * aux_at(aD, ti, tj, r);
             else {
@@ -402,22 +452,22 @@ __global__ __launch_bounds__(64 * BNW, 2) void bf_reverse_kernel(BfBwdArgs g) {
             }
             X[row * BP + col] = to_bf(o[j]);
           }
-          k8_store_quad(g.gz[l - 1], row0, ti, q, col, h, o[0], o[1], o[2], o[3]);
+          k8_store_quad(g.gz[l - 1], rowW, ti, q, col, h, o[0], o[1], o[2], o[3]);
         }
     }
     lds_barrier();
   }
   // layer 0: g_e += gz_0 W_0 (Ep = 64 columns: wave 0)
   if (n0 < 64) {
-    bf_layer_mma(X, g.wbf + g.wT_off[0], FH, n0, lane, acc);
+    bf_layer_mma<TI>(Xw, g.wbf + g.wT_off[0], FH, n0, lane, acc);
 #pragma unroll
     for (int tj = 0; tj < 2; ++tj) {
       const int col = n0 + tj * 32 + cl;
       if (col < g.pe) {
 #pragma unroll
-        for (int ti = 0; ti < 2; ++ti)
+        for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) GE[(ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * FEP + col] += acc[ti][tj][r];
+          for (int r = 0; r < 16; ++r) GE[(rb + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * FEP + col] += acc[ti][tj][r];
       }
     }
   }
@@ -443,16 +493,21 @@ __global__ __launch_bounds__(64 * BNW, 2) void bf_reverse_kernel(BfBwdArgs g) {
 }
 
 // RA: u_{l+1} = (u_l W_l^T) * D_l, zR_l = 100 (u_l W_l^T) gz_l (1 - D_l)
-__global__ __launch_bounds__(64 * BNW, 2) void bf_ra_kernel(BfBwdArgs g) {
+template <int TI>
+__global__ __launch_bounds__(BfCfg<TI>::NT, TI == 1 ? 4 : 2) void bf_ra_kernel(BfBwdArgs g) {
+  constexpr int NW = BfCfg<TI>::NW, NT = BfCfg<TI>::NT;
   __shared__ __attribute__((aligned(16))) bfraw X[BT * BP];
   __shared__ float E[BT * FEP];   // adjoint of g_e of the tile (re-enters at the skip connection)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = wave_id();
   const int64_t row0 = (int64_t)blockIdx.x * BT;
-  const int n0 = wave * 64;
+  const int n0 = (wave & 3) * 64;          // column group of the wave
+  const int rb = (wave >> 2) * 32;         // first row of the wave inside the tile (TI == 1: two row halves)
+  const int64_t rowW = row0 + rb;
+  const bfraw* Xw = X + rb * BP;
   const int h = lane >> 5, cl = lane & 31;
 
-  for (int idx = tid; idx < BT * g.Ep; idx += 64 * BNW) {
+  for (int idx = tid; idx < BT * g.Ep; idx += NT) {
     const int r = idx / g.Ep, c = idx - r * g.Ep;
     const float v = g.geb[(row0 + r) * g.Ep + c];
     X[r * BP + c] = to_bf(v);
@@ -460,7 +515,7 @@ __global__ __launch_bounds__(64 * BNW, 2) void bf_ra_kernel(BfBwdArgs g) {
   }
   __syncthreads();
   // u_0 in K8 (the Y operand of layer 0's weight gradient)
-  for (int u = tid; u < (BT / 8) * g.Ep; u += 64 * BNW) {
+  for (int u = tid; u < (BT / 8) * g.Ep; u += NT) {
     const int blk = u / g.Ep, c = u - blk * g.Ep;
     bfraw v[8];
 #pragma unroll
@@ -470,12 +525,12 @@ __global__ __launch_bounds__(64 * BNW, 2) void bf_ra_kernel(BfBwdArgs g) {
     *reinterpret_cast<vu4*>(g.u[0] + (((size_t)(row0 >> 3) + blk) * g.Ep + c) * 8) = o;
   }
 
-  v16f acc[2][2];
-  AuxBf aD, aG;
+  v16f acc[TI][2];
+  AuxBf<TI> aD, aG;
   for (int l = 0; l < g.nh; ++l) {
-    k8_prefetch(g.D[l], row0, n0, lane, aD);
-    k8_prefetch(g.gz[l], row0, n0, lane, aG);
-    bf_layer_mma(X, g.wbf + g.w_off[l], g.Kp[l], n0, lane, acc);   // gzb = u_l W_l^T
+    k8_prefetch<TI>(g.D[l], rowW, n0, lane, aD);
+    k8_prefetch<TI>(g.gz[l], rowW, n0, lane, aG);
+    bf_layer_mma<TI>(Xw, g.wbf + g.w_off[l], g.Kp[l], n0, lane, acc);   // gzb = u_l W_l^T
     lds_barrier();
     const int n_real = g.n_real[l];
     const bool pe_tail = (l + 1 == g.skip);
@@ -483,14 +538,14 @@ __global__ __launch_bounds__(64 * BNW, 2) void bf_ra_kernel(BfBwdArgs g) {
     for (int tj = 0; tj < 2; ++tj) {
       const int col = n0 + tj * 32 + cl;
 #pragma unroll
-      for (int ti = 0; ti < 2; ++ti)
+      for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           float un[4], zr[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int r = 4 * q + j;
-            const int row = ti * 32 + 8 * q + 4 * h + j;
+            const int row = rb + ti * 32 + 8 * q + 4 * h + j;
             const float v = acc[ti][tj][r];
             if (col < n_real) {
               un[j] = v * aux_at(aD, ti, tj, r);
@@ -501,8 +556,8 @@ __global__ __launch_bounds__(64 * BNW, 2) void bf_ra_kernel(BfBwdArgs g) {
             }
             X[row * BP + col] = to_bf(un[j]);
           }
-          k8_store_quad(g.u[l + 1], row0, ti, q, col, h, un[0], un[1], un[2], un[3]);
-          k8_store_quad(g.zR[l], row0, ti, q, col, h, zr[0], zr[1], zr[2], zr[3]);
+          k8_store_quad(g.u[l + 1], rowW, ti, q, col, h, un[0], un[1], un[2], un[3]);
+          k8_store_quad(g.zR[l], rowW, ti, q, col, h, zr[0], zr[1], zr[2], zr[3]);
         }
     }
     lds_barrier();
@@ -510,27 +565,39 @@ __global__ __launch_bounds__(64 * BNW, 2) void bf_ra_kernel(BfBwdArgs g) {
 }
 
 // FB: zb_{l-1} = (zb_l W_l) * D_{l-1} + zR_{l-1}, head: ab_{nh-1} = fbar W_feat + sbar / scale * w_sdf
-__global__ __launch_bounds__(64 * BNW, 2) void bf_fb_kernel(BfBwdArgs g) {
+template <int TI>
+__global__ __launch_bounds__(BfCfg<TI>::NT, TI == 1 ? 4 : 2) void bf_fb_kernel(BfBwdArgs g) {
+  constexpr int NW = BfCfg<TI>::NW, NT = BfCfg<TI>::NT;
   __shared__ __attribute__((aligned(16))) bfraw X[BT * BP];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = wave_id();
   const int64_t row0 = (int64_t)blockIdx.x * BT;
-  const int n0 = wave * 64;
+  const int n0 = (wave & 3) * 64;          // column group of the wave
+  const int rb = (wave >> 2) * 32;         // first row of the wave inside the tile (TI == 1: two row halves)
+  const int64_t rowW = row0 + rb;
+  const bfraw* Xw = X + rb * BP;
   const int h = lane >> 5, cl = lane & 31;
 
-  v16f acc[2][2];
-  AuxBf aD, aZ;
-  bf_zero(acc);
-  if (g.fbar != nullptr) {
+  v16f acc[TI][2];
+  AuxBf<TI> aD, aZ;
+  bf_zero<TI>(acc);
+  if (g.fbar_in_k8) {
+    const bfraw* fb = g.fbar8 + (size_t)(row0 >> 3) * FH * 8;
+    for (int u = tid; u < (BT / 8) * FH; u += NT)
+      lds_scatter8<BP>(X, u / FH, u % FH, *reinterpret_cast<const vu4*>(fb + (size_t)u * 8));
+    __syncthreads();
+    bf_layer_mma<TI>(Xw, g.wbf + g.wfT_off, FH, n0, lane, acc);
+    lds_barrier();
+  } else if (g.fbar != nullptr) {
     // fbar (fp32 row-major, from the albedo net's backward) -> LDS bf16, and K8 for the feature head's dW
-    for (int idx = tid; idx < BT * FH / 4; idx += 64 * BNW) {
+    for (int idx = tid; idx < BT * FH / 4; idx += NT) {
       const int r = idx >> 6, c4 = idx & 63;
       const vf4 v = *reinterpret_cast<const vf4*>(g.fbar + (size_t)(row0 + r) * g.ld_fbar + c4 * 4);
       const vu2 o = {pack2(v.x, v.y), pack2(v.z, v.w)};
       *reinterpret_cast<vu2*>(X + r * BP + c4 * 4) = o;
     }
     __syncthreads();
-    for (int u = tid; u < (BT / 8) * FH; u += 64 * BNW) {
+    for (int u = tid; u < (BT / 8) * FH; u += NT) {
       const int blk = u / FH, c = u - blk * FH;
       bfraw v[8];
 #pragma unroll
@@ -539,12 +606,12 @@ __global__ __launch_bounds__(64 * BNW, 2) void bf_fb_kernel(BfBwdArgs g) {
                (unsigned)v[4] | ((unsigned)v[5] << 16), (unsigned)v[6] | ((unsigned)v[7] << 16)};
       *reinterpret_cast<vu4*>(g.fbar8 + (((size_t)(row0 >> 3) + blk) * FH + c) * 8) = o;
     }
-    bf_layer_mma(X, g.wbf + g.wfT_off, FH, n0, lane, acc);
+    bf_layer_mma<TI>(Xw, g.wbf + g.wfT_off, FH, n0, lane, acc);
     lds_barrier();
   }
   for (int l = g.nh - 1; l >= 0; --l) {
-    k8_prefetch(g.D[l], row0, n0, lane, aD);
-    k8_prefetch(g.zR[l], row0, n0, lane, aZ);
+    k8_prefetch<TI>(g.D[l], rowW, n0, lane, aD);
+    k8_prefetch<TI>(g.zR[l], rowW, n0, lane, aZ);
     const int n_real = g.n_real[l];
     const bool head = (l == g.nh - 1);
 #pragma unroll
@@ -552,26 +619,297 @@ __global__ __launch_bounds__(64 * BNW, 2) void bf_fb_kernel(BfBwdArgs g) {
       const int col = n0 + tj * 32 + cl;
       const float ws = head ? g.packed[g.wsdf_off + col] : 0.f;
 #pragma unroll
-      for (int ti = 0; ti < 2; ++ti)
+      for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           float zb[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int r = 4 * q + j;
-            const int row = ti * 32 + 8 * q + 4 * h + j;
+            const int row = rb + ti * 32 + 8 * q + 4 * h + j;
             float v = acc[ti][tj][r];
             if (head) v = fmaf(g.sbar[row0 + row] * g.inv_scale, ws, v);   // the sdf head's contribution
             zb[j] = col < n_real ? fmaf(v, aux_at(aD, ti, tj, r), aux_at(aZ, ti, tj, r)) : 0.f;
             X[row * BP + col] = to_bf(zb[j]);
           }
-          k8_store_quad(g.zb[l], row0, ti, q, col, h, zb[0], zb[1], zb[2], zb[3]);
+          k8_store_quad(g.zb[l], rowW, ti, q, col, h, zb[0], zb[1], zb[2], zb[3]);
         }
     }
     if (l == 0) break;
     lds_barrier();
-    bf_layer_mma(X, g.wbf + g.wT_off[l], FH, n0, lane, acc);   // ab_{l-1} = zb_l W_l
+    bf_layer_mma<TI>(Xw, g.wbf + g.wT_off[l], FH, n0, lane, acc);   // ab_{l-1} = zb_l W_l
     lds_barrier();   // every wave has finished reading the tile
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// albedo network (RenderingNetwork, mode no_view_dir: models/fields.py:177-215) in bf16
+// ---------------------------------------------------------------------------------------------------------------
+// Input [feature | pe(p) | pe(n) | 0] (Cinp = 320 columns, the packed column order of weightnorm.hip), nc hidden ReLU
+// layers of width 256, output layer (<= 4 rows, sigmoid) on the VALU with fp32 weights.  Saved for the backward in K8
+// bf16: cin8 (all Cinp columns), ac8[l].  One 64-point tile per workgroup, 4 waves of 64 rows x 64 columns.
+constexpr int CP = 328;    // LDS pitch (bf16 elements) of a [point][Cinp <= 320] row: 656 bytes, conflict-free ds_read_b128
+constexpr int CMAX = 320;
+
+struct BfColArgs {
+  const float* pts;        // [M,3]
+  const float* nrm;        // [Mp,4]
+  int64_t M;
+  const float* packed;
+  const bfraw* wbf;
+  int nc, F, pev, multires_view, Cinp, Co, squeeze;
+  int Kp[RNB_MAX_LIN];
+  long long w_off[RNB_MAX_LIN], wT_off[RNB_MAX_LIN], b_off[RNB_MAX_LIN];
+  long long wo_off, bo_off;
+  int ldwo;
+  bfraw* cin8;             // [Mp,Cinp] K8: features written by the F sweep; this kernel adds the pe columns
+  bfraw* ac8[RNB_MAX_LIN]; // [Mp,256] K8
+  float* alb;              // [Mp,4]
+  // backward
+  const float* albbar;     // [Mp,4]
+  bfraw* zc8[RNB_MAX_LIN]; // [Mp,256] K8
+  bfraw* fbar8;            // [Mp,256] K8 (out): adjoint of the feature columns
+  float* cinb;             // [Mp,Cinp] fp32 row-major: only the pe columns F.. are written (consumed by nbar_geb_kernel)
+};
+
+__global__ __launch_bounds__(256, 2) void bf_color_fwd_kernel(BfColArgs g) {
+  __shared__ __attribute__((aligned(16))) bfraw X[BT * CP];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = wave_id();
+  const int64_t row0 = (int64_t)blockIdx.x * BT;
+  const int n0 = wave * 64;
+  const int h = lane >> 5, cl = lane & 31;
+  // features: K8 units of cin8 -> LDS rows
+  {
+    const bfraw* src = g.cin8 + (size_t)(row0 >> 3) * g.Cinp * 8;
+    for (int u = tid; u < (BT / 8) * g.F; u += 256) {
+      const int blk = u / g.F, c = u - blk * g.F;
+      lds_scatter8<CP>(X, blk, c, *reinterpret_cast<const vu4*>(src + ((size_t)blk * g.Cinp + c) * 8));
+    }
+  }
+  // pe(p), pe(n) (fp32 math, models/embedder.py:40-46): 4 threads per point = (which vector, even / odd octaves)
+  {
+    const int p = tid & 63, part = tid >> 6, which = part >> 1, sub = part & 1;
+    const int64_t row = row0 + p;
+    float v[3] = {0.f, 0.f, 0.f};
+    if (row < g.M) {
+      if (which == 0) { v[0] = g.pts[row * 3]; v[1] = g.pts[row * 3 + 1]; v[2] = g.pts[row * 3 + 2]; }
+      else { v[0] = g.nrm[row * 4]; v[1] = g.nrm[row * 4 + 1]; v[2] = g.nrm[row * 4 + 2]; }
+    }
+    bfraw* xr = X + p * CP + g.F + which * g.pev;
+    if (sub == 0) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d) xr[d] = to_bf(v[d]);
+      if (which == 1)
+        for (int c = g.F + 2 * g.pev; c < g.Cinp; ++c) X[p * CP + c] = 0;
+    }
+    for (int k = sub; k < g.multires_view; k += 2) {
+      const float f = (float)(1 << k);
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        float sn, co;
+        sincosf(v[d] * f, &sn, &co);
+        xr[3 + 6 * k + d] = to_bf(sn);
+        xr[3 + 6 * k + 3 + d] = to_bf(co);
+      }
+    }
+  }
+  __syncthreads();
+  // the pe columns of the input in K8 (Y operand of layer 0's weight gradient)
+  {
+    const int W = g.Cinp - g.F;
+    for (int u = tid; u < (BT / 8) * W; u += 256) {
+      const int blk = u / W, c = g.F + (u - blk * W);
+      *reinterpret_cast<vu4*>(g.cin8 + (((size_t)(row0 >> 3) + blk) * g.Cinp + c) * 8) = lds_gather8<CP>(X, blk, c);
+    }
+  }
+  v16f acc[2][2];
+  for (int l = 0; l < g.nc; ++l) {
+    bf_layer_mma<2, CP>(X, g.wbf + g.w_off[l], g.Kp[l], n0, lane, acc);
+    lds_barrier();
+    const float* bias = g.packed + g.b_off[l];
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj) {
+      const int col = n0 + tj * 32 + cl;
+      const float bc = bias[col];
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float a[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            a[j] = fmaxf(acc[ti][tj][4 * q + j] + bc, 0.f);
+            X[(ti * 32 + 8 * q + 4 * h + j) * CP + col] = to_bf(a[j]);
+          }
+          k8_store_quad(g.ac8[l], row0, ti, q, col, h, a[0], a[1], a[2], a[3]);
+        }
+    }
+    lds_barrier();
+  }
+  // output layer + sigmoid: fp32 weights on the bf16 activations, 16 rows per wave
+  {
+    float w[4][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) w[c][u] = c < g.Co ? g.packed[g.wo_off + (long long)c * g.ldwo + lane + 64 * u] : 0.f;
+    for (int rr = 0; rr < BT / 4; ++rr) {
+      const int row = wave * (BT / 4) + rr;
+      float sc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float a = bf_f(X[row * CP + lane + 64 * u]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) sc[c] = fmaf(a, w[c][u], sc[c]);
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sc[c] += __shfl_xor(sc[c], o, 64);
+      if (lane < 4) {
+        float v = 0.f;
+        if (lane < g.Co) {
+          v = sc[lane] + g.packed[g.bo_off + lane];
+          if (g.squeeze) v = 1.f / (1.f + expf(-v));
+        }
+        g.alb[(row0 + row) * 4 + lane] = v;
+      }
+    }
+  }
+}
+
+// backward: zo = albbar * alb (1 - alb); zc_last = (zo Wo) * relu'; zc_{l-1} = (zc_l W_l) * relu'; cinb = zc_0 W_0
+__global__ __launch_bounds__(256, 2) void bf_color_bwd_kernel(BfColArgs g) {
+  __shared__ __attribute__((aligned(16))) bfraw X[BT * BP];
+  __shared__ float ZO[BT * 4];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = wave_id();
+  const int64_t row0 = (int64_t)blockIdx.x * BT;
+  const int n0 = wave * 64;
+  const int h = lane >> 5, cl = lane & 31;
+  if (tid < BT) {
+    const int64_t row = row0 + tid;
+    const vf4 a4 = *reinterpret_cast<const vf4*>(g.alb + row * 4);
+    const vf4 g4 = *reinterpret_cast<const vf4*>(g.albbar + row * 4);
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      ZO[tid * 4 + c] = (c < g.Co && row < g.M) ? g4[c] * (g.squeeze ? a4[c] * (1.f - a4[c]) : 1.f) : 0.f;
+  }
+  __syncthreads();
+  {   // zc_{nc-1}: one K8 unit (8 points of one column) per thread and step
+    const int L = g.nc - 1;
+    const bfraw* ac = g.ac8[L] + (size_t)(row0 >> 3) * FH * 8;
+    bfraw* zc = g.zc8[L] + (size_t)(row0 >> 3) * FH * 8;
+    for (int u = tid; u < (BT / 8) * FH; u += 256) {
+      const int blk = u / FH, c = u - blk * FH;
+      float w[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) w[k] = k < g.Co ? g.packed[g.wo_off + (long long)k * g.ldwo + c] : 0.f;
+      const vu4 a = *reinterpret_cast<const vu4*>(ac + (size_t)u * 8);
+      const unsigned aw[4] = {a.x, a.y, a.z, a.w};
+      float z[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float av = (j & 1) ? bf_hi(aw[j >> 1]) : bf_lo(aw[j >> 1]);
+        const float* zo = ZO + (blk * 8 + j) * 4;
+        const float t = fmaf(zo[0], w[0], fmaf(zo[1], w[1], fmaf(zo[2], w[2], zo[3] * w[3])));
+        z[j] = av > 0.f ? t : 0.f;
+        X[(blk * 8 + j) * BP + c] = to_bf(z[j]);
+      }
+      *reinterpret_cast<vu4*>(zc + (size_t)u * 8) = vu4{pack2(z[0], z[1]), pack2(z[2], z[3]), pack2(z[4], z[5]), pack2(z[6], z[7])};
+    }
+  }
+  __syncthreads();
+  v16f acc[2][2];
+  AuxBf<2> aA;
+  for (int l = g.nc - 1; l >= 1; --l) {
+    k8_prefetch<2>(g.ac8[l - 1], row0, n0, lane, aA);
+    bf_layer_mma<2>(X, g.wbf + g.wT_off[l], FH, n0, lane, acc);   // zc_l W_l  (columns = inputs of layer l)
+    lds_barrier();
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj) {
+      const int col = n0 + tj * 32 + cl;
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float z[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            z[j] = aux_at(aA, ti, tj, 4 * q + j) > 0.f ? acc[ti][tj][4 * q + j] : 0.f;
+            X[(ti * 32 + 8 * q + 4 * h + j) * BP + col] = to_bf(z[j]);
+          }
+          k8_store_quad(g.zc8[l - 1], row0, ti, q, col, h, z[0], z[1], z[2], z[3]);
+        }
+    }
+    lds_barrier();
+  }
+  // cinb = zc_0 W_0: columns 0 .. F-1 (features) -> fbar8 (K8 bf16, what the FB sweep and the feature head's dW read);
+  // columns F .. Cin-1 (pe(p) | pe(n)) -> fp32 row-major cinb (the normal's adjoint, nbar_geb_kernel)
+  bf_layer_mma<2>(X, g.wbf + g.wT_off[0], FH, n0, lane, acc);
+#pragma unroll
+  for (int tj = 0; tj < 2; ++tj) {
+    const int col = n0 + tj * 32 + cl;
+    if (col < g.F) {
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          k8_store_quad(g.fbar8, row0, ti, q, col, h, acc[ti][tj][4 * q], acc[ti][tj][4 * q + 1], acc[ti][tj][4 * q + 2],
+                        acc[ti][tj][4 * q + 3]);
+    }
+  }
+  if (wave == 0) {   // the 64 pe columns: one more 64 x 64 block
+    bf_layer_mma<2>(X, g.wbf + g.wT_off[0], FH, g.F, lane, acc);
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj) {
+      const int col = g.F + tj * 32 + cl;
+      if (col < g.Cinp) {
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            g.cinb[(size_t)(row0 + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * g.Cinp + col] = acc[ti][tj][r];
+      }
+    }
+  }
+}
+
+// gradient of the albedo output layer: dWo[c][k] += sum_rows zo[row][c] ac_last[row][k], dbo[c] += sum_rows zo[row][c].
+// One thread per column k and point slab (one slab in the deterministic variant).
+__global__ __launch_bounds__(256) void bf_color_out_bwd_kernel(const bfraw* __restrict__ ac, const float* __restrict__ alb,
+                                                               const float* __restrict__ albbar, int Co, int squeeze,
+                                                               int64_t M, int64_t rows_per_blk, int ldwo,
+                                                               float* __restrict__ dWo, float* __restrict__ dbo) {
+  const int c = threadIdx.x;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_blk;
+  const int64_t r1 = r0 + rows_per_blk < M ? r0 + rows_per_blk : M;
+  double s[4] = {0.0, 0.0, 0.0, 0.0}, sb[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int64_t r = r0; r < r1; r += 8) {
+    const vu4 av = *reinterpret_cast<const vu4*>(ac + ((size_t)(r >> 3) * FH + c) * 8);
+    const unsigned aw[4] = {av.x, av.y, av.z, av.w};
+    float t[4] = {0.f, 0.f, 0.f, 0.f}, tb[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (r + j < r1) {
+        const float a = (j & 1) ? bf_hi(aw[j >> 1]) : bf_lo(aw[j >> 1]);
+        const vf4 a4 = *reinterpret_cast<const vf4*>(alb + (r + j) * 4);
+        const vf4 g4 = *reinterpret_cast<const vf4*>(albbar + (r + j) * 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float zo = k < Co ? g4[k] * (squeeze ? a4[k] * (1.f - a4[k]) : 1.f) : 0.f;
+          t[k] = fmaf(zo, a, t[k]);
+          tb[k] += zo;
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { s[k] += (double)t[k]; sb[k] += (double)tb[k]; }
+  }
+  for (int k = 0; k < Co; ++k) {
+    atomicAdd(dWo + (size_t)k * ldwo + c, (float)s[k]);
+    if (c == 0) atomicAdd(dbo + k, (float)sb[k]);
   }
 }
 
@@ -889,12 +1227,93 @@ __global__ void bf_pack_kernel(const float* __restrict__ src, int64_t n, bfraw* 
 // ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
+// the albedo network runs in bf16 too when it has the shipped shape; otherwise its fp32 kernels (mlp.hip) are used
+bool bf16_color_supported(const Layout& L) {
+  if (L.F != FH || L.Hc != FH || L.Hcp != FH) return false;
+  if (L.Cinp > CMAX || L.Cinp % 64 != 0 || L.Cinp - L.F > 64) return false;
+  if (L.nc < 1 || L.Co < 1 || L.Co > 4) return false;
+  return true;
+}
+
+static void fill_col(const Layout& L, const float* packed, const float* pts, PointBufs& pb, BfColArgs& g) {
+  memset(&g, 0, sizeof(g));
+  g.pts = pts;
+  g.nrm = pb.nrm;
+  g.M = pb.M;
+  g.packed = packed;
+  g.wbf = reinterpret_cast<const bfraw*>(packed + L.total);
+  g.nc = L.nc; g.F = L.F; g.pev = L.pev; g.multires_view = L.multires_view; g.Cinp = L.Cinp; g.Co = L.Co;
+  g.squeeze = L.squeeze;
+  for (int l = 0; l < L.nc; ++l) {
+    g.Kp[l] = L.col[l].Kp;
+    g.w_off[l] = L.col[l].w_off;
+    g.wT_off[l] = L.col[l].wT_off;
+    g.b_off[l] = L.col[l].b_off;
+    g.ac8[l] = reinterpret_cast<bfraw*>(pb.ac8[l]);
+    g.zc8[l] = reinterpret_cast<bfraw*>(pb.zc8[l]);
+  }
+  g.wo_off = L.colo.w_off;
+  g.bo_off = L.colo.b_off;
+  g.ldwo = L.colo.Kp;
+  g.cin8 = reinterpret_cast<bfraw*>(pb.cin8);
+  g.alb = pb.alb;
+  g.albbar = pb.albbar;
+  g.fbar8 = reinterpret_cast<bfraw*>(pb.fbar_k8);
+  g.cinb = pb.cinb;
+}
+
+static double color_flops(const Layout& L, int64_t M, int first) {
+  double fl = 0;
+  for (int l = first; l < L.nc; ++l) fl += 2.0 * (double)M * L.col[l].N * L.col[l].K;
+  return fl;
+}
+
+// C: albedo network forward on the tile state the F and R sweeps left (cin8 features, pb.nrm)
+int bf16_color_forward(const Layout& L, const float* packed, PointBufs& pb, const float* pts, hipStream_t s) {
+  BfColArgs g;
+  fill_col(L, packed, pts, pb, g);
+  ProfScope prof(color_flops(L, pb.M, 0) + 2.0 * (double)pb.M * L.colo.N * L.colo.K, s);
+  hipLaunchKernelGGL(bf_color_fwd_kernel, dim3((unsigned)(pb.Mp / BT)), dim3(256), 0, s, g);
+  RNB_CHECK_LAUNCH();
+  return RNB_OK;
+}
+
+// C': albedo network backward (writes zc8, fbar8, the pe columns of cinb, dWo / dbo); its hidden-layer weight
+// gradients join the grouped dW launch of bf16_backward
+int bf16_color_backward(const Layout& L, const float* packed, PointBufs& pb, float* packed_grad, hipStream_t s) {
+  BfColArgs g;
+  fill_col(L, packed, nullptr, pb, g);
+  const bool det = (L.variant & RNB_VARIANT_DETERMINISTIC) != 0;
+  {
+    ProfScope prof(color_flops(L, pb.M, 0) + 2.0 * (double)pb.M * L.colo.N * L.colo.K, s);
+    hipLaunchKernelGGL(bf_color_bwd_kernel, dim3((unsigned)(pb.Mp / BT)), dim3(256), 0, s, g);
+    RNB_CHECK_LAUNCH();
+  }
+  int64_t slabs = det ? 1 : 256;
+  int64_t rows_per_blk = (pb.M + slabs - 1) / slabs;
+  rows_per_blk = (rows_per_blk + 7) / 8 * 8;
+  hipLaunchKernelGGL(bf_color_out_bwd_kernel, dim3((unsigned)((pb.M + rows_per_blk - 1) / rows_per_blk)), dim3(256), 0, s,
+                     reinterpret_cast<const bfraw*>(pb.ac8[L.nc - 1]), pb.alb, pb.albbar, L.Co, L.squeeze, pb.M, rows_per_blk,
+                     L.colo.Kp, packed_grad + L.colo.w_off, packed_grad + L.colo.b_off);
+  RNB_CHECK_LAUNCH();
+  return RNB_OK;
+}
+
 int bf16_pack_weights(const Layout& L, float* packed, hipStream_t s) {
   bfraw* dst = reinterpret_cast<bfraw*>(packed + L.total);
   const int64_t pairs = (L.total + 1) / 2;
   hipLaunchKernelGGL(bf_pack_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, s, packed, L.total, dst);
   RNB_CHECK_LAUNCH();
   return RNB_OK;
+}
+
+// rows per wave of the sweeps: RNB_VARIANT_{FWD,BWD}_TI (1: 32 rows x 8 waves, 2: 64 rows x 4 waves).  Default 2:
+// measured 4.23 ms / step against 5.04 ms with TI = 1 on both (512 rays x 256 samples) — the 8-wave form doubles the
+// weight bytes each CU pulls from L2 per point (every fragment feeds one row tile instead of two), and that stream,
+// not latency, is what these sweeps wait for.
+static int bf_ti(const Layout& L, int shift) {
+  const int v = L.knob(shift);
+  return v == 1 ? 1 : 2;
 }
 
 static const bfraw* wbf_of(const Layout& L, const float* packed) { return reinterpret_cast<const bfraw*>(packed + L.total); }
@@ -906,7 +1325,7 @@ static double hidden_flops_bf(const Layout& L, int64_t M, int first) {
 }
 
 int bf16_forward(const Layout& L, const float* packed, const float* pts, int64_t M, PointBufs& pb, bool save, bool need_feat,
-                 hipStream_t s, const GridGen* grid) {
+                 hipStream_t s, const GridGen* grid, bool feat_k8) {
   BfFwdArgs g;
   memset(&g, 0, sizeof(g));
   if (grid) g.grid = *grid;
@@ -932,6 +1351,7 @@ int bf16_forward(const Layout& L, const float* packed, const float* pts, int64_t
   g.wf_off = L.feat.w_off;
   g.bf_off = L.feat.b_off;
   g.cin = pb.cin;
+  g.cin8 = feat_k8 ? reinterpret_cast<bfraw*>(pb.cin8) : nullptr;
   g.sdf = pb.sdf;
   g.x4 = pb.x;
   g.e = reinterpret_cast<bfraw*>(pb.e);
@@ -939,8 +1359,11 @@ int bf16_forward(const Layout& L, const float* packed, const float* pts, int64_t
   if (need_feat) fl += 2.0 * (double)M * L.F * L.H;
   ProfScope prof(fl, s);
   const unsigned blocks = (unsigned)(pb.Mp / BT);
-  if (save) hipLaunchKernelGGL(bf_forward_kernel<true>, dim3(blocks), dim3(64 * BNW), 0, s, g);
-  else hipLaunchKernelGGL(bf_forward_kernel<false>, dim3(blocks), dim3(64 * BNW), 0, s, g);
+  const int ti = bf_ti(L, RNB_VARIANT_FWD_TI_SHIFT);
+  if (save && ti == 1) hipLaunchKernelGGL((bf_forward_kernel<true, 1>), dim3(blocks), dim3(512), 0, s, g);
+  else if (save) hipLaunchKernelGGL((bf_forward_kernel<true, 2>), dim3(blocks), dim3(256), 0, s, g);
+  else if (ti == 1) hipLaunchKernelGGL((bf_forward_kernel<false, 1>), dim3(blocks), dim3(512), 0, s, g);
+  else hipLaunchKernelGGL((bf_forward_kernel<false, 2>), dim3(blocks), dim3(256), 0, s, g);
   RNB_CHECK_LAUNCH();
   return RNB_OK;
 }
@@ -977,21 +1400,25 @@ int bf16_reverse(const Layout& L, const float* packed, PointBufs& pb, hipStream_
   BfBwdArgs g;
   fill_bwd(L, packed, pb, g);
   ProfScope prof(hidden_flops_bf(L, pb.M, 0), s);
-  hipLaunchKernelGGL(bf_reverse_kernel, dim3((unsigned)(pb.Mp / BT)), dim3(64 * BNW), 0, s, g);
+  if (bf_ti(L, RNB_VARIANT_BWD_TI_SHIFT) == 1) hipLaunchKernelGGL(bf_reverse_kernel<1>, dim3((unsigned)(pb.Mp / BT)), dim3(512), 0, s, g);
+  else hipLaunchKernelGGL(bf_reverse_kernel<2>, dim3((unsigned)(pb.Mp / BT)), dim3(256), 0, s, g);
   RNB_CHECK_LAUNCH();
   return RNB_OK;
 }
 
 // RA, sdf-head row gradient, FB and every dW job of the SDF network (+ the feature head's) for one backward
-int bf16_backward(const Layout& L, const float* packed, PointBufs& pb, bool with_color, float* packed_grad, hipStream_t s) {
+int bf16_backward(const Layout& L, const float* packed, PointBufs& pb, bool with_color, bool color_bf16, float* packed_grad,
+                  hipStream_t s) {
   const int64_t M = pb.M;
   const bool det = (L.variant & RNB_VARIANT_DETERMINISTIC) != 0;
   BfBwdArgs g;
   fill_bwd(L, packed, pb, g);
   const unsigned blocks = (unsigned)(pb.Mp / BT);
+  const int bti = bf_ti(L, RNB_VARIANT_BWD_TI_SHIFT);
   {
     ProfScope prof(hidden_flops_bf(L, M, 0), s);
-    hipLaunchKernelGGL(bf_ra_kernel, dim3(blocks), dim3(64 * BNW), 0, s, g);
+    if (bti == 1) hipLaunchKernelGGL(bf_ra_kernel<1>, dim3(blocks), dim3(512), 0, s, g);
+    else hipLaunchKernelGGL(bf_ra_kernel<2>, dim3(blocks), dim3(256), 0, s, g);
     RNB_CHECK_LAUNCH();
   }
   {
@@ -1004,10 +1431,12 @@ int bf16_backward(const Layout& L, const float* packed, PointBufs& pb, bool with
     RNB_CHECK_LAUNCH();
   }
   {
-    g.fbar = with_color ? pb.cinb : nullptr;
+    g.fbar = (with_color && !color_bf16) ? pb.cinb : nullptr;
     g.ld_fbar = L.Cinp;
+    g.fbar_in_k8 = (with_color && color_bf16) ? 1 : 0;
     ProfScope prof(hidden_flops_bf(L, M, 1) + (with_color ? 2.0 * (double)M * L.F * L.H : 0.0), s);
-    hipLaunchKernelGGL(bf_fb_kernel, dim3(blocks), dim3(64 * BNW), 0, s, g);
+    if (bti == 1) hipLaunchKernelGGL(bf_fb_kernel<1>, dim3(blocks), dim3(512), 0, s, g);
+    else hipLaunchKernelGGL(bf_fb_kernel<2>, dim3(blocks), dim3(256), 0, s, g);
     RNB_CHECK_LAUNCH();
   }
   // ---- dW jobs ----------------------------------------------------------------------------------------------
@@ -1015,7 +1444,7 @@ int bf16_backward(const Layout& L, const float* packed, PointBufs& pb, bool with
   memset(&grp, 0, sizeof(grp));
   grp.M = M;
   // points per workgroup: enough workgroups to fill the chip (njobs x splits >= ~2 per CU), ranges a multiple of 16
-  const int njobs_est = L.nh + (with_color ? 1 : 0);
+  const int njobs_est = L.nh + (with_color ? 1 : 0) + ((with_color && color_bf16) ? L.nc + 1 : 0);
   int splits = (int)((512 + njobs_est - 1) / njobs_est);
   int64_t rows = (M + splits - 1) / splits;
   rows = (rows + 63) / 64 * 64;
@@ -1026,13 +1455,14 @@ int bf16_backward(const Layout& L, const float* packed, PointBufs& pb, bool with
   int64_t part_left = det ? pb.dw_part_floats : 0;
   double fl = 0;
   auto add = [&](const bfraw* X1, const bfraw* Y1, int Cy1, const bfraw* X2, const bfraw* Y2, int Cy2, int npairs, int K,
-                 const Lin& ln, int bias_pair, double f) -> int {
+                 const Lin& ln, int bias_pair, double f, int ycol0 = 0, bool with_bias = true) -> int {
+    if (grp.njobs == kMaxBfDwJobs) RNB_FAIL(RNB_E_INVALID, "too many weight-gradient jobs for one bf16 launch");
     BfDwJob& J = grp.job[grp.njobs++];
-    J.X[0] = X1; J.Y[0] = Y1; J.Cy[0] = Cy1; J.ycol0[0] = 0;
-    J.X[1] = X2; J.Y[1] = Y2; J.Cy[1] = Cy2; J.ycol0[1] = 0;
+    J.X[0] = X1; J.Y[0] = Y1; J.Cy[0] = Cy1; J.ycol0[0] = ycol0;
+    J.X[1] = X2; J.Y[1] = Y2; J.Cy[1] = Cy2; J.ycol0[1] = ycol0;
     J.npairs = npairs; J.K = K; J.lddw = ln.Kp; J.bias_pair = bias_pair;
-    J.dW = packed_grad + ln.w_off;
-    J.db = packed_grad + ln.b_off;
+    J.dW = packed_grad + ln.w_off + ycol0;      // a column range [ycol0, ycol0 + K) of the layer's [256 x Kp] gradient
+    J.db = with_bias ? packed_grad + ln.b_off : nullptr;
     J.part = nullptr; J.partb = nullptr;
     if (det) {
       const int64_t need = (int64_t)splits * FH * ln.Kp + (int64_t)splits * FH;
@@ -1055,6 +1485,16 @@ int bf16_backward(const Layout& L, const float* packed, PointBufs& pb, bool with
   if (with_color) {
     RNB_TRY(add(reinterpret_cast<const bfraw*>(pb.fbar_k8), reinterpret_cast<const bfraw*>(pb.a[L.nh - 1]), FH, nullptr,
                 nullptr, 0, 1, L.feat.Kp, L.feat, 0, 2.0 * (double)M * L.feat.N * L.feat.K));
+    if (color_bf16) {   // the albedo net's hidden layers: dW_l = zc_l^T in_l
+      for (int l = L.nc - 1; l >= 1; --l)
+        RNB_TRY(add(reinterpret_cast<const bfraw*>(pb.zc8[l]), reinterpret_cast<const bfraw*>(pb.ac8[l - 1]), FH, nullptr, nullptr,
+                    0, 1, L.col[l].Kp, L.col[l], 0, 2.0 * (double)M * L.col[l].N * L.col[l].K));
+      // layer 0 reads the Cinp-wide input: its 256 feature columns and its 64 pe columns are two jobs
+      RNB_TRY(add(reinterpret_cast<const bfraw*>(pb.zc8[0]), reinterpret_cast<const bfraw*>(pb.cin8), L.Cinp, nullptr, nullptr, 0, 1,
+                  FH, L.col[0], 0, 2.0 * (double)M * L.col[0].N * L.col[0].K));
+      RNB_TRY(add(reinterpret_cast<const bfraw*>(pb.zc8[0]), reinterpret_cast<const bfraw*>(pb.cin8), L.Cinp, nullptr, nullptr, 0, 1,
+                  L.Cinp - FH, L.col[0], 0, 0.0, FH, false));
+    }
   }
   {
     ProfScope prof(fl, s);
@@ -1070,7 +1510,8 @@ int bf16_backward(const Layout& L, const float* packed, PointBufs& pb, bool with
 
 // floats of deterministic partial-slab workspace for bf16_backward over M points
 int64_t bf16_dw_partial_floats(const Layout& L, int64_t M, bool with_color) {
-  const int njobs_est = L.nh + (with_color ? 1 : 0);
+  const bool cbf = with_color && bf16_color_supported(L);
+  const int njobs_est = L.nh + (with_color ? 1 : 0) + (cbf ? L.nc + 1 : 0);
   int splits = (int)((512 + njobs_est - 1) / njobs_est);
   int64_t rows = (M + splits - 1) / splits;
   rows = (rows + 63) / 64 * 64;
@@ -1078,6 +1519,10 @@ int64_t bf16_dw_partial_floats(const Layout& L, int64_t M, bool with_color) {
   int64_t total = 0;
   for (int l = 0; l < L.nh; ++l) total += (int64_t)splits * FH * L.hid[l].Kp + (int64_t)splits * FH;
   if (with_color) total += (int64_t)splits * FH * L.feat.Kp + (int64_t)splits * FH;
+  if (cbf) {
+    for (int l = 1; l < L.nc; ++l) total += (int64_t)splits * FH * L.col[l].Kp + (int64_t)splits * FH;
+    total += 2 * ((int64_t)splits * FH * L.col[0].Kp + (int64_t)splits * FH);
+  }
   return total;
 }
 

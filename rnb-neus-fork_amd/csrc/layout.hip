@@ -137,6 +137,10 @@ void carve_points(const Layout& L, Carver& c, int64_t M, int mode, PointBufs* pb
     pb->cin = c.take<float>(Mp * L.Cinp);
     for (int l = 0; l < L.nc; ++l) pb->ac[l] = c.take<float>(Mp * L.Hcp);
     pb->alb = c.take<float>(Mp * 4);
+    if (bf && bf16_color_supported(L)) {
+      pb->cin8 = c.take<uint16_t>(Mp * L.Cinp);
+      for (int l = 0; l < L.nc; ++l) pb->ac8[l] = c.take<uint16_t>(Mp * L.Hcp);
+    }
   }
   if (mode & PM_WITH_BACKWARD) {
     for (int l = 1; l <= L.nh; ++l) pb->u[l] = take_state(Mp * L.Hp);
@@ -153,6 +157,8 @@ void carve_points(const Layout& L, Carver& c, int64_t M, int mode, PointBufs* pb
     if (mode & PM_WITH_COLOR) {
       for (int l = 0; l < L.nc; ++l) pb->zc[l] = c.take<float>(Mp * L.Hcp);
       pb->cinb = c.take<float>(Mp * L.Cinp);
+      if (bf && bf16_color_supported(L))
+        for (int l = 0; l < L.nc; ++l) pb->zc8[l] = c.take<uint16_t>(Mp * L.Hcp);
     }
     if (L.variant & RNB_VARIANT_DETERMINISTIC) {
       pb->dw_part_floats = dw_partial_floats(L, M, (mode & PM_WITH_COLOR) != 0) +

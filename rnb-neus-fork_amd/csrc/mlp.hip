@@ -824,8 +824,11 @@ int sweep_backward(const Layout& L, const float* packed, PointBufs& pb, bool wit
     RNB_CHECK_HIP(hipMemsetAsync(pb.dw_part, 0, (size_t)pb.dw_part_floats * sizeof(float), s));
   }
   DwBatch dw(M, s, (L.variant & RNB_VARIANT_DW_LDS) != 0, det ? pb.dw_part : nullptr, det ? pb.dw_part_floats : 0);
+  const bool color_bf16 = is_bf16(L) && with_color && bf16_color_supported(L) && pb.cin8 != nullptr;
   // ---- C': albedo network backward ---------------------------------------------------------------
-  if (with_color) {
+  if (color_bf16) {
+    RNB_TRY(bf16_color_backward(L, packed, pb, packed_grad, s));
+  } else if (with_color) {
     const int chunks = L.Hcp / 32;   // 32-column chunks x row slabs, ~256 workgroups, slabs a multiple of 64 rows
     int64_t slabs = det ? 1 : (256 + chunks - 1) / chunks;   // deterministic: ONE slab, i.e. one add per address onto zero
     int rows_per_blk = (int)((M + slabs - 1) / slabs);
@@ -862,7 +865,7 @@ int sweep_backward(const Layout& L, const float* packed, PointBufs& pb, bool wit
     // RNB_VARIANT_BF16: RA, the sdf-head row, FB and every weight gradient of the SDF network (+ feature head) run as
     // bf16 sweeps on the bf16 saved state; the albedo net's own (fp32) weight-gradient jobs were queued above
     RNB_TRY(dw.flush_all());
-    return bf16_backward(L, packed, pb, with_color, packed_grad, s);
+    return bf16_backward(L, packed, pb, with_color, color_bf16, packed_grad, s);
   }
   // ---- RA: adjoint of the reverse sweep, forward layer order -----------------------------------------
   if (fused) {

@@ -137,6 +137,9 @@ struct PointBufs {
   float* nbar;    // [Mp,4]
   float* albbar;  // [Mp,4]
   void* u0_k8;              // RNB_VARIANT_BF16: u_0 = J_pe nbar as bf16 K8 [Mp,Ep]   (written by the RA sweep)
+  void* cin8;               // RNB_VARIANT_BF16, bf16 albedo path: albedo-net input as bf16 K8 [Mp,Cinp]
+  void* ac8[RNB_MAX_LIN];   //   hidden activations as bf16 K8 [Mp,256]
+  void* zc8[RNB_MAX_LIN];   //   pre-activation adjoints as bf16 K8 [Mp,256]
   void* fbar_k8;            // RNB_VARIANT_BF16: feature part of cinb as bf16 K8 [Mp,256] (written by the FB sweep)
   float* dw_part;           // RNB_VARIANT_DETERMINISTIC: partial slabs of the split-K weight-gradient GEMMs
   int64_t dw_part_floats;
@@ -172,9 +175,13 @@ int launch_scale_copy(const float* src, float scale, int64_t n, float* dst, hipS
 inline bool is_bf16(const Layout& L) { return (L.variant & RNB_VARIANT_BF16) != 0; }
 int bf16_pack_weights(const Layout& L, float* packed, hipStream_t s);
 int bf16_forward(const Layout& L, const float* packed, const float* pts, int64_t M, PointBufs& pb, bool save, bool need_feat,
-                 hipStream_t s, const GridGen* grid = nullptr);
+                 hipStream_t s, const GridGen* grid = nullptr, bool feat_k8 = false);
 int bf16_reverse(const Layout& L, const float* packed, PointBufs& pb, hipStream_t s);
-int bf16_backward(const Layout& L, const float* packed, PointBufs& pb, bool with_color, float* packed_grad, hipStream_t s);
+bool bf16_color_supported(const Layout& L);
+int bf16_color_forward(const Layout& L, const float* packed, PointBufs& pb, const float* pts, hipStream_t s);
+int bf16_color_backward(const Layout& L, const float* packed, PointBufs& pb, float* packed_grad, hipStream_t s);
+int bf16_backward(const Layout& L, const float* packed, PointBufs& pb, bool with_color, bool color_bf16, float* packed_grad,
+                  hipStream_t s);
 int64_t bf16_dw_partial_floats(const Layout& L, int64_t M, bool with_color);
 
 // ---- sampling / composite ------------------------------------------------------------------------
