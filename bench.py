@@ -71,6 +71,7 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--no-gemm-events", action="store_true")
     ap.add_argument("--deterministic", action="store_true", help="ordered reductions instead of fp32 atomics")
+    ap.add_argument("--dw-staged", action="store_true", help="A/B knob: LDS-DMA staged dW kernel for the 256x256 jobs")
     ap.add_argument("--fwd-ti", type=int, default=0, help="A/B knob: tile rows per wave of the forward sweep (1 | 2)")
     ap.add_argument("--bwd-ti", type=int, default=0, help="A/B knob: tile rows per wave of the backward sweeps (1 | 2)")
     ap.add_argument("--torch-train-ops", action="store_true",
@@ -223,7 +224,7 @@ def init_distributed(args):
     return world, rank, dev, backend, rehearsal
 
 
-def build_model(R, dev, samples, dtype, deterministic, fwd_ti=0, bwd_ti=0):
+def build_model(R, dev, samples, dtype, deterministic, fwd_ti=0, bwd_ti=0, dw_staged=False):
     import torch
     # confs/wmask_rnb.conf:53-90, constructed in the order of exp_runner.py:95-100 under seed 0
     torch.manual_seed(0)
@@ -234,7 +235,7 @@ def build_model(R, dev, samples, dtype, deterministic, fwd_ti=0, bwd_ti=0):
                              weight_norm=True, multires_view=4, squeeze_out=True).to(dev)
     ren = R.NeuSRenderer(None, sdf, devnet, col, n_samples=samples // 2, n_importance=samples // 2, n_outside=0,
                          up_sample_steps=4, perturb=1.0)
-    ren.set_variant(bf16=(dtype == "bf16"), deterministic=deterministic, fwd_ti=fwd_ti, bwd_ti=bwd_ti)
+    ren.set_variant(bf16=(dtype == "bf16"), deterministic=deterministic, fwd_ti=fwd_ti, bwd_ti=bwd_ti, dw_staged=dw_staged)
     return sdf, devnet, col, ren
 
 
@@ -251,7 +252,7 @@ def run_train(args):
     lib = R.native.load()
 
     S = args.samples
-    sdf, devnet, col, ren = build_model(R, dev, S, args.dtype, args.deterministic, args.fwd_ti, args.bwd_ti)
+    sdf, devnet, col, ren = build_model(R, dev, S, args.dtype, args.deterministic, args.fwd_ti, args.bwd_ti, args.dw_staged)
     exact_dp = not args.torch_train_ops     # the reference's torch-op loss knows nothing about shards
     if world > 1:
         P.broadcast_parameters([sdf, devnet, col])
@@ -414,7 +415,7 @@ def run_train(args):
                                       "scaling measurement")
         if cpu:
             line["gpu_over_cpu"] = round(value / cpu["value"], 1)
-        print(json.dumps(line), flush=True)
+        emit(line)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -494,16 +495,35 @@ def run_mesh(args):
             line["rehearsal"] = True
         if cpu:
             line["gpu_over_cpu"] = round(line["value"] / cpu["value"], 1)
-        print(json.dumps(line), flush=True)
+        emit(line)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+JSON_OUT = None
+
+
+def claim_stdout():
+    """The contract is ONE JSON line on stdout.  Native libraries (gloo's connection banner, the ROCm runtime) print
+    to file descriptor 1 behind Python's back, so fd 1 is pointed at stderr for the life of the process and the JSON
+    line goes to a private duplicate of the original stdout."""
+    global JSON_OUT
+    sys.stdout.flush()
+    JSON_OUT = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
+
+def emit(line):
+    JSON_OUT.write(json.dumps(line) + "\n")
+    JSON_OUT.flush()
 
 
 def main():
     args = parse()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args))
+    claim_stdout()
     if args.mode == "mesh":
         run_mesh(args)
     else:

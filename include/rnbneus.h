@@ -79,7 +79,12 @@ typedef struct rnb_model_desc {
  *   RNB_VARIANT_DETERMINISTIC split-K partial sums go to workspace slabs and are reduced in a fixed order instead of
  *                             through fp32 atomics: gradients are bit-reproducible from run to run and across ranks.
  *   RNB_VARIANT_GENERIC       per-layer GEMM chain for every sweep even when the fused kernels support the shape.
- *   RNB_VARIANT_DW_LDS        LDS-staged weight-gradient GEMMs instead of the register-direct ones.
+ *   RNB_VARIANT_DW_LDS        register-staged LDS weight-gradient GEMMs (the guarded generic kernel) for every job.
+ *   RNB_VARIANT_DW_STAGED     256 x 256 weight gradients through the LDS-DMA staged kernel (one 16-wave workgroup owns a
+ *                             whole gradient of a point range: every operand byte is fetched once, partial gradients
+ *                             leave through slabs + an ordered reduction, no atomics) instead of the register-direct
+ *                             128 x 128-tile kernel.  Halves the operand traffic of that launch; measured 2 % slower
+ *                             per step, hence not the default.
  *   RNB_VARIANT_*_TI/_NW      tile height (1: 32 points, 2: 64 points) / waves per workgroup (4 or 8) of the fused
  *                             backward sweeps (BWD) and of the fused forward (FWD); 0 = the measured default. */
 enum {
@@ -87,6 +92,7 @@ enum {
   RNB_VARIANT_DETERMINISTIC = 2,
   RNB_VARIANT_GENERIC = 4,
   RNB_VARIANT_DW_LDS = 8,
+  RNB_VARIANT_DW_STAGED = 16,
   RNB_VARIANT_BWD_TI_SHIFT = 8,   /* 2 bits: 0 default, 1, 2 */
   RNB_VARIANT_BWD_NW_SHIFT = 10,  /* 2 bits: 0 default, 1 = 4 waves, 2 = 8 waves */
   RNB_VARIANT_FWD_TI_SHIFT = 12,

@@ -1451,6 +1451,7 @@ int bf16_backward(const Layout& L, const float* packed, PointBufs& pb, bool with
   splits = (int)((M + rows - 1) / rows);
   grp.splits = splits;
   grp.rows_per_split = rows;
+  // (the staged fp32 kernel's slabs at the tail of the workspace are free again: its reduction was enqueued earlier)
   float* part = det ? pb.dw_part : nullptr;
   int64_t part_left = det ? pb.dw_part_floats : 0;
   double fl = 0;

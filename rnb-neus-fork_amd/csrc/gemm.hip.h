@@ -566,6 +566,133 @@ __global__ __launch_bounds__(256) void dw_reduce_kernel(const DwGroup g) {
   }
 }
 
+// ---- dW for 256 x 256 weight matrices, operands staged in LDS by LDS-DMA ---------------------------------------------
+// The register-direct kernel above gives every 128 x 128 tile its own workgroup, so each operand half is fetched by two
+// workgroups that are not synchronised: 2.0x the unique bytes at the memory side (profiles/hbm_traffic.json, round 1).
+// Here ONE workgroup of 16 waves owns the whole 256 x 256 gradient of a point range: per 32-point chunk the two operand
+// slabs (32 x 256 fp32 = 32 KB each, rows of the point-major matrices as they lie in memory) are copied global -> LDS by
+// global_load_lds_dwordx4 (no VGPR round trip) into two alternating buffers: one raw barrier per 32-point chunk, the
+// next chunk's DMAs in flight while this one is multiplied.  The fragments are what the direct kernel loads from global: lane (i, h)
+// reads X[m + h][2i, 2i + 1] (8 bytes: the wave's two row tiles are the even / odd rows of its 64-row band) and
+// Y[m + h][i], Y[m + h][32 + i] — conflict-free ds_read_b64 / ds_read_b32.  Wave (wm, wn) = rows 64 wm.., columns 64 wn...
+constexpr int kStChunk = 32;                    // points per chunk
+constexpr int kStOpBytes = kStChunk * 256 * 4;  // one operand slab (32 KB)
+constexpr int kStBufs = 2;                      // chunk c + 1 is copied while chunk c is multiplied
+
+__device__ inline void dw_staged_issue(const DwPair& p, int m_begin, int nchunks, int chunk, char* buf, int wave, int lane) {
+  const int c = chunk < nchunks ? chunk : nchunks - 1;   // past the end: harmless re-fetch, keeps vmcnt uniform
+#pragma unroll
+  for (int q = 0; q < kStChunk / 16; ++q) {
+    const int u = (q * 16 + wave) * 64 + lane;           // 16-byte unit of the slab: row u / 64, columns 4 (u % 64)..
+    const int row = m_begin + c * kStChunk + (u >> 6);
+    const float* xs = p.X + (size_t)row * p.ldx + (u & 63) * 4;
+    const float* ys = p.Y + (size_t)row * p.ldy + (u & 63) * 4;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)xs,
+                                     (__attribute__((address_space(3))) void*)(buf + (q * 16 + wave) * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ys,
+                                     (__attribute__((address_space(3))) void*)(buf + kStOpBytes + (q * 16 + wave) * 1024), 16, 0, 0);
+  }
+}
+
+template <int DUMMY>
+__global__ __launch_bounds__(1024, 1) void gemm_dw_staged_kernel(const DwGroup g) {
+  __shared__ __attribute__((aligned(16))) char lds[kStBufs * 2 * kStOpBytes];   // 128 KB: the only shared object
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = wave_id();
+  const int wm = wave >> 2, wn = wave & 3;
+  int ji = 0, begin = 0;
+  for (int q = 0; q + 1 < g.njobs; ++q)
+    if ((int)blockIdx.x >= g.job[q].block_end) { ji = q + 1; begin = g.job[q].block_end; }
+  const DwJob& J = g.job[ji];
+  const int split = (int)blockIdx.x - begin;
+  if (split >= J.splits) return;
+  const int m_begin = split * J.rows_per_split;
+  const int m_end = min(g.M, m_begin + J.rows_per_split);
+  if (m_begin >= m_end) return;
+  const int nchunks = (m_end - m_begin) / kStChunk;   // ranges are multiples of the chunk (host)
+  const int i = lane & 31, h = lane >> 5;
+  v16f acc[2][2];
+  zero_acc<2>(acc);
+  double bs0 = 0.0, bs1 = 0.0;
+  const bool bias_wave = J.db != nullptr && wn == 0;
+  for (int pi = 0; pi < J.npairs; ++pi) {
+    const DwPair p = pi == 0 ? J.p1 : J.p2;
+    const bool do_bias = bias_wave && pi == J.bias_pair;
+    __builtin_amdgcn_s_barrier();   // every wave is done with the buffers of the previous pair
+    dw_staged_issue(p, m_begin, nchunks, 0, lds, wave, lane);
+    for (int c = 0; c < nchunks; ++c) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of chunk c has landed
+      __builtin_amdgcn_s_barrier();                      // ... every wave's; and chunk c - 1 has been read by all
+      dw_staged_issue(p, m_begin, nchunks, c + 1, lds + ((c + 1) & 1) * 2 * kStOpBytes, wave, lane);
+      const char* bx = lds + (c & 1) * 2 * kStOpBytes;
+      const char* by = bx + kStOpBytes;
+      float t0 = 0.f, t1 = 0.f;
+      // fragments of point pair q + 1 are read while the four MFMAs of pair q run (explicit two-deep rotation: left to
+      // itself the compiler waits for each pair's reads right in front of its MFMAs)
+      const char* ax = bx + h * 1024 + (wm * 64 + 2 * i) * 4;
+      const char* ay = by + h * 1024 + (wn * 64 + i) * 4;
+      vf2 a0 = *reinterpret_cast<const vf2*>(ax);
+      float b00 = *reinterpret_cast<const float*>(ay), b01 = *reinterpret_cast<const float*>(ay + 128);
+#pragma unroll
+      for (int q = 0; q < kStChunk / 2; q += 2) {
+        const vf2 a1 = *reinterpret_cast<const vf2*>(ax + (q + 1) * 2048);
+        const float b10 = *reinterpret_cast<const float*>(ay + (q + 1) * 2048);
+        const float b11 = *reinterpret_cast<const float*>(ay + (q + 1) * 2048 + 128);
+        __builtin_amdgcn_sched_barrier(0);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b00, acc[0][0], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b00, acc[1][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b01, acc[0][1], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b01, acc[1][1], 0, 0, 0);
+        if (do_bias) { t0 += a0.x; t1 += a0.y; }
+        __builtin_amdgcn_sched_barrier(0);
+        if (q + 2 < kStChunk / 2) {
+          a0 = *reinterpret_cast<const vf2*>(ax + (q + 2) * 2048);
+          b00 = *reinterpret_cast<const float*>(ay + (q + 2) * 2048);
+          b01 = *reinterpret_cast<const float*>(ay + (q + 2) * 2048 + 128);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b10, acc[0][0], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b10, acc[1][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b11, acc[0][1], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b11, acc[1][1], 0, 0, 0);
+        if (do_bias) { t0 += a1.x; t1 += a1.y; }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (do_bias) { bs0 += (double)t0; bs1 += (double)t1; }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's LDS reads of chunk c are complete
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the over-fetched chunk before the buffers are reused
+  }
+  // accumulator (ti, tj, r) of lane (i, h) is dW[64 wm + 2 rho + ti][64 wn + 32 tj + i], rho = (r & 3) + 8 (r >> 2) + 4 h
+  const int lddw = J.lddw;
+  float* __restrict__ pdst = J.part ? J.part + (size_t)split * J.N * lddw : nullptr;
+#pragma unroll
+  for (int tj = 0; tj < 2; ++tj) {
+    const int col = wn * 64 + tj * 32 + i;
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * 64 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * h) + ti;
+        if (pdst) pdst[(size_t)row * lddw + col] = acc[ti][tj][r];
+        else atomicAdd(J.dW + (size_t)row * lddw + col, acc[ti][tj][r]);
+      }
+  }
+  if (bias_wave) {
+    bs0 += __shfl_xor(bs0, 32, 64);
+    bs1 += __shfl_xor(bs1, 32, 64);
+    if (h == 0) {
+      if (J.partb) {
+        J.partb[(size_t)split * J.N + wm * 64 + 2 * i] = (float)bs0;
+        J.partb[(size_t)split * J.N + wm * 64 + 2 * i + 1] = (float)bs1;
+      } else {
+        atomicAdd(J.db + wm * 64 + 2 * i, (float)bs0);
+        atomicAdd(J.db + wm * 64 + 2 * i + 1, (float)bs1);
+      }
+    }
+  }
+}
+
 // ---- activation helpers ----------------------------------------------------------------------------
 // nn.Softplus(beta=100) with PyTorch's threshold 20 (models/fields.py:80)
 __device__ inline float softplus100(float z) {

@@ -44,7 +44,7 @@ int make_layout(const rnb_model_desc* d, Layout* L) {
   if (d->sdf_multires < 0 || d->sdf_multires > 16) RNB_FAIL(RNB_E_INVALID, "bad sdf_multires");
   if (!(d->sdf_scale > 0.f)) RNB_FAIL(RNB_E_INVALID, "sdf_scale must be positive");
   L->variant = d->variant;
-  if (d->variant & ~0xFF0F) RNB_FAIL(RNB_E_INVALID, "unknown bits in rnb_model_desc.variant (0x%x)", d->variant);
+  if (d->variant & ~0xFF1F) RNB_FAIL(RNB_E_INVALID, "unknown bits in rnb_model_desc.variant (0x%x)", d->variant);
   L->nh = d->sdf_n_layers;
   L->multires = d->sdf_multires;
   L->pe = 3 * (1 + 2 * d->sdf_multires);
@@ -160,10 +160,12 @@ void carve_points(const Layout& L, Carver& c, int64_t M, int mode, PointBufs* pb
       if (bf && bf16_color_supported(L))
         for (int l = 0; l < L.nc; ++l) pb->zc8[l] = c.take<uint16_t>(Mp * L.Hcp);
     }
-    if (L.variant & RNB_VARIANT_DETERMINISTIC) {
-      pb->dw_part_floats = dw_partial_floats(L, M, (mode & PM_WITH_COLOR) != 0) +
-                           (bf ? bf16_dw_partial_floats(L, M, (mode & PM_WITH_COLOR) != 0) : 0);
-      pb->dw_part = c.take<float>(pb->dw_part_floats);
+    {
+      const bool wc = (mode & PM_WITH_COLOR) != 0;
+      pb->dw_part_floats = dw_staged_floats(L, M, wc);
+      if (L.variant & RNB_VARIANT_DETERMINISTIC)
+        pb->dw_part_floats += dw_partial_floats(L, M, wc) + (bf ? bf16_dw_partial_floats(L, M, wc) : 0);
+      pb->dw_part = c.take<float>(pb->dw_part_floats > 0 ? pb->dw_part_floats : 64);
     }
   }
 }

@@ -615,17 +615,85 @@ static void dw_plan(int64_t M, int N, int K, int* v_out, int* splits_out, int* r
   *rows_out = rows;
 }
 
+// Point split of the staged 256 x 256 kernel: one workgroup per (job, split) and ONE round of workgroups (<= 256, one per
+// CU), each job's share of them proportional to its work (operand pairs), so every CU multiplies for the whole launch.
+// Partial gradients leave through plain stores into slabs that dw_reduce_kernel sums in split order: an fp32 atomic tail
+// of 256 KB per workgroup would cost ~50 us per round at the chip's ~1.3 TB/s atomic rate, with nothing to hide under.
+static void dw_staged_plan(int64_t M, int npairs, int total_pairs, int* splits_out, int* rows_out) {
+  int splits = total_pairs > 0 ? (256 * npairs) / total_pairs : 1;
+  if (splits < 1) splits = 1;
+  int64_t rows = (M + splits - 1) / splits;
+  rows = (rows + kStChunk - 1) / kStChunk * kStChunk;
+  if (rows < 2 * kStChunk) rows = 2 * kStChunk;
+  splits = (int)((M + rows - 1) / rows);     // every split is non-empty: the reduction reads every slab
+  *splits_out = splits;
+  *rows_out = (int)rows;
+}
+
 struct DwBatch {
-  DwGroup grp[3];     // [0] K % 128 == 0, [1] K % 64 == 0, [2] anything (guarded)
-  double flops[3];
+  DwGroup grp[4];     // [0] K % 128 == 0, [1] K % 64 == 0, [2] anything (guarded), [3] 256 x 256 (LDS-DMA staged)
+  double flops[4];
   int64_t M;
   hipStream_t s;
   bool lds_path;      // RNB_VARIANT_DW_LDS: staged-through-LDS kernels (A/B switch)
+  bool no_staged = true;    // RNB_VARIANT_DW_STAGED clears it: 256 x 256 jobs through the LDS-DMA staged kernel
   float* part;        // RNB_VARIANT_DETERMINISTIC: bump allocator over the zeroed partial-slab workspace (or nullptr)
   int64_t part_left;
-  DwBatch(int64_t M_, hipStream_t s_, bool lds_path_, float* part_, int64_t part_floats)
-      : M(M_), s(s_), lds_path(lds_path_), part(part_), part_left(part_floats) {
-    for (int v = 0; v < 3; ++v) { grp[v].njobs = 0; grp[v].M = (int)M_; flops[v] = 0.0; }
+  float* slab;        // slabs of the staged 256 x 256 kernel (always; the tail of the same workspace)
+  int64_t slab_left;
+  DwBatch(int64_t M_, hipStream_t s_, bool lds_path_, float* part_, int64_t part_floats, float* slab_, int64_t slab_floats)
+      : M(M_), s(s_), lds_path(lds_path_), part(part_), part_left(part_floats), slab(slab_), slab_left(slab_floats) {
+    for (int v = 0; v < 4; ++v) { grp[v].njobs = 0; grp[v].M = (int)M_; flops[v] = 0.0; }
+  }
+  // the staged kernel: every job of the group is split the same way, decided when the group is complete
+  int flush_staged() {
+    DwGroup& g = grp[3];
+    if (g.njobs == 0) return RNB_OK;
+    int total_pairs = 0;
+    for (int q = 0; q < g.njobs; ++q) total_pairs += g.job[q].npairs;
+    for (int a = 0, b = g.njobs - 1; a < b; ++a, --b) {   // most recently produced operands first (see flush)
+      const DwJob t = g.job[a];
+      g.job[a] = g.job[b];
+      g.job[b] = t;
+    }
+    int end = 0;
+    for (int q = 0; q < g.njobs; ++q) {
+      DwJob& j = g.job[q];
+      int splits, rows;
+      dw_staged_plan(M, j.npairs, total_pairs, &splits, &rows);
+      {   // never more slabs than the workspace holds (a group smaller than the one the workspace was sized for)
+        const int64_t per_split = (int64_t)j.N * j.lddw + j.N;
+        const int64_t room = slab != nullptr ? slab_left / per_split / (g.njobs - q) : 0;
+        if (room < 1) RNB_FAIL(RNB_E_WORKSPACE, "weight-gradient slab workspace exhausted");
+        if (splits > room) {
+          splits = (int)room;
+          int64_t r = (M + splits - 1) / splits;
+          r = (r + kStChunk - 1) / kStChunk * kStChunk;
+          rows = (int)r;
+          splits = (int)((M + rows - 1) / rows);
+        }
+      }
+      j.splits = splits;
+      j.rows_per_split = rows;
+      end += splits;
+      j.block_end = end;
+      const int64_t need = (int64_t)splits * j.N * j.lddw + (int64_t)splits * j.N;
+      if (slab == nullptr || need > slab_left) RNB_FAIL(RNB_E_WORKSPACE, "weight-gradient slab workspace exhausted");
+      j.part = slab;
+      j.partb = slab + (int64_t)splits * j.N * j.lddw;
+      slab += need;
+      slab_left -= need;
+    }
+    {
+      ProfScope prof(flops[3], s);
+      hipLaunchKernelGGL(gemm_dw_staged_kernel<0>, dim3((unsigned)end), dim3(1024), 0, s, g);
+      RNB_CHECK_LAUNCH();
+      hipLaunchKernelGGL(dw_reduce_kernel<0>, dim3(64, g.njobs), dim3(256), 0, s, g);
+    }
+    g.njobs = 0;
+    flops[3] = 0.0;
+    RNB_CHECK_LAUNCH();
+    return RNB_OK;
   }
   int flush(int v) {
     DwGroup& g = grp[v];
@@ -669,6 +737,16 @@ struct DwBatch {
   int add(DwPair p1, DwPair p2, int npairs, int N, int K, float* dW, int lddw, float* db, int bias_pair, double fl) {
     int v, splits, rows;
     dw_plan(M, N, K, &v, &splits, &rows);
+    if (v == 0 && N == 256 && K == 256 && M % kStChunk == 0 && !lds_path && !no_staged) {   // -> the staged kernel
+      if (grp[3].njobs == kMaxDwJobs) RNB_TRY(flush_staged());
+      DwJob& j = grp[3].job[grp[3].njobs++];
+      j.p1 = p1; j.p2 = p2; j.dW = dW; j.db = db;
+      j.part = nullptr; j.partb = nullptr;
+      j.npairs = npairs; j.N = N; j.K = K; j.lddw = lddw; j.bias_pair = bias_pair;
+      j.splits = 0; j.rows_per_split = 0; j.block_end = 0;
+      flops[3] += fl;
+      return RNB_OK;
+    }
     if (grp[v].njobs == kMaxDwJobs) RNB_TRY(flush(v));
     const int kt = v == 0 ? 128 : 64;
     const int tiles = ((N + 127) / 128) * ((K + kt - 1) / kt);
@@ -696,6 +774,7 @@ struct DwBatch {
   }
   int flush_all() {
     RNB_TRY(flush(1));   // holds the first layer's job: its operands are the most recent
+    RNB_TRY(flush_staged());
     RNB_TRY(flush(0));
     return flush(2);
   }
@@ -703,6 +782,30 @@ struct DwBatch {
 
 // floats of partial-slab workspace the deterministic variant needs for one backward over M points: the same job list
 // as sweep_backward
+// floats of slab workspace of the staged kernel for one backward over M points (the 256 x 256 jobs of sweep_backward)
+int64_t dw_staged_floats(const Layout& L, int64_t M, bool with_color) {
+  int total_pairs = 0;
+  for (int l = 0; l < L.nh; ++l) total_pairs += 2 * (L.hid[l].Np == 256 && L.hid[l].Kp == 256);
+  if (with_color) {
+    total_pairs += (L.feat.Np == 256 && L.feat.Kp == 256);
+    for (int l = 0; l < L.nc; ++l) total_pairs += (L.col[l].Np == 256 && L.col[l].Kp == 256);
+  }
+  int64_t total = 0;
+  auto job = [&](const Lin& ln, int npairs) {
+    if (ln.Np != 256 || ln.Kp != 256) return;
+    int splits, rows;
+    dw_staged_plan(M, npairs, total_pairs, &splits, &rows);
+    total += (int64_t)splits * 256 * 256 + (int64_t)splits * 256;
+  };
+  for (int l = 0; l < L.nh; ++l) job(L.hid[l], 2);
+  if (with_color) {
+    job(L.feat, 1);
+    for (int l = 0; l < L.nc; ++l) job(L.col[l], 1);
+  }
+  return total;
+}
+
+// floats of ordered-reduction workspace of the atomic kernels (RNB_VARIANT_DETERMINISTIC), same job list as sweep_backward
 int64_t dw_partial_floats(const Layout& L, int64_t M, bool with_color) {
   int64_t total = 0;
   auto job = [&](int N, int K) {
@@ -819,11 +922,14 @@ int sweep_backward(const Layout& L, const float* packed, PointBufs& pb, bool wit
                    bool fused, hipStream_t s) {
   const int64_t M = pb.M, Mp = pb.Mp;
   const bool det = (L.variant & RNB_VARIANT_DETERMINISTIC) != 0;
-  if (det) {
-    if (pb.dw_part == nullptr) RNB_FAIL(RNB_E_WORKSPACE, "deterministic variant: no partial-slab workspace was carved");
-    RNB_CHECK_HIP(hipMemsetAsync(pb.dw_part, 0, (size_t)pb.dw_part_floats * sizeof(float), s));
-  }
-  DwBatch dw(M, s, (L.variant & RNB_VARIANT_DW_LDS) != 0, det ? pb.dw_part : nullptr, det ? pb.dw_part_floats : 0);
+  if (pb.dw_part == nullptr) RNB_FAIL(RNB_E_WORKSPACE, "no weight-gradient slab workspace was carved");
+  // workspace = [ordered-reduction slabs of the atomic kernels (deterministic variant only) | slabs of the staged kernel]
+  const int64_t staged_floats = dw_staged_floats(L, M, with_color);
+  const int64_t det_floats = pb.dw_part_floats - staged_floats;
+  if (det) RNB_CHECK_HIP(hipMemsetAsync(pb.dw_part, 0, (size_t)det_floats * sizeof(float), s));
+  DwBatch dw(M, s, (L.variant & RNB_VARIANT_DW_LDS) != 0, det ? pb.dw_part : nullptr, det ? det_floats : 0,
+             pb.dw_part + det_floats, staged_floats);
+  dw.no_staged = (L.variant & RNB_VARIANT_DW_STAGED) == 0;
   const bool color_bf16 = is_bf16(L) && with_color && bf16_color_supported(L) && pb.cin8 != nullptr;
   // ---- C': albedo network backward ---------------------------------------------------------------
   if (color_bf16) {

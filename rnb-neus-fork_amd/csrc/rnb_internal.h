@@ -141,7 +141,7 @@ struct PointBufs {
   void* ac8[RNB_MAX_LIN];   //   hidden activations as bf16 K8 [Mp,256]
   void* zc8[RNB_MAX_LIN];   //   pre-activation adjoints as bf16 K8 [Mp,256]
   void* fbar_k8;            // RNB_VARIANT_BF16: feature part of cinb as bf16 K8 [Mp,256] (written by the FB sweep)
-  float* dw_part;           // RNB_VARIANT_DETERMINISTIC: partial slabs of the split-K weight-gradient GEMMs
+  float* dw_part;           // partial slabs of the split-K weight-gradient GEMMs: [deterministic variant | staged kernel]
   int64_t dw_part_floats;
 };
 
@@ -158,6 +158,7 @@ int sweep_color(const Layout& L, const float* packed, PointBufs& pb, const float
 int launch_copy_cols(const float* src, int ld, int ncols, int64_t M, float* out, hipStream_t s);
 int launch_fill_cols(const float* src, int ncols, int64_t M, int64_t Mp, int ld, float* dst, hipStream_t s);
 int64_t dw_partial_floats(const Layout& L, int64_t M, bool with_color);
+int64_t dw_staged_floats(const Layout& L, int64_t M, bool with_color);
 int sweep_backward(const Layout& L, const float* packed, PointBufs& pb, bool with_color, float* packed_grad,
                    bool fused, hipStream_t s);
 int fused_reverse(const Layout& L, const float* packed, PointBufs& pb, hipStream_t s);

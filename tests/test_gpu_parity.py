@@ -460,6 +460,7 @@ def test_fused_and_generic_paths_agree(R):
     res = {}
     z = None
     for tag, kw in (("fused", {}), ("generic", dict(generic=True)), ("dw_lds", dict(dw_lds=True)),
+                    ("dw_staged", dict(dw_staged=True)), ("dw_staged_det", dict(dw_staged=True, deterministic=True)),
                     ("bwd_ti1", dict(bwd_ti=1, bwd_nw=4)), ("bwd_ti2", dict(bwd_ti=2, bwd_nw=4)),
                     ("bwd_ti2_nw8", dict(bwd_ti=2, bwd_nw=8)), ("fwd_ti1", dict(fwd_ti=1, fwd_nw=4)),
                     ("deterministic", dict(deterministic=True))):
