@@ -380,7 +380,7 @@ def run_train(args):
                         "traffic": round(tr["hbm_bytes_per_launch"]) if tr else None,
                         "traffic_unit": "HBM bytes per launch",
                         "algorithmic_bytes_per_step": alg,
-                        "kernel": "bf16-MFMA family: bf_forward/reverse/ra/fb_kernel, bf_dw_kernel (+ the fp32 albedo GEMMs)",
+                        "kernel": "bf16-MFMA family: bf_forward/reverse/ra/fb_kernel, bf_color_fwd/bwd_kernel, bf_dw_kernel",
                         "mfma_tflops": round(ach, 2), "mfma_frac_of_bf16_peak": round(ach / BF16_MFMA_PEAK_TFLOPS, 4),
                         "step_frac_of_bf16_peak": round(step_tf / BF16_MFMA_PEAK_TFLOPS, 4)}
                 roof.update(common)
