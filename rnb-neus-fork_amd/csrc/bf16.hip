@@ -41,6 +41,10 @@ __device__ inline unsigned pack2(float a, float b) {
   bf2 p = {(__bf16)a, (__bf16)b};   // v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN
   return __builtin_bit_cast(unsigned, p);
 }
+// A value the optimiser cannot see through: address arithmetic derived from it is redone where it is used instead of
+// being hoisted out of the layer loop (loop-invariant per-lane offsets of ~40 loads and stores, kept live across the
+// matrix loop, were what spilled in the sweeps with two epilogue operand tiles).
+__device__ inline int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
 __device__ inline bfraw to_bf(float a) { return __builtin_bit_cast(bfraw, (__bf16)a); }
 __device__ inline float bf_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
 __device__ inline float bf_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
@@ -56,30 +60,44 @@ __device__ inline size_t k8(int64_t row, int col, int C) { return ((size_t)(row 
 // register set (two alternating sets, no copies).
 // KS = 16-k steps per prefetched weight block: 4 (two register sets of 32) at TI = 2, 2 (two sets of 16) at TI = 1,
 // where four resident waves per SIMD cover the L2 latency instead of a deeper per-wave prefetch.
+// Weight matrices in the bf16 mirror are stored in MFMA-FRAGMENT ORDER (bf16_pack_weights): for W [N][K], fragment
+// (nt, ks) = rows 32 nt .. +32, k = 16 ks .. +16 is 64 consecutive 16-byte units, unit (h, c) = W[32 nt + c][16 ks + 8 h .. +8].
+// One B-fragment load of a wave is then ONE contiguous 1 KB read (8 cache lines).  Row-major weights make the same
+// load touch 32 lines (32 bytes of each of 32 rows) — at 8 loads per 16 MFMAs that kept the L1 tag pipeline, not the
+// matrix cores, busy: the sweeps ran at 14 % of the bf16 MFMA rate.
 template <int KS>
 __device__ inline void bf_load_b(const bfraw* __restrict__ W, int K, int n0, int Q, int lane, vu4 (&b)[KS][2]) {
-  const int i = lane & 31, h = lane >> 5;
+  const int nks = K >> 4;
 #pragma unroll
   for (int tj = 0; tj < 2; ++tj) {
-    const bfraw* p = W + (size_t)(n0 + tj * 32 + i) * K + Q * (16 * KS) + h * 8;
+    const bfraw* p = W + ((size_t)((n0 >> 5) + tj) * nks + Q * KS) * 512 + lane * 8;
 #pragma unroll
-    for (int s = 0; s < KS; ++s) b[s][tj] = *reinterpret_cast<const vu4*>(p + s * 16);
+    for (int s = 0; s < KS; ++s) b[s][tj] = *reinterpret_cast<const vu4*>(p + s * 512);
   }
 }
+// One 16 KS-k block: the A fragments of step s + 1 are read from LDS while the MFMAs of step s run (explicit rotation +
+// a scheduling fence per step: left alone, hipcc parks every ds_read right in front of its MFMAs and waits for it).
 template <int TI, int KS, int PITCH>
 __device__ inline void bf_mma_block(const bfraw* __restrict__ X, int Q, int lane, const vu4 (&b)[KS][2], v16f (&acc)[TI][2]) {
   const int i = lane & 31, h = lane >> 5;
+  const bfraw* xp = X + i * PITCH + Q * (16 * KS) + h * 8;
+  vu4 a[2][TI];
+#pragma unroll
+  for (int ti = 0; ti < TI; ++ti) a[0][ti] = *reinterpret_cast<const vu4*>(xp + ti * 32 * PITCH);
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
-    vu4 a[TI];
+    if (s + 1 < KS) {
 #pragma unroll
-    for (int ti = 0; ti < TI; ++ti) a[ti] = *reinterpret_cast<const vu4*>(X + (ti * 32 + i) * PITCH + Q * (16 * KS) + s * 16 + h * 8);
+      for (int ti = 0; ti < TI; ++ti) a[(s + 1) & 1][ti] = *reinterpret_cast<const vu4*>(xp + ti * 32 * PITCH + (s + 1) * 16);
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
       for (int ti = 0; ti < TI; ++ti)
-        acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, a[ti]), __builtin_bit_cast(bf8, b[s][tj]),
+        acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, a[s & 1][ti]), __builtin_bit_cast(bf8, b[s][tj]),
                                                               acc[ti][tj], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 template <int TI>
@@ -91,23 +109,52 @@ __device__ inline void bf_zero(v16f (&acc)[TI][2]) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 }
-// X points at the first of the wave's 32 TI rows
+// X points at the first of the wave's 32 TI rows.
+// `pre` holds weight block 0 of THIS product, requested by the previous call (`Wnext` / `Knext`: the product that
+// follows; its block 0 is requested here as soon as this product's last block is in flight, so that it lands during
+// the epilogue instead of costing an exposed L2 round trip at the top of every layer).  The block loop is unrolled for
+// the compile-time block count NQ (K = 64 NQ / (4 / KS)): two alternating register sets, no copies for even NQ.
+template <int TI, int PITCH = BP, int KSV = (TI == 1 ? 2 : 4)>
+struct BfMma {
+  static constexpr int KS = KSV;
+  vu4 pre[KS][2];
+  __device__ inline void request(const bfraw* __restrict__ W, int K, int n0, int lane) { bf_load_b<KS>(W, K, n0, 0, lane, pre); }
+  template <int NQ>
+  __device__ inline void run_fixed(const bfraw* __restrict__ X, const bfraw* __restrict__ W, int K, int n0, int lane,
+                                   v16f (&acc)[TI][2], const bfraw* __restrict__ Wnext, int Knext, int n0next) {
+    bf_zero<TI>(acc);
+    vu4 alt[KS][2];
+#pragma unroll
+    for (int Q = 0; Q < NQ; ++Q) {
+      // request the block after this one into the set that is not being multiplied
+      if (Q + 1 < NQ) {
+        if (Q & 1) bf_load_b<KS>(W, K, n0, Q + 1, lane, pre); else bf_load_b<KS>(W, K, n0, Q + 1, lane, alt);
+      } else if (Wnext) {
+        if (Q & 1) bf_load_b<KS>(Wnext, Knext, n0next, 0, lane, pre); else bf_load_b<KS>(Wnext, Knext, n0next, 0, lane, alt);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (Q & 1) bf_mma_block<TI, KS, PITCH>(X, Q, lane, alt, acc); else bf_mma_block<TI, KS, PITCH>(X, Q, lane, pre, acc);
+    }
+    if ((NQ & 1) && Wnext) {   // odd block count: the next product's block 0 sits in `alt`
+#pragma unroll
+      for (int s = 0; s < KS; ++s) { pre[s][0] = alt[s][0]; pre[s][1] = alt[s][1]; }
+    }
+  }
+  // K is one of 64 (PE input), 256 (hidden) or 320 (the albedo net's input): the call sites know which
+  template <int KK>
+  __device__ inline void run(const bfraw* __restrict__ X, const bfraw* __restrict__ W, int n0, int lane, v16f (&acc)[TI][2],
+                             const bfraw* __restrict__ Wnext, int Knext, int n0next) {
+    run_fixed<KK / (16 * KS)>(X, W, KK, n0, lane, acc, Wnext, Knext, n0next);
+  }
+};
 template <int TI, int PITCH = BP>
 __device__ inline void bf_layer_mma(const bfraw* __restrict__ X, const bfraw* __restrict__ W, int K, int n0, int lane,
                                     v16f (&acc)[TI][2]) {
-  constexpr int KS = TI == 1 ? 2 : 4;
-  bf_zero<TI>(acc);
-  const int nQ = K / (16 * KS);   // (K is a multiple of 64)
-  vu4 b0[KS][2], b1[KS][2];
-  bf_load_b<KS>(W, K, n0, 0, lane, b0);
-  for (int Q = 0; Q < nQ; Q += 2) {
-    if (Q + 1 < nQ) bf_load_b<KS>(W, K, n0, Q + 1, lane, b1);
-    bf_mma_block<TI, KS, PITCH>(X, Q, lane, b0, acc);
-    if (Q + 1 < nQ) {
-      if (Q + 2 < nQ) bf_load_b<KS>(W, K, n0, Q + 2, lane, b0);
-      bf_mma_block<TI, KS, PITCH>(X, Q + 1, lane, b1, acc);
-    }
-  }
+  BfMma<TI, PITCH> m;
+  m.request(W, K, n0, lane);
+  if (K == 256) m.template run<256>(X, W, n0, lane, acc, nullptr, 0, 0);
+  else if (K == 64) m.template run<64>(X, W, n0, lane, acc, nullptr, 0, 0);
+  else m.template run<320>(X, W, n0, lane, acc, nullptr, 0, 0);
 }
 
 // ---- accumulator-layout access to K8 matrices -------------------------------------------------------------------
@@ -269,9 +316,18 @@ __global__ __launch_bounds__(BfCfg<TI>::NT, TI == 1 ? 4 : 2) void bf_forward_ker
   }
 
   v16f acc[TI][2];
+  // cross-layer weight prefetch (the next layer's block 0 in flight during the epilogue) only where the registers are
+  // free: with SAVE the epilogue also holds the D values and the packed stores (29 spilled registers otherwise)
+  constexpr bool XL = true;
+  BfMma<TI> mm;
+  if (XL) mm.request(g.wbf + g.w_off[0], g.Kp[0], n0, lane);
   for (int l = 0; l < g.nh; ++l) {
-    bf_layer_mma<TI>(Xw, g.wbf + g.w_off[l], g.Kp[l], n0, lane, acc);
+    const bfraw* wn = !XL ? nullptr : (l + 1 < g.nh ? g.wbf + g.w_off[l + 1] : (g.with_feat ? g.wbf + g.wf_off : nullptr));
+    if (!XL) mm.request(g.wbf + g.w_off[l], g.Kp[l], n0, lane);
+    if (l == 0) mm.template run<64>(Xw, g.wbf + g.w_off[0], n0, lane, acc, wn, FH, n0);   // (fused_supported: Ep = 64, hidden 256)
+    else mm.template run<256>(Xw, g.wbf + g.w_off[l], n0, lane, acc, wn, FH, n0);
     lds_barrier();   // every wave has finished reading the input activations (the tile is updated in place)
+    const int lo = opaque(lane), h = lo >> 5, cl = lo & 31;
     const float* bias = g.packed + g.b_off[l];
     const int n_real = g.n_real[l];
     const bool pe_tail = (l + 1 == g.skip);
@@ -293,13 +349,12 @@ __global__ __launch_bounds__(BfCfg<TI>::NT, TI == 1 ? 4 : 2) void bf_forward_ker
           } else {   // only the tile straddling the skip connection's PE columns
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              const int row = rb + ti * 32 + 8 * q + 4 * h + j;
               if (real) softplus_aD_fast(acc[ti][tj][4 * q + j] + bc, a[j], D[j]);
-              else { a[j] = pe_col ? E[row * FEP + (col - n_real)] : 0.f; D[j] = 0.f; }
+              else { a[j] = pe_col ? E[(rb + 4 * h) * FEP + (col - n_real) + (ti * 32 + 8 * q + j) * FEP] : 0.f; D[j] = 0.f; }
             }
           }
 #pragma unroll
-          for (int j = 0; j < 4; ++j) X[(rb + ti * 32 + 8 * q + 4 * h + j) * BP + col] = to_bf(a[j]);
+          for (int j = 0; j < 4; ++j) X[(rb + 4 * h) * BP + col + (ti * 32 + 8 * q + j) * BP] = to_bf(a[j]);
           if (SAVE) {
             k8_store_quad(g.a[l], rowW, ti, q, col, h, a[0], a[1], a[2], a[3]);
             k8_store_quad(g.D[l], rowW, ti, q, col, h, D[0], D[1], D[2], D[3]);
@@ -333,7 +388,8 @@ __global__ __launch_bounds__(BfCfg<TI>::NT, TI == 1 ? 4 : 2) void bf_forward_ker
   }
   // ---- feature head: rows 1.. of the output layer, written (fp32) into the albedo network's input -------------------
   if (g.with_feat) {
-    bf_layer_mma<TI>(Xw, g.wbf + g.wf_off, FH, n0, lane, acc);
+    if (!XL) mm.request(g.wbf + g.wf_off, FH, n0, lane);
+    mm.template run<256>(Xw, g.wbf + g.wf_off, n0, lane, acc, nullptr, 0, 0);   // (XL: block 0 was requested by the last hidden layer)
     const float* bias = g.packed + g.bf_off;
 #pragma unroll
     for (int tj = 0; tj < 2; ++tj) {
@@ -426,32 +482,42 @@ __global__ __launch_bounds__(BfCfg<TI>::NT, TI == 1 ? 4 : 2) void bf_reverse_ker
 
   v16f acc[TI][2];
   AuxBf<TI> aD;
+  BfMma<TI> mm;
+  mm.request(g.wbf + g.wT_off[g.nh - 1], FH, n0, lane);
   for (int l = g.nh - 1; l >= 1; --l) {
-    k8_prefetch<TI>(g.D[l - 1], rowW, n0, lane, aD);
-    bf_layer_mma<TI>(Xw, g.wbf + g.wT_off[l], FH, n0, lane, acc);   // g = gz_l W_l  (columns = inputs of layer l)
+    k8_prefetch<TI>(g.D[l - 1], rowW, n0, opaque(lane), aD);
+    const bfraw* wn = (l > 1 || n0 < 64) ? g.wbf + g.wT_off[l - 1] : nullptr;   // layer 0's product: wave(s) of columns 0..63
+    mm.template run<256>(Xw, g.wbf + g.wT_off[l], n0, lane, acc, wn, FH, n0);   // g = gz_l W_l  (columns = inputs of layer l)
     lds_barrier();
+    const int lo = opaque(lane), h = lo >> 5, cl = lo & 31;
     const bool is_skip = (l == g.skip);
     const int ksplit = is_skip ? FH - g.pe : FH;   // columns that belong to layer l-1's output
 #pragma unroll
     for (int tj = 0; tj < 2; ++tj) {
       const int col = n0 + tj * 32 + cl;
+      const bool tile_full = n0 + tj * 32 + 32 <= ksplit;   // wave-uniform: no per-element column tests
 #pragma unroll
       for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           float o[4];
+          if (tile_full) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int r = 4 * q + j;
-            const int row = rb + ti * 32 + 8 * q + 4 * h + j;
-            const float v = acc[ti][tj][r];
-            if (col < ksplit) o[j] = v * aux_at(aD, ti, tj, r);
-            else {
-              if (col < ksplit + g.pe) GE[row * FEP + (col - ksplit)] = v;   // skip connection: straight to g_e
-              o[j] = 0.f;
+            for (int j = 0; j < 4; ++j) o[j] = acc[ti][tj][4 * q + j] * aux_at(aD, ti, tj, 4 * q + j);
+          } else {   // only the tile straddling the skip connection's PE columns
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int r = 4 * q + j;
+              const float v = acc[ti][tj][r];
+              if (col < ksplit) o[j] = v * aux_at(aD, ti, tj, r);
+              else {
+                if (col < ksplit + g.pe) GE[(rb + 4 * h) * FEP + (col - ksplit) + (ti * 32 + 8 * q + j) * FEP] = v;   // skip connection: straight to g_e
+                o[j] = 0.f;
+              }
             }
-            X[row * BP + col] = to_bf(o[j]);
           }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) X[(rb + 4 * h) * BP + col + (ti * 32 + 8 * q + j) * BP] = to_bf(o[j]);
           k8_store_quad(g.gz[l - 1], rowW, ti, q, col, h, o[0], o[1], o[2], o[3]);
         }
     }
@@ -459,7 +525,8 @@ __global__ __launch_bounds__(BfCfg<TI>::NT, TI == 1 ? 4 : 2) void bf_reverse_ker
   }
   // layer 0: g_e += gz_0 W_0 (Ep = 64 columns: wave 0)
   if (n0 < 64) {
-    bf_layer_mma<TI>(Xw, g.wbf + g.wT_off[0], FH, n0, lane, acc);
+    if (g.nh == 1) mm.request(g.wbf + g.wT_off[0], FH, n0, lane);
+    mm.template run<256>(Xw, g.wbf + g.wT_off[0], n0, lane, acc, nullptr, 0, 0);
 #pragma unroll
     for (int tj = 0; tj < 2; ++tj) {
       const int col = n0 + tj * 32 + cl;
@@ -527,35 +594,53 @@ __global__ __launch_bounds__(BfCfg<TI>::NT, TI == 1 ? 4 : 2) void bf_ra_kernel(B
 
   v16f acc[TI][2];
   AuxBf<TI> aD, aG;
+  // no cross-layer weight prefetch and 32-k weight blocks here: the two epilogue operand tiles already fill the registers
+  BfMma<TI> mm;
+  mm.request(g.wbf + g.w_off[0], g.Kp[0], n0, lane);
   for (int l = 0; l < g.nh; ++l) {
-    k8_prefetch<TI>(g.D[l], rowW, n0, lane, aD);
-    k8_prefetch<TI>(g.gz[l], rowW, n0, lane, aG);
-    bf_layer_mma<TI>(Xw, g.wbf + g.w_off[l], g.Kp[l], n0, lane, acc);   // gzb = u_l W_l^T
+    const int lp = opaque(lane);
+    k8_prefetch<TI>(g.D[l], rowW, n0, lp, aD);
+    k8_prefetch<TI>(g.gz[l], rowW, n0, lp, aG);
+    const bfraw* wn = l + 1 < g.nh ? g.wbf + g.w_off[l + 1] : nullptr;
+    if (l == 0) mm.template run<64>(Xw, g.wbf + g.w_off[0], n0, lane, acc, wn, FH, n0);   // gzb = u_l W_l^T
+    else mm.template run<256>(Xw, g.wbf + g.w_off[l], n0, lane, acc, wn, FH, n0);
     lds_barrier();
+    const int lo = opaque(lane), h = lo >> 5, cl = lo & 31;
     const int n_real = g.n_real[l];
     const bool pe_tail = (l + 1 == g.skip);
 #pragma unroll
     for (int tj = 0; tj < 2; ++tj) {
       const int col = n0 + tj * 32 + cl;
+      const bool tile_full = n0 + tj * 32 + 32 <= n_real;   // wave-uniform: no per-element column tests
 #pragma unroll
       for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           float un[4], zr[4];
+          if (tile_full) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int r = 4 * q + j;
-            const int row = rb + ti * 32 + 8 * q + 4 * h + j;
-            const float v = acc[ti][tj][r];
-            if (col < n_real) {
+            for (int j = 0; j < 4; ++j) {
+              const int r = 4 * q + j;
+              const float v = acc[ti][tj][r];
               un[j] = v * aux_at(aD, ti, tj, r);
               zr[j] = ((v - un[j]) * aux_at(aG, ti, tj, r)) * 100.f;
-            } else {
-              zr[j] = 0.f;
-              un[j] = (pe_tail && col < n_real + g.pe) ? E[row * FEP + (col - n_real)] : 0.f;
             }
-            X[row * BP + col] = to_bf(un[j]);
+          } else {   // only the tile straddling the skip connection's PE columns
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int r = 4 * q + j;
+              const float v = acc[ti][tj][r];
+              if (col < n_real) {
+                un[j] = v * aux_at(aD, ti, tj, r);
+                zr[j] = ((v - un[j]) * aux_at(aG, ti, tj, r)) * 100.f;
+              } else {
+                zr[j] = 0.f;
+                un[j] = (pe_tail && col < n_real + g.pe) ? E[(rb + 4 * h) * FEP + (col - n_real) + (ti * 32 + 8 * q + j) * FEP] : 0.f;
+              }
+            }
           }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) X[(rb + 4 * h) * BP + col + (ti * 32 + 8 * q + j) * BP] = to_bf(un[j]);
           k8_store_quad(g.u[l + 1], rowW, ti, q, col, h, un[0], un[1], un[2], un[3]);
           k8_store_quad(g.zR[l], rowW, ti, q, col, h, zr[0], zr[1], zr[2], zr[3]);
         }
@@ -580,13 +665,18 @@ __global__ __launch_bounds__(BfCfg<TI>::NT, TI == 1 ? 4 : 2) void bf_fb_kernel(B
 
   v16f acc[TI][2];
   AuxBf<TI> aD, aZ;
+  BfMma<TI> mm;
+  const bool has_head = g.fbar_in_k8 || g.fbar != nullptr;
+  if (has_head) mm.request(g.wbf + g.wfT_off, FH, n0, lane);
+  else if (g.nh > 1) mm.request(g.wbf + g.wT_off[g.nh - 1], FH, n0, lane);
+  const bfraw* w_first = g.nh > 1 ? g.wbf + g.wT_off[g.nh - 1] : nullptr;
   bf_zero<TI>(acc);
   if (g.fbar_in_k8) {
     const bfraw* fb = g.fbar8 + (size_t)(row0 >> 3) * FH * 8;
     for (int u = tid; u < (BT / 8) * FH; u += NT)
       lds_scatter8<BP>(X, u / FH, u % FH, *reinterpret_cast<const vu4*>(fb + (size_t)u * 8));
     __syncthreads();
-    bf_layer_mma<TI>(Xw, g.wbf + g.wfT_off, FH, n0, lane, acc);
+    mm.template run<256>(Xw, g.wbf + g.wfT_off, n0, lane, acc, w_first, FH, n0);
     lds_barrier();
   } else if (g.fbar != nullptr) {
     // fbar (fp32 row-major, from the albedo net's backward) -> LDS bf16, and K8 for the feature head's dW
@@ -606,12 +696,13 @@ __global__ __launch_bounds__(BfCfg<TI>::NT, TI == 1 ? 4 : 2) void bf_fb_kernel(B
                (unsigned)v[4] | ((unsigned)v[5] << 16), (unsigned)v[6] | ((unsigned)v[7] << 16)};
       *reinterpret_cast<vu4*>(g.fbar8 + (((size_t)(row0 >> 3) + blk) * FH + c) * 8) = o;
     }
-    bf_layer_mma<TI>(Xw, g.wbf + g.wfT_off, FH, n0, lane, acc);
+    mm.template run<256>(Xw, g.wbf + g.wfT_off, n0, lane, acc, w_first, FH, n0);
     lds_barrier();
   }
   for (int l = g.nh - 1; l >= 0; --l) {
-    k8_prefetch<TI>(g.D[l], rowW, n0, lane, aD);
-    k8_prefetch<TI>(g.zR[l], rowW, n0, lane, aZ);
+    const int lo = opaque(lane), h = lo >> 5, cl = lo & 31;
+    k8_prefetch<TI>(g.D[l], rowW, n0, lo, aD);
+    k8_prefetch<TI>(g.zR[l], rowW, n0, lo, aZ);
     const int n_real = g.n_real[l];
     const bool head = (l == g.nh - 1);
 #pragma unroll
@@ -626,18 +717,17 @@ __global__ __launch_bounds__(BfCfg<TI>::NT, TI == 1 ? 4 : 2) void bf_fb_kernel(B
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int r = 4 * q + j;
-            const int row = rb + ti * 32 + 8 * q + 4 * h + j;
             float v = acc[ti][tj][r];
-            if (head) v = fmaf(g.sbar[row0 + row] * g.inv_scale, ws, v);   // the sdf head's contribution
+            if (head) v = fmaf(g.sbar[row0 + rb + 4 * h + (ti * 32 + 8 * q + j)] * g.inv_scale, ws, v);   // the sdf head's contribution
             zb[j] = col < n_real ? fmaf(v, aux_at(aD, ti, tj, r), aux_at(aZ, ti, tj, r)) : 0.f;
-            X[row * BP + col] = to_bf(zb[j]);
+            X[(rb + 4 * h) * BP + col + (ti * 32 + 8 * q + j) * BP] = to_bf(zb[j]);
           }
           k8_store_quad(g.zb[l], rowW, ti, q, col, h, zb[0], zb[1], zb[2], zb[3]);
         }
     }
     if (l == 0) break;
     lds_barrier();
-    bf_layer_mma<TI>(Xw, g.wbf + g.wT_off[l], FH, n0, lane, acc);   // ab_{l-1} = zb_l W_l
+    mm.template run<256>(Xw, g.wbf + g.wT_off[l], n0, lane, acc, l > 1 ? g.wbf + g.wT_off[l - 1] : nullptr, FH, n0);   // ab_{l-1} = zb_l W_l
     lds_barrier();   // every wave has finished reading the tile
   }
 }
@@ -878,15 +968,16 @@ __global__ __launch_bounds__(256, 2) void bf_color_bwd_kernel(BfColArgs g) {
 
 // gradient of the albedo output layer: dWo[c][k] += sum_rows zo[row][c] ac_last[row][k], dbo[c] += sum_rows zo[row][c].
 // One thread per column k and point slab (one slab in the deterministic variant).
-__global__ __launch_bounds__(256) void bf_color_out_bwd_kernel(const bfraw* __restrict__ ac, const float* __restrict__ alb,
-                                                               const float* __restrict__ albbar, int Co, int squeeze,
-                                                               int64_t M, int64_t rows_per_blk, int ldwo,
-                                                               float* __restrict__ dWo, float* __restrict__ dbo) {
-  const int c = threadIdx.x;
+__global__ __launch_bounds__(1024) void bf_color_out_bwd_kernel(const bfraw* __restrict__ ac, const float* __restrict__ alb,
+                                                                const float* __restrict__ albbar, int Co, int squeeze,
+                                                                int64_t M, int64_t rows_per_blk, int ldwo,
+                                                                float* __restrict__ dWo, float* __restrict__ dbo) {
+  __shared__ double red[4][4][FH], redb[4][4];
+  const int c = threadIdx.x & 255, ph = threadIdx.x >> 8;   // column, one of 4 row phases
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_blk;
   const int64_t r1 = r0 + rows_per_blk < M ? r0 + rows_per_blk : M;
   double s[4] = {0.0, 0.0, 0.0, 0.0}, sb[4] = {0.0, 0.0, 0.0, 0.0};
-  for (int64_t r = r0; r < r1; r += 8) {
+  for (int64_t r = r0 + 8 * ph; r < r1; r += 32) {
     const vu4 av = *reinterpret_cast<const vu4*>(ac + ((size_t)(r >> 3) * FH + c) * 8);
     const unsigned aw[4] = {av.x, av.y, av.z, av.w};
     float t[4] = {0.f, 0.f, 0.f, 0.f}, tb[4] = {0.f, 0.f, 0.f, 0.f};
@@ -907,9 +998,17 @@ __global__ __launch_bounds__(256) void bf_color_out_bwd_kernel(const bfraw* __re
 #pragma unroll
     for (int k = 0; k < 4; ++k) { s[k] += (double)t[k]; sb[k] += (double)tb[k]; }
   }
-  for (int k = 0; k < Co; ++k) {
-    atomicAdd(dWo + (size_t)k * ldwo + c, (float)s[k]);
-    if (c == 0) atomicAdd(dbo + k, (float)sb[k]);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    red[ph][k][c] = s[k];
+    if (c == 0) redb[ph][k] = sb[k];
+  }
+  __syncthreads();
+  if (ph == 0) {
+    for (int k = 0; k < Co; ++k) {
+      atomicAdd(dWo + (size_t)k * ldwo + c, (float)(red[0][k][c] + red[1][k][c] + red[2][k][c] + red[3][k][c]));
+      if (c == 0) atomicAdd(dbo + k, (float)(redb[0][k] + redb[1][k] + redb[2][k] + redb[3][k]));
+    }
   }
 }
 
@@ -1188,15 +1287,16 @@ __global__ __launch_bounds__(256) void bf_dw_reduce_kernel(const BfDwGroup g) {
 // gradient of the sdf-head row: dw_sdf[k] += sum_rows (sbar / scale * a_last + u_last), db_sdf += sum sbar / scale.
 // One thread per column and point slab; K8 units (8 points of one column) per load.  One slab per column chunk in the
 // deterministic variant (a single add onto zero per address).
-__global__ __launch_bounds__(256) void bf_sdf_head_bwd_kernel(const bfraw* __restrict__ a, const bfraw* __restrict__ ulast,
-                                                              const float* __restrict__ sbar, float inv_scale, int64_t M,
-                                                              int64_t rows_per_blk, float* __restrict__ dwsdf,
-                                                              float* __restrict__ dbsdf) {
-  const int c = threadIdx.x;
+__global__ __launch_bounds__(1024) void bf_sdf_head_bwd_kernel(const bfraw* __restrict__ a, const bfraw* __restrict__ ulast,
+                                                               const float* __restrict__ sbar, float inv_scale, int64_t M,
+                                                               int64_t rows_per_blk, float* __restrict__ dwsdf,
+                                                               float* __restrict__ dbsdf) {
+  __shared__ double red[4][FH], redb[4];
+  const int c = threadIdx.x & 255, ph = threadIdx.x >> 8;   // column, one of 4 row phases (8-point blocks ph, ph + 4, ...)
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_blk;
   const int64_t r1 = r0 + rows_per_blk < M ? r0 + rows_per_blk : M;
   double s = 0.0, sb = 0.0;
-  for (int64_t r = r0; r < r1; r += 8) {
+  for (int64_t r = r0 + 8 * ph; r < r1; r += 32) {
     const vu4 av = *reinterpret_cast<const vu4*>(a + ((size_t)(r >> 3) * FH + c) * 8);
     const vu4 uv = *reinterpret_cast<const vu4*>(ulast + ((size_t)(r >> 3) * FH + c) * 8);
     const float af[8] = {bf_lo(av.x), bf_hi(av.x), bf_lo(av.y), bf_hi(av.y), bf_lo(av.z), bf_hi(av.z), bf_lo(av.w), bf_hi(av.w)};
@@ -1213,15 +1313,34 @@ __global__ __launch_bounds__(256) void bf_sdf_head_bwd_kernel(const bfraw* __res
     s += (double)t;
     sb += (double)tb;
   }
-  atomicAdd(dwsdf + c, (float)s);
-  if (c == 0) atomicAdd(dbsdf, (float)sb);
+  red[ph][c] = s;
+  if (c == 0) redb[ph] = sb;
+  __syncthreads();
+  if (ph == 0) {
+    atomicAdd(dwsdf + c, (float)(red[0][c] + red[1][c] + red[2][c] + red[3][c]));
+    if (c == 0) atomicAdd(dbsdf, (float)(redb[0] + redb[1] + redb[2] + redb[3]));
+  }
 }
 
-// fp32 packed weights -> bf16 mirror (same element offsets)
-__global__ void bf_pack_kernel(const float* __restrict__ src, int64_t n, bfraw* __restrict__ dst) {
-  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
-  if (i + 1 < n) *reinterpret_cast<unsigned*>(dst + i) = pack2(src[i], src[i + 1]);
-  else if (i < n) dst[i] = to_bf(src[i]);
+// fp32 packed weights -> bf16 mirror: every matrix that serves as an MFMA B operand, at its own element offset, in
+// fragment order (see bf_load_b).  One workgroup per 32-row x 16-k fragment... one thread per 16-byte unit.
+struct BfPackEntry { long long off; int N, K; int unit_begin; };
+constexpr int kMaxPack = 4 * RNB_MAX_LIN + 4;
+struct BfPackTable { int n, total_units; BfPackEntry e[kMaxPack]; };
+__global__ void bf_pack_kernel(const float* __restrict__ src, BfPackTable t, bfraw* __restrict__ dst) {
+  const int u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= t.total_units) return;
+  int ei = 0;
+  while (ei + 1 < t.n && u >= t.e[ei + 1].unit_begin) ++ei;
+  const BfPackEntry en = t.e[ei];
+  const int lu = u - en.unit_begin;            // unit inside the matrix: fragment lu / 64, lane lu % 64
+  const int frag = lu >> 6, lane = lu & 63;
+  const int nks = en.K >> 4;
+  const int nt = frag / nks, ks = frag - nt * nks;
+  const int c = lane & 31, h = lane >> 5;
+  const float* sp = src + en.off + (size_t)(nt * 32 + c) * en.K + ks * 16 + h * 8;
+  const vu4 o = {pack2(sp[0], sp[1]), pack2(sp[2], sp[3]), pack2(sp[4], sp[5]), pack2(sp[6], sp[7])};
+  *reinterpret_cast<vu4*>(dst + en.off + (size_t)lu * 8) = o;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1292,7 +1411,7 @@ int bf16_color_backward(const Layout& L, const float* packed, PointBufs& pb, flo
   int64_t slabs = det ? 1 : 256;
   int64_t rows_per_blk = (pb.M + slabs - 1) / slabs;
   rows_per_blk = (rows_per_blk + 7) / 8 * 8;
-  hipLaunchKernelGGL(bf_color_out_bwd_kernel, dim3((unsigned)((pb.M + rows_per_blk - 1) / rows_per_blk)), dim3(256), 0, s,
+  hipLaunchKernelGGL(bf_color_out_bwd_kernel, dim3((unsigned)((pb.M + rows_per_blk - 1) / rows_per_blk)), dim3(1024), 0, s,
                      reinterpret_cast<const bfraw*>(pb.ac8[L.nc - 1]), pb.alb, pb.albbar, L.Co, L.squeeze, pb.M, rows_per_blk,
                      L.colo.Kp, packed_grad + L.colo.w_off, packed_grad + L.colo.b_off);
   RNB_CHECK_LAUNCH();
@@ -1301,8 +1420,28 @@ int bf16_color_backward(const Layout& L, const float* packed, PointBufs& pb, flo
 
 int bf16_pack_weights(const Layout& L, float* packed, hipStream_t s) {
   bfraw* dst = reinterpret_cast<bfraw*>(packed + L.total);
-  const int64_t pairs = (L.total + 1) / 2;
-  hipLaunchKernelGGL(bf_pack_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, s, packed, L.total, dst);
+  BfPackTable t;
+  t.n = 0;
+  t.total_units = 0;
+  auto add = [&](long long off, int N, int K) {
+    if (off < 0 || N <= 0 || K <= 0) return;
+    BfPackEntry& e = t.e[t.n++];
+    e.off = off; e.N = N; e.K = K; e.unit_begin = t.total_units;
+    t.total_units += N * K / 8;
+  };
+  for (int l = 0; l < L.nh; ++l) {
+    add(L.hid[l].w_off, L.hid[l].Np, L.hid[l].Kp);
+    add(L.hid[l].wT_off, L.hid[l].Kp, L.hid[l].Np);
+  }
+  if (L.F > 0) {
+    add(L.feat.w_off, L.feat.Np, L.feat.Kp);
+    add(L.feat.wT_off, L.feat.Kp, L.feat.Np);
+    for (int l = 0; l < L.nc; ++l) {
+      add(L.col[l].w_off, L.col[l].Np, L.col[l].Kp);
+      add(L.col[l].wT_off, L.col[l].Kp, L.col[l].Np);
+    }
+  }
+  hipLaunchKernelGGL(bf_pack_kernel, dim3((unsigned)((t.total_units + 255) / 256)), dim3(256), 0, s, packed, t, dst);
   RNB_CHECK_LAUNCH();
   return RNB_OK;
 }
@@ -1425,7 +1564,7 @@ int bf16_backward(const Layout& L, const float* packed, PointBufs& pb, bool with
     int64_t slabs = det ? 1 : 256;
     int64_t rows_per_blk = (M + slabs - 1) / slabs;
     rows_per_blk = (rows_per_blk + 7) / 8 * 8;
-    hipLaunchKernelGGL(bf_sdf_head_bwd_kernel, dim3((unsigned)((M + rows_per_blk - 1) / rows_per_blk)), dim3(256), 0, s,
+    hipLaunchKernelGGL(bf_sdf_head_bwd_kernel, dim3((unsigned)((M + rows_per_blk - 1) / rows_per_blk)), dim3(1024), 0, s,
                        reinterpret_cast<const bfraw*>(pb.a[L.nh - 1]), reinterpret_cast<const bfraw*>(pb.u[L.nh]), pb.sbar,
                        1.f / L.sdf_scale, M, rows_per_blk, packed_grad + L.wsdf_off, packed_grad + L.bsdf_off);
     RNB_CHECK_LAUNCH();
