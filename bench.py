@@ -71,9 +71,13 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--no-gemm-events", action="store_true")
     ap.add_argument("--deterministic", action="store_true", help="ordered reductions instead of fp32 atomics")
+    ap.add_argument("--x3", action="store_true", help="request RNB_VARIANT_X3 explicitly (it is the default for the 256-wide shape)")
+    ap.add_argument("--f32-mfma", action="store_true", help="A/B knob: native fp32 MFMA sweeps (RNB_VARIANT_F32_MFMA) instead of x3")
     ap.add_argument("--dw-staged", action="store_true", help="A/B knob: LDS-DMA staged dW kernel for the 256x256 jobs")
     ap.add_argument("--fwd-ti", type=int, default=0, help="A/B knob: tile rows per wave of the forward sweep (1 | 2)")
     ap.add_argument("--bwd-ti", type=int, default=0, help="A/B knob: tile rows per wave of the backward sweeps (1 | 2)")
+    ap.add_argument("--fwd-nw", type=int, default=0, help="A/B knob: waves per workgroup of the forward sweep (4 | 8)")
+    ap.add_argument("--bwd-nw", type=int, default=0, help="A/B knob: waves per workgroup of the backward sweeps (4 | 8)")
     ap.add_argument("--torch-train-ops", action="store_true",
                     help="loss as the reference's chain of torch ops and torch.optim.Adam(fused=True) instead of "
                          "the library's one-launch loss and flat Adam")
@@ -224,7 +228,7 @@ def init_distributed(args):
     return world, rank, dev, backend, rehearsal
 
 
-def build_model(R, dev, samples, dtype, deterministic, fwd_ti=0, bwd_ti=0, dw_staged=False):
+def build_model(R, dev, samples, dtype, deterministic, fwd_ti=0, bwd_ti=0, dw_staged=False, x3=False, fwd_nw=0, bwd_nw=0, f32_mfma=False):
     import torch
     # confs/wmask_rnb.conf:53-90, constructed in the order of exp_runner.py:95-100 under seed 0
     torch.manual_seed(0)
@@ -235,7 +239,8 @@ def build_model(R, dev, samples, dtype, deterministic, fwd_ti=0, bwd_ti=0, dw_st
                              weight_norm=True, multires_view=4, squeeze_out=True).to(dev)
     ren = R.NeuSRenderer(None, sdf, devnet, col, n_samples=samples // 2, n_importance=samples // 2, n_outside=0,
                          up_sample_steps=4, perturb=1.0)
-    ren.set_variant(bf16=(dtype == "bf16"), deterministic=deterministic, fwd_ti=fwd_ti, bwd_ti=bwd_ti, dw_staged=dw_staged)
+    ren.set_variant(bf16=(dtype == "bf16"), deterministic=deterministic, fwd_ti=fwd_ti, bwd_ti=bwd_ti, dw_staged=dw_staged, x3=x3,
+                    fwd_nw=fwd_nw, bwd_nw=bwd_nw, f32_mfma=f32_mfma)
     return sdf, devnet, col, ren
 
 
@@ -252,7 +257,8 @@ def run_train(args):
     lib = R.native.load()
 
     S = args.samples
-    sdf, devnet, col, ren = build_model(R, dev, S, args.dtype, args.deterministic, args.fwd_ti, args.bwd_ti, args.dw_staged)
+    sdf, devnet, col, ren = build_model(R, dev, S, args.dtype, args.deterministic, args.fwd_ti, args.bwd_ti, args.dw_staged, args.x3,
+                                        args.fwd_nw, args.bwd_nw, args.f32_mfma)
     exact_dp = not args.torch_train_ops     # the reference's torch-op loss knows nothing about shards
     if world > 1:
         P.broadcast_parameters([sdf, devnet, col])
@@ -429,7 +435,7 @@ def run_mesh(args):
     world, rank, dev, backend, rehearsal = init_distributed(args)
     import rnb_neus_fork_amd as R
     lib = R.native.load()
-    sdf, devnet, col, ren = build_model(R, dev, 128, args.dtype, False)
+    sdf, devnet, col, ren = build_model(R, dev, 128, args.dtype, False, x3=args.x3, f32_mfma=args.f32_mfma)
     if world > 1:
         from rnb_neus_fork_amd import parallel as P
         P.broadcast_parameters([sdf, devnet, col])

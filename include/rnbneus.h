@@ -85,6 +85,13 @@ typedef struct rnb_model_desc {
  *                             leave through slabs + an ordered reduction, no atomics) instead of the register-direct
  *                             128 x 128-tile kernel.  Halves the operand traffic of that launch; measured 2 % slower
  *                             per step, hence not the default.
+ *   RNB_VARIANT_X3            fp32 products of the fused sweeps and of the 256 x 256 weight gradients on the bf16 matrix
+ *                             pipe: each fp32 operand as three bf16 terms (hi + mid + lo = x exactly), six of the nine
+ *                             cross terms per product, fp32 accumulate.  Same fp32 state, same results to fp32 rounding
+ *                             (the dropped terms are < 2^-26 relative); rnb_packed_floats grows by the split weight
+ *                             mirror (1.5 x).  This is what variant 0 selects for the 256-wide network shape; the bit
+ *                             only makes the request explicit (an unsupported shape is then an error).
+ *   RNB_VARIANT_F32_MFMA      the same kernels on v_mfma_f32_32x32x2_f32 (the round-1 arithmetic; A/B switch).
  *   RNB_VARIANT_*_TI/_NW      tile height (1: 32 points, 2: 64 points) / waves per workgroup (4 or 8) of the fused
  *                             backward sweeps (BWD) and of the fused forward (FWD); 0 = the measured default. */
 enum {
@@ -93,6 +100,8 @@ enum {
   RNB_VARIANT_GENERIC = 4,
   RNB_VARIANT_DW_LDS = 8,
   RNB_VARIANT_DW_STAGED = 16,
+  RNB_VARIANT_X3 = 32,
+  RNB_VARIANT_F32_MFMA = 64,
   RNB_VARIANT_BWD_TI_SHIFT = 8,   /* 2 bits: 0 default, 1, 2 */
   RNB_VARIANT_BWD_NW_SHIFT = 10,  /* 2 bits: 0 default, 1 = 4 waves, 2 = 8 waves */
   RNB_VARIANT_FWD_TI_SHIFT = 12,

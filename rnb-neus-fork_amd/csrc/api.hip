@@ -28,6 +28,7 @@ RNB_API int rnb_weightnorm_fwd(const rnb_model_desc* desc, const rnb_mlp_params*
   RNB_TRY(make_layout(desc, &L));
   RNB_TRY(weightnorm_fwd(desc, L, sdf, color, packed, (hipStream_t)stream));
   if (is_bf16(L)) RNB_TRY(bf16_pack_weights(L, packed, (hipStream_t)stream));   // bf16 mirror behind the fp32 weights
+  if (is_x3(L)) RNB_TRY(x3_pack_weights(L, packed, (hipStream_t)stream));       // hi / mid / lo mirror
   return RNB_OK;
 }
 

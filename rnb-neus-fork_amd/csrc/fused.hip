@@ -15,6 +15,7 @@ struct FusedFwdArgs {
   const float* pts;     // [M,3]
   int64_t M;
   const float* packed;
+  const x3raw* w3;      // RNB_VARIANT_X3: split mirror of the weight matrices (matrix at 3 x its float offset)
   int nh, skip, pe, multires, Ep;
   float scale;
   int n_real[RNB_MAX_LIN];
@@ -38,7 +39,7 @@ struct FusedFwdArgs {
 // every CU still gets a workgroup).  NW = waves per workgroup: 4 (each wave 64 output columns) or 8 (32 columns
 // each) — the latter for batches so small that a CU holds a single workgroup: two waves per SIMD instead of one
 // hide each other's LDS / L2 waits.
-template <int TI, bool SAVE, int NW = 4>
+template <int TI, bool SAVE, int NW = 4, bool X3 = false>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_forward_kernel(FusedFwdArgs g) {
   constexpr int FT = 32 * TI;
   constexpr int NT = 64 * NW;     // threads
@@ -112,7 +113,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_forward_kernel
   const int h = lane >> 5, cl = lane & 31;
   v16f acc[TI][TJ];
   for (int l = 0; l < g.nh; ++l) {
-    layer_mma_nt<TI, NoHook, TJ>(X, g.packed + g.w_off[l], g.Kp[l], n0, lane, acc);
+    if constexpr (X3) layer_mma_x3<TI, TJ>(X, g.w3 + 3 * g.w_off[l], g.Kp[l], n0, lane, acc);
+    else layer_mma_nt<TI, NoHook, TJ>(X, g.packed + g.w_off[l], g.Kp[l], n0, lane, acc);
     if constexpr (NBUF == 1) lds_barrier();   // every wave has finished reading the input activations
     const float* bias = g.packed + g.b_off[l];
     // saved state goes out through buffer stores: one 32-bit lane offset per column tile plus a
@@ -188,7 +190,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_forward_kernel
   }
   // ---- feature head: rows 1.. of the output layer, written into the albedo network's input ------------
   if (g.with_feat) {
-    layer_mma_nt<TI, NoHook, TJ>(X, g.packed + g.wf_off, FH, n0, lane, acc);
+    if constexpr (X3) layer_mma_x3<TI, TJ>(X, g.w3 + 3 * g.wf_off, FH, n0, lane, acc);
+    else layer_mma_nt<TI, NoHook, TJ>(X, g.packed + g.wf_off, FH, n0, lane, acc);
     const float* bias = g.packed + g.bf_off;
     const BufRsrc rc = tile_rsrc(g.cin + (size_t)row0 * g.Cinp, FT * g.Cinp * 4);
     const unsigned rowb = (unsigned)g.Cinp * 4u;   // bytes per row of the albedo-net input
@@ -211,6 +214,54 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_forward_kernel
   }
 }
 
+// ---- RNB_VARIANT_X3: the split weight mirror ----------------------------------------------------------------
+constexpr int kMaxX3 = 4 * RNB_MAX_LIN + 2;
+struct X3Entry { long long off; int N, K, unit_begin; };
+struct X3Table { int n, total_units; X3Entry e[kMaxX3]; };
+// one thread per 16-byte unit of one plane-triple: W[32 nt + c][16 ks + 8 h .. +8] -> hi, mid, lo
+__global__ void x3_pack_kernel(const float* __restrict__ src, X3Table t, x3raw* __restrict__ dst) {
+  const int u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= t.total_units) return;
+  int ei = 0;
+  while (ei + 1 < t.n && u >= t.e[ei + 1].unit_begin) ++ei;
+  const X3Entry en = t.e[ei];
+  const int lu = u - en.unit_begin;            // fragment lu / 64, lane lu % 64
+  const int frag = lu >> 6, lane = lu & 63;
+  const int nks = en.K >> 4;
+  const int nt = frag / nks, ks = frag - nt * nks;
+  const int c = lane & 31, h = lane >> 5;
+  const float* sp = src + en.off + (size_t)(nt * 32 + c) * en.K + ks * 16 + h * 8;
+  vu4x hi, mid, lo;
+  x3_split8(*reinterpret_cast<const vf4*>(sp), *reinterpret_cast<const vf4*>(sp + 4), hi, mid, lo);
+  x3raw* dp = dst + 3 * en.off + ((size_t)frag * 3 * 64 + lane) * 8;
+  *reinterpret_cast<vu4x*>(dp) = hi;
+  *reinterpret_cast<vu4x*>(dp + 512) = mid;
+  *reinterpret_cast<vu4x*>(dp + 1024) = lo;
+}
+int x3_pack_weights(const Layout& L, float* packed, hipStream_t s) {
+  x3raw* dst = reinterpret_cast<x3raw*>(packed + L.total);
+  X3Table t;
+  t.n = 0;
+  t.total_units = 0;
+  auto add = [&](long long off, int N, int K) {
+    if (off < 0 || N <= 0 || K <= 0) return;
+    X3Entry& e = t.e[t.n++];
+    e.off = off; e.N = N; e.K = K; e.unit_begin = t.total_units;
+    t.total_units += N * K / 8;
+  };
+  for (int l = 0; l < L.nh; ++l) {
+    add(L.hid[l].w_off, L.hid[l].Np, L.hid[l].Kp);
+    add(L.hid[l].wT_off, L.hid[l].Kp, L.hid[l].Np);
+  }
+  if (L.F > 0) {
+    add(L.feat.w_off, L.feat.Np, L.feat.Kp);
+    add(L.feat.wT_off, L.feat.Kp, L.feat.Np);
+  }
+  hipLaunchKernelGGL(x3_pack_kernel, dim3((unsigned)((t.total_units + 255) / 256)), dim3(256), 0, s, packed, t, dst);
+  RNB_CHECK_LAUNCH();
+  return RNB_OK;
+}
+
 bool fused_supported(const Layout& L) {
   if (L.Hp != FH || L.H != FH) return false;
   if (L.Ep > 64 || L.pe > FEP) return false;
@@ -230,6 +281,7 @@ int fused_forward(const Layout& L, const float* packed, const float* pts, int64_
   g.pts = pts;
   g.M = M;
   g.packed = packed;
+  g.w3 = reinterpret_cast<const x3raw*>(packed + L.total);
   g.nh = L.nh;
   g.skip = L.skip;
   g.pe = L.pe;
@@ -266,16 +318,25 @@ int fused_forward(const Layout& L, const float* packed, const float* pts, int64_
   const int force_ti = L.knob(RNB_VARIANT_FWD_TI_SHIFT);   // tuning knob: 1 or 2 forces the tile height
   const bool small = force_ti ? (force_ti == 1) : (pb.Mp / 64 < 512);
   const int force_nw = L.knob(RNB_VARIANT_FWD_NW_SHIFT);   // tuning knob: 1 = 4 waves, 2 = 8 waves (small batches)
+  const bool x3 = is_x3(L);
   if (small) {
     const unsigned blocks = (unsigned)(pb.Mp / 32);
     const bool wide = force_nw ? (force_nw == 2) : (blocks <= 256);   // at most one workgroup per CU
-    if (save && wide) hipLaunchKernelGGL((fused_forward_kernel<1, true, 8>), dim3(blocks), dim3(512), 0, s, g);
+    if (x3) {
+      if (save && wide) hipLaunchKernelGGL((fused_forward_kernel<1, true, 8, true>), dim3(blocks), dim3(512), 0, s, g);
+      else if (save) hipLaunchKernelGGL((fused_forward_kernel<1, true, 4, true>), dim3(blocks), dim3(256), 0, s, g);
+      else if (wide) hipLaunchKernelGGL((fused_forward_kernel<1, false, 8, true>), dim3(blocks), dim3(512), 0, s, g);
+      else hipLaunchKernelGGL((fused_forward_kernel<1, false, 4, true>), dim3(blocks), dim3(256), 0, s, g);
+    } else if (save && wide) hipLaunchKernelGGL((fused_forward_kernel<1, true, 8>), dim3(blocks), dim3(512), 0, s, g);
     else if (save) hipLaunchKernelGGL((fused_forward_kernel<1, true>), dim3(blocks), dim3(256), 0, s, g);
     else if (wide) hipLaunchKernelGGL((fused_forward_kernel<1, false, 8>), dim3(blocks), dim3(512), 0, s, g);
     else hipLaunchKernelGGL((fused_forward_kernel<1, false>), dim3(blocks), dim3(256), 0, s, g);
   } else {
     const unsigned blocks = (unsigned)(pb.Mp / 64);
-    if (save) hipLaunchKernelGGL((fused_forward_kernel<2, true>), dim3(blocks), dim3(256), 0, s, g);
+    if (x3) {
+      if (save) hipLaunchKernelGGL((fused_forward_kernel<2, true, 4, true>), dim3(blocks), dim3(256), 0, s, g);
+      else hipLaunchKernelGGL((fused_forward_kernel<2, false, 4, true>), dim3(blocks), dim3(256), 0, s, g);
+    } else if (save) hipLaunchKernelGGL((fused_forward_kernel<2, true>), dim3(blocks), dim3(256), 0, s, g);
     else hipLaunchKernelGGL((fused_forward_kernel<2, false>), dim3(blocks), dim3(256), 0, s, g);
   }
   RNB_CHECK_LAUNCH();

@@ -23,6 +23,7 @@ namespace rnb {
 
 struct FusedBwdArgs {
   const float* packed;
+  const x3raw* w3;      // RNB_VARIANT_X3: split mirror of the weight matrices (matrix at 3 x its float offset)
   int nh, skip, pe, multires, Ep;
   float inv_scale;
   int n_real[RNB_MAX_LIN];   // real output width of hidden layer l
@@ -107,19 +108,21 @@ __device__ inline void prefetch_tile(const float* base, int64_t row0, int n0, in
   });
 }
 
-// matrix loop of one layer: two alternating weight-register sets, except for 64-point tiles with 64-column
-// waves, which use the one-set ring (register budget)
-template <int TI, int TJ = 2, class Hook = NoHook>
-__device__ inline void layer_mma(const float* __restrict__ X, const float* __restrict__ W, int K, int n0, int lane,
+// matrix loop of one layer (weights at float offset `off` of the packed buffer): two alternating weight-register
+// sets, except for 64-point tiles with 64-column waves, which use the one-set ring (register budget).  X3: the same
+// product as six bf16 MFMA terms per 16 k (fused_common.hip.h).
+template <int TI, int TJ = 2, bool X3 = false, class Hook = NoHook>
+__device__ inline void layer_mma(const float* __restrict__ X, const FusedBwdArgs& g, long long off, int K, int n0, int lane,
                                  v16f (&acc)[TI][TJ], Hook hook = Hook(), int hook_late = 0) {
-  if constexpr (TI == 2 && TJ == 2) layer_mma_nt_ring<TI>(X, W, K, n0, lane, acc, hook);
-  else layer_mma_nt<TI, Hook, TJ>(X, W, K, n0, lane, acc, hook, hook_late);
+  if constexpr (X3) layer_mma_x3<TI, TJ, Hook>(X, g.w3 + 3 * off, K, n0, lane, acc, hook);
+  else if constexpr (TI == 2 && TJ == 2) layer_mma_nt_ring<TI>(X, g.packed + off, K, n0, lane, acc, hook);
+  else layer_mma_nt<TI, Hook, TJ>(X, g.packed + off, K, n0, lane, acc, hook, hook_late);
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // R sweep
 // ---------------------------------------------------------------------------------------------------------
-template <int TI, int NW = 4>
+template <int TI, int NW = 4, bool X3 = false>
 __global__ __launch_bounds__(64 * NW, (NW == 8 && TI == 2) ? 1 : 2) void fused_reverse_kernel(FusedBwdArgs g) {
   constexpr int BT = 32 * TI;
   constexpr int NT = 64 * NW;   // threads
@@ -157,7 +160,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TI == 2) ? 1 : 2) void fused_r
   v16f acc[TI][TJ];
   AuxTile<TI, TJ> aD;
   for (int l = g.nh - 1; l >= 1; --l) {
-    layer_mma<TI, TJ>(X, g.packed + g.wT_off[l], FH, n0, lane, acc,   // g = gz_l W_l  (columns = inputs of layer l)
+    layer_mma<TI, TJ, X3>(X, g, g.wT_off[l], FH, n0, lane, acc,   // g = gz_l W_l  (columns = inputs of layer l)
                      [&]() { prefetch_tile<TI, TJ>(g.D[l - 1], row0, n0, lane, aD); });
     if constexpr (NBUF == 1) lds_barrier();   // every wave has finished reading the tile
     const bool is_skip = (l == g.skip);
@@ -187,7 +190,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TI == 2) ? 1 : 2) void fused_r
   }
   // layer 0: g_e += gz_0 W_0 (Ep = 64 columns: the waves that own columns 0..63)
   if (n0 < 64) {
-    layer_mma<TI, TJ>(X, g.packed + g.wT_off[0], FH, n0, lane, acc);
+    layer_mma<TI, TJ, X3>(X, g, g.wT_off[0], FH, n0, lane, acc);
     for_each_acc<TI, TJ>(n0, lane, [&](int tj, int ti, int r, int col, int rowc, int row) {
       if (col < g.pe) GE[row * FEP + col] += acc[ti][tj][r];
     });
@@ -217,7 +220,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TI == 2) ? 1 : 2) void fused_r
 // ---------------------------------------------------------------------------------------------------------
 // RA sweep
 // ---------------------------------------------------------------------------------------------------------
-template <int TI, int NW = 4>
+template <int TI, int NW = 4, bool X3 = false>
 __global__ __launch_bounds__(64 * NW, (NW == 8 && TI == 2) ? 1 : 2) void fused_ra_kernel(FusedBwdArgs g) {
   constexpr int BT = 32 * TI;
   constexpr int NT = 64 * NW;   // threads
@@ -248,7 +251,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TI == 2) ? 1 : 2) void fused_r
   for (int l = 0; l < g.nh; ++l) {
     // TI == 2: only one operand tile fits next to the weight fragments during the matrix loop; the second
     // one is requested right after it, into the registers the weight fragments leave behind
-    layer_mma<TI, TJ>(X, g.packed + g.w_off[l], g.Kp[l], n0, lane, acc,   // gzb = u_l W_l^T
+    layer_mma<TI, TJ, X3>(X, g, g.w_off[l], g.Kp[l], n0, lane, acc,   // gzb = u_l W_l^T
                      [&]() {
                        prefetch_tile<TI, TJ>(g.D[l], row0, n0, lane, aD);
                        if constexpr (BOTH_IN_LOOP) prefetch_tile<TI, TJ>(g.gz[l], row0, n0, lane, aG);
@@ -295,7 +298,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TI == 2) ? 1 : 2) void fused_r
 // ---------------------------------------------------------------------------------------------------------
 // FB sweep
 // ---------------------------------------------------------------------------------------------------------
-template <int TI, int NW = 4>
+template <int TI, int NW = 4, bool X3 = false>
 __global__ __launch_bounds__(64 * NW, (NW == 8 && TI == 2) ? 1 : 2) void fused_fb_kernel(FusedBwdArgs g) {
   constexpr int BT = 32 * TI;
   constexpr int NT = 64 * NW;   // threads
@@ -324,7 +327,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TI == 2) ? 1 : 2) void fused_f
       *reinterpret_cast<vf4*>(X + r * FP + c4 * 4) = *reinterpret_cast<const vf4*>(fb + (size_t)r * g.ld_fbar + c4 * 4);
     }
     __syncthreads();
-    layer_mma<TI, TJ>(X, g.packed + g.wfT_off, FH, n0, lane, acc);
+    layer_mma<TI, TJ, X3>(X, g, g.wfT_off, FH, n0, lane, acc);
     if constexpr (NBUF == 1) lds_barrier();
   }
   for (int l = g.nh - 1; l >= 0; --l) {
@@ -352,7 +355,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TI == 2) ? 1 : 2) void fused_f
     if (l == 0) break;
     lds_barrier();
     if constexpr (NBUF == 2) { float* t = X; X = Y; Y = t; }
-    layer_mma<TI, TJ>(X, g.packed + g.wT_off[l], FH, n0, lane, acc,   // ab_{l-1} = zb_l W_l
+    layer_mma<TI, TJ, X3>(X, g, g.wT_off[l], FH, n0, lane, acc,   // ab_{l-1} = zb_l W_l
                      [&]() {
                        prefetch_tile<TI, TJ>(g.D[l - 1], row0, n0, lane, aD);
                        if constexpr (BOTH_IN_LOOP) prefetch_tile<TI, TJ>(g.zR[l - 1], row0, n0, lane, aZ);
@@ -366,6 +369,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TI == 2) ? 1 : 2) void fused_f
 static void fill_args(const Layout& L, const float* packed, PointBufs& pb, FusedBwdArgs& g) {
   memset(&g, 0, sizeof(g));
   g.packed = packed;
+  g.w3 = reinterpret_cast<const x3raw*>(packed + L.total);
   g.nh = L.nh;
   g.skip = L.skip;
   g.pe = L.pe;
@@ -419,10 +423,17 @@ int fused_reverse(const Layout& L, const float* packed, PointBufs& pb, hipStream
   FusedBwdArgs g;
   fill_args(L, packed, pb, g);
   ProfScope prof(hidden_flops(L, pb.M, 0), s);
-  if (bwd_ti(L, 1) == 2 && bwd_nw(L, 8) == 8) hipLaunchKernelGGL((fused_reverse_kernel<2, 8>), dim3((unsigned)(pb.Mp / 64)), dim3(512), 0, s, g);
-  else if (bwd_ti(L, 1) == 2) hipLaunchKernelGGL(fused_reverse_kernel<2>, dim3((unsigned)(pb.Mp / 64)), dim3(256), 0, s, g);
-  else if (bwd_nw(L, 8) == 8) hipLaunchKernelGGL((fused_reverse_kernel<1, 8>), dim3((unsigned)(pb.Mp / 32)), dim3(512), 0, s, g);
-  else hipLaunchKernelGGL(fused_reverse_kernel<1>, dim3((unsigned)(pb.Mp / 32)), dim3(256), 0, s, g);
+  const int ti = bwd_ti(L, 1), nw = bwd_nw(L, 8);
+  const dim3 grid((unsigned)(pb.Mp / (32 * ti))), block(64 * nw);
+  if (is_x3(L)) {
+    if (ti == 2 && nw == 8) hipLaunchKernelGGL((fused_reverse_kernel<2, 8, true>), grid, block, 0, s, g);
+    else if (ti == 2) hipLaunchKernelGGL((fused_reverse_kernel<2, 4, true>), grid, block, 0, s, g);
+    else if (nw == 8) hipLaunchKernelGGL((fused_reverse_kernel<1, 8, true>), grid, block, 0, s, g);
+    else hipLaunchKernelGGL((fused_reverse_kernel<1, 4, true>), grid, block, 0, s, g);
+  } else if (ti == 2 && nw == 8) hipLaunchKernelGGL((fused_reverse_kernel<2, 8>), grid, block, 0, s, g);
+  else if (ti == 2) hipLaunchKernelGGL(fused_reverse_kernel<2>, grid, block, 0, s, g);
+  else if (nw == 8) hipLaunchKernelGGL((fused_reverse_kernel<1, 8>), grid, block, 0, s, g);
+  else hipLaunchKernelGGL(fused_reverse_kernel<1>, grid, block, 0, s, g);
   RNB_CHECK_LAUNCH();
   return RNB_OK;
 }
@@ -431,10 +442,17 @@ int fused_ra(const Layout& L, const float* packed, PointBufs& pb, hipStream_t s)
   FusedBwdArgs g;
   fill_args(L, packed, pb, g);
   ProfScope prof(hidden_flops(L, pb.M, 0), s);
-  if (bwd_ti(L, 1) == 2 && bwd_nw(L, 8) == 8) hipLaunchKernelGGL((fused_ra_kernel<2, 8>), dim3((unsigned)(pb.Mp / 64)), dim3(512), 0, s, g);
-  else if (bwd_ti(L, 1) == 2) hipLaunchKernelGGL(fused_ra_kernel<2>, dim3((unsigned)(pb.Mp / 64)), dim3(256), 0, s, g);
-  else if (bwd_nw(L, 8) == 8) hipLaunchKernelGGL((fused_ra_kernel<1, 8>), dim3((unsigned)(pb.Mp / 32)), dim3(512), 0, s, g);
-  else hipLaunchKernelGGL(fused_ra_kernel<1>, dim3((unsigned)(pb.Mp / 32)), dim3(256), 0, s, g);
+  const int ti = bwd_ti(L, 1), nw = bwd_nw(L, 8);
+  const dim3 grid((unsigned)(pb.Mp / (32 * ti))), block(64 * nw);
+  if (is_x3(L)) {
+    if (ti == 2 && nw == 8) hipLaunchKernelGGL((fused_ra_kernel<2, 8, true>), grid, block, 0, s, g);
+    else if (ti == 2) hipLaunchKernelGGL((fused_ra_kernel<2, 4, true>), grid, block, 0, s, g);
+    else if (nw == 8) hipLaunchKernelGGL((fused_ra_kernel<1, 8, true>), grid, block, 0, s, g);
+    else hipLaunchKernelGGL((fused_ra_kernel<1, 4, true>), grid, block, 0, s, g);
+  } else if (ti == 2 && nw == 8) hipLaunchKernelGGL((fused_ra_kernel<2, 8>), grid, block, 0, s, g);
+  else if (ti == 2) hipLaunchKernelGGL(fused_ra_kernel<2>, grid, block, 0, s, g);
+  else if (nw == 8) hipLaunchKernelGGL((fused_ra_kernel<1, 8>), grid, block, 0, s, g);
+  else hipLaunchKernelGGL(fused_ra_kernel<1>, grid, block, 0, s, g);
   RNB_CHECK_LAUNCH();
   return RNB_OK;
 }
@@ -445,10 +463,17 @@ int fused_fb(const Layout& L, const float* packed, PointBufs& pb, bool with_colo
   g.fbar = with_color ? pb.cinb : nullptr;
   g.ld_fbar = L.Cinp;
   ProfScope prof(hidden_flops(L, pb.M, 1) + (with_color ? 2.0 * (double)pb.M * L.F * L.H : 0.0), s);
-  if (bwd_ti(L, 1) == 2 && bwd_nw(L, 8) == 8) hipLaunchKernelGGL((fused_fb_kernel<2, 8>), dim3((unsigned)(pb.Mp / 64)), dim3(512), 0, s, g);
-  else if (bwd_ti(L, 1) == 2) hipLaunchKernelGGL(fused_fb_kernel<2>, dim3((unsigned)(pb.Mp / 64)), dim3(256), 0, s, g);
-  else if (bwd_nw(L, 8) == 8) hipLaunchKernelGGL((fused_fb_kernel<1, 8>), dim3((unsigned)(pb.Mp / 32)), dim3(512), 0, s, g);
-  else hipLaunchKernelGGL(fused_fb_kernel<1>, dim3((unsigned)(pb.Mp / 32)), dim3(256), 0, s, g);
+  const int ti = bwd_ti(L, 1), nw = bwd_nw(L, 8);
+  const dim3 grid((unsigned)(pb.Mp / (32 * ti))), block(64 * nw);
+  if (is_x3(L)) {
+    if (ti == 2 && nw == 8) hipLaunchKernelGGL((fused_fb_kernel<2, 8, true>), grid, block, 0, s, g);
+    else if (ti == 2) hipLaunchKernelGGL((fused_fb_kernel<2, 4, true>), grid, block, 0, s, g);
+    else if (nw == 8) hipLaunchKernelGGL((fused_fb_kernel<1, 8, true>), grid, block, 0, s, g);
+    else hipLaunchKernelGGL((fused_fb_kernel<1, 4, true>), grid, block, 0, s, g);
+  } else if (ti == 2 && nw == 8) hipLaunchKernelGGL((fused_fb_kernel<2, 8>), grid, block, 0, s, g);
+  else if (ti == 2) hipLaunchKernelGGL(fused_fb_kernel<2>, grid, block, 0, s, g);
+  else if (nw == 8) hipLaunchKernelGGL((fused_fb_kernel<1, 8>), grid, block, 0, s, g);
+  else hipLaunchKernelGGL(fused_fb_kernel<1>, grid, block, 0, s, g);
   RNB_CHECK_LAUNCH();
   return RNB_OK;
 }

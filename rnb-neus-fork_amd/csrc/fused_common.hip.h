@@ -151,6 +151,95 @@ __device__ inline void layer_mma_nt_ring(const float* __restrict__ X, const floa
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// fp32 products on the bf16 matrix pipe ("x3": every fp32 operand as THREE bf16 terms)
+// ---------------------------------------------------------------------------------------------------------------
+// x = hi + mid + lo with hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid): three round-to-nearest bf16 values
+// whose sum is x exactly (8 + 8 + 8 mantissa bits; |mid| <= 2^-9 |x|, |lo| <= 2^-18 |x|).  a b is then taken as the six
+// terms  a_hi b_hi + a_hi b_mid + a_mid b_hi + a_hi b_lo + a_lo b_hi + a_mid b_mid, accumulated in fp32 by
+// v_mfma_f32_32x32x16_bf16.  The three dropped terms are below 2^-26 |a b| together: a quarter of the rounding error
+// fp32 itself commits on the product, so the result is an fp32 product in every sense the parity tests can see — at
+// 6 x 32 cycles per 16 k (192) against 8 x 64 = 512 for v_mfma_f32_32x32x2_f32, and, unlike the fp32 MFMA, the bf16
+// MFMA co-executes with the VALU work of the epilogues (profiles/r02_overlap_probe_*).
+// Weights are split once per step into a fragment-ordered mirror (x3_pack_weights): for W [N][K], fragment (nt, ks)
+// = rows 32 nt .. +32, k = 16 ks .. +16 is three consecutive 1 KB blocks (hi, mid, lo), each 64 lanes x 16 bytes with
+// lane (c, h) = W[32 nt + c][16 ks + 8 h .. +8].  Activations stay fp32 in LDS and are split as they are read.
+template <int TJ>
+__device__ inline void x3_load_b(const x3raw* __restrict__ W3, int nks, int n0, int ks, int lane, vu4x (&b)[TJ][3]) {
+#pragma unroll
+  for (int tj = 0; tj < TJ; ++tj) {
+    const x3raw* p = W3 + ((size_t)((n0 >> 5) + tj) * nks + ks) * (3 * 512) + lane * 8;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) b[tj][pl] = *reinterpret_cast<const vu4x*>(p + pl * 512);
+  }
+}
+template <int TI>
+__device__ inline void x3_read_a(const float* __restrict__ xp, int ks, vf4 (&a)[TI][2]) {
+#pragma unroll
+  for (int ti = 0; ti < TI; ++ti) {
+    a[ti][0] = *reinterpret_cast<const vf4*>(xp + ti * 32 * FP + ks * 16);
+    a[ti][1] = *reinterpret_cast<const vf4*>(xp + ti * 32 * FP + ks * 16 + 4);
+  }
+}
+template <int TI>
+__device__ inline void x3_split(const vf4 (&raw)[TI][2], vu4x (&a)[TI][3]) {
+#pragma unroll
+  for (int ti = 0; ti < TI; ++ti) x3_split8(raw[ti][0], raw[ti][1], a[ti][0], a[ti][1], a[ti][2]);
+}
+// One pipeline stage: the MFMAs of step s (operands `a`, `b`) with, between them, the split of step s + 1's rows
+// (`raw` -> `an`): the bf16 MFMA leaves about four vector-instruction issue slots free per instruction
+// (tools/overlap_probe), which is where the 36 TI split instructions go.  Then the raw rows of step s + 2 are
+// requested into `raw` (the caller clamps the step index: no branch inside the pipeline, the last re-read is unused).
+template <int TI, int TJ, bool FIRST>
+__device__ inline void x3_stage(const float* __restrict__ xp, int ks_next_raw, vf4 (&raw)[TI][2],
+                                const vu4x (&a)[TI][3], vu4x (&an)[TI][3], const vu4x (&b)[TJ][3], v16f (&acc)[TI][TJ]) {
+  x3_mfma<TI, TJ, FIRST>(a, b, acc);
+  x3_split<TI>(raw, an);
+  constexpr int NM = 6 * TI * TJ;
+  constexpr int PER = (36 * TI + NM - 1) / NM;   // vector instructions behind each MFMA
+#pragma unroll
+  for (int m = 0; m < NM; ++m) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA
+    __builtin_amdgcn_sched_group_barrier(0x002, PER, 0);   // PER VALU
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  x3_read_a<TI>(xp, ks_next_raw, raw);
+  __builtin_amdgcn_sched_barrier(0);
+}
+// acc = X W^T (overwritten) for one wave: rows = the TI 32-row tiles at X, columns n0 .. n0 + 32 TJ.  X: LDS fp32, pitch
+// FP.  W3: the layer's x3 mirror.  K a multiple of 32.  Weight fragments run one 16-k step ahead in a second register
+// set; the split A operands likewise.  `hook` runs once, inside step 1 (the epilogue's operand loads).
+template <int TI, int TJ = 2, class Hook = NoHook>
+__device__ inline void layer_mma_x3(const float* __restrict__ X, const x3raw* __restrict__ W3, int K, int n0, int lane,
+                                    v16f (&acc)[TI][TJ], Hook hook = Hook()) {
+  const int i = lane & 31, h = lane >> 5;
+  const float* xp = X + i * FP + h * 8;
+  const int nks = K >> 4;   // even
+  vu4x b0[TJ][3], b1[TJ][3];
+  vu4x a0[TI][3], a1[TI][3];
+  vf4 raw[TI][2];
+  x3_load_b<TJ>(W3, nks, n0, 0, lane, b0);
+  x3_read_a<TI>(xp, 0, raw);
+  x3_load_b<TJ>(W3, nks, n0, 1, lane, b1);
+  x3_split<TI>(raw, a0);
+  x3_read_a<TI>(xp, 1, raw);
+  __builtin_amdgcn_sched_barrier(0);
+  // step 0 (splits step 1), then pairs
+  const int last = nks - 1;
+  x3_stage<TI, TJ, true>(xp, min(2, last), raw, a0, a1, b0, acc);
+  hook();
+  for (int ks = 1; ks + 1 < nks; ks += 2) {   // (nks even: ks + 2 <= last inside the loop)
+    x3_load_b<TJ>(W3, nks, n0, ks + 1, lane, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    x3_stage<TI, TJ, false>(xp, ks + 2, raw, a1, a0, b1, acc);
+    x3_load_b<TJ>(W3, nks, n0, ks + 2, lane, b1);
+    __builtin_amdgcn_sched_barrier(0);
+    x3_stage<TI, TJ, false>(xp, min(ks + 3, last), raw, a0, a1, b0, acc);
+  }
+  x3_mfma<TI, TJ, false>(a1, b1, acc);   // the last step: nothing left to split
+}
+
 template <int TI>
 __device__ inline void zero_acc2(v16f (&acc)[TI][2]) {
 #pragma unroll

@@ -309,6 +309,60 @@ __device__ inline void dw_main_loop(const DwPair& p, int m_begin, int m_end, int
   }
 }
 
+// ---- fp32 products as bf16 MFMA terms ("x3"): primitives (the scheme is described in fused_common.hip.h) ----------
+typedef unsigned short x3raw;
+typedef unsigned vu4x __attribute__((ext_vector_type(4)));
+typedef __bf16 x3bf8 __attribute__((ext_vector_type(8)));
+typedef __bf16 x3bf2 __attribute__((ext_vector_type(2)));
+
+__device__ inline unsigned x3_pack2(float a, float b) {
+  x3bf2 p = {(__bf16)a, (__bf16)b};   // v_cvt_pk_bf16_f32, round to nearest even
+  return __builtin_bit_cast(unsigned, p);
+}
+// 8 consecutive k of one row -> the row's hi / mid / lo operand registers: 3 conversions, 4 unpacks and 4 subtractions
+// per pair.  The subtractions (exact) must stay scalar: beside MFMAs a v_pk_add_f32 costs ~13 cycles more than the two
+// v_sub_f32 it replaces (MI355X_MICROARCH.md, packed f32 VALU), and hipcc's SLP pass would pack two adjacent
+// subtractions — so one of each pair is written as an fma, which it cannot merge with the other.
+__device__ inline void x3_split8(const vf4& x0, const vf4& x1, vu4x& hi, vu4x& mid, vu4x& lo) {
+  const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const float a = x[2 * p], b = x[2 * p + 1];
+    unsigned uh = x3_pack2(a, b);
+    asm("" : "+v"(uh));   // one conversion per pair (otherwise the low half is converted a second time for `uh << 16`)
+    const float ra = a - __builtin_bit_cast(float, uh << 16);
+    const float rb = __builtin_fmaf(__builtin_bit_cast(float, uh & 0xffff0000u), -1.f, b);
+    unsigned um = x3_pack2(ra, rb);
+    asm("" : "+v"(um));
+    const float sa = ra - __builtin_bit_cast(float, um << 16);
+    const float sb = __builtin_fmaf(__builtin_bit_cast(float, um & 0xffff0000u), -1.f, rb);
+    hi[p] = uh;
+    mid[p] = um;
+    lo[p] = x3_pack2(sa, sb);
+  }
+}
+// the six terms of one 16-k step, small ones first, the (ti, tj) accumulators in rotation
+template <int TI, int TJ, bool FIRST>
+__device__ inline void x3_mfma(const vu4x (&a)[TI][3], const vu4x (&b)[TJ][3], v16f (&acc)[TI][TJ]) {
+  constexpr int PA[6] = {2, 0, 1, 1, 0, 0};   // a_lo b_hi, a_hi b_lo, a_mid b_mid, a_mid b_hi, a_hi b_mid, a_hi b_hi
+  constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+  for (int t = 0; t < 6; ++t)
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+      for (int ti = 0; ti < TI; ++ti) {
+        if (FIRST && t == 0) {
+          const v16f zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(x3bf8, a[ti][PA[t]]),
+                                                                __builtin_bit_cast(x3bf8, b[tj][PB[t]]), zero, 0, 0, 0);
+        } else {
+          acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(x3bf8, a[ti][PA[t]]),
+                                                                __builtin_bit_cast(x3bf8, b[tj][PB[t]]), acc[ti][tj], 0, 0, 0);
+        }
+      }
+}
+
 // One dW job = one weight matrix; a launch carries a group of jobs so that the atomic tail of one matrix
 // overlaps the main loop of the next (a single 256x256 job is ONE resident wave of workgroups: all of them
 // would reach their atomics together).  block_end = exclusive prefix sum of the jobs' block counts, each a
@@ -690,6 +744,183 @@ __global__ __launch_bounds__(1024, 1) void gemm_dw_staged_kernel(const DwGroup g
         atomicAdd(J.db + wm * 64 + 2 * i + 1, (float)bs1);
       }
     }
+  }
+}
+
+// ---- dW for 256 x 256 weight matrices as six bf16 MFMA terms (RNB_VARIANT_X3) --------------------------------------
+// Same ownership as the staged kernel (one workgroup = the whole 256 x 256 gradient of a point range, slabs + ordered
+// reduction), but the operands are split ONCE per workgroup on their way into LDS: thread (column c, operand o) loads
+// X_o[m .. m + 16][c] (sixteen coalesced dword loads: a wave reads 64 consecutive columns of one row), splits each
+// group of eight points into hi / mid / lo (x3_split8) and writes six 16-byte units.  LDS image of a 16-point chunk:
+// [operand][plane][point half][column] x 16 bytes (48 KB, two buffers) — exactly the MFMA operand of lane (column, half),
+// read back by conflict-free ds_read_b128.  8 waves: wave (wm, wn) owns rows 64 wm .. + 64, columns 128 wn .. + 128 of
+// dW (128 accumulator registers; two waves per SIMD leave each 256).  Per chunk a wave issues 18 fragment reads and 48
+// MFMAs; the split of the next chunk (72 vector instructions per thread) rides in the MFMA gaps; the raw rows run TWO
+// chunks ahead in two register sets (one chunk of matrix work is shorter than an HBM round trip under load).
+// 2.1 GB of operands per step at HBM speed is the bound, not the matrix pipe (6 x 32 cycles per 16 points against
+// 8 x 64 for the fp32 MFMA).
+constexpr int kX3Chunk = 16;
+constexpr int kX3OpBytes = 3 * 2 * 256 * 16;    // one operand of one chunk: 24 KB
+constexpr int kX3BufBytes = 2 * kX3OpBytes;     // both operands
+
+__device__ inline void dw_x3_load(const float* __restrict__ src, int ld, int row0, int c, float (&x)[16]) {
+#pragma unroll
+  for (int j = 0; j < 16; ++j) x[j] = src[(size_t)(row0 + j) * ld + c];
+}
+// One chunk of one wave: the 48 MFMAs on the fragments at fx / fy (one column tile of Y at a time, the next tile's
+// fragments requested before the current tile's MFMAs), and — in the MFMA gaps, three vector instructions behind each
+// MFMA — the split of the raw rows `x` of a later chunk, written to `w` at the end.  Returns the sum of x (bias).
+__device__ inline float dw_x3_chunk(const char* fx, const char* fy, v16f (&acc)[2][4], const float (&x)[16], char* w) {
+  vu4x a[2][3], b[2][3];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) a[t][pl] = *reinterpret_cast<const vu4x*>(fx + pl * 8192 + t * 512);
+#pragma unroll
+  for (int pl = 0; pl < 3; ++pl) b[0][pl] = *reinterpret_cast<const vu4x*>(fy + pl * 8192);
+  vu4x hi[2], mid[2], lo[2];
+#pragma unroll
+  for (int ph = 0; ph < 2; ++ph)
+    x3_split8(vf4{x[8 * ph], x[8 * ph + 1], x[8 * ph + 2], x[8 * ph + 3]},
+              vf4{x[8 * ph + 4], x[8 * ph + 5], x[8 * ph + 6], x[8 * ph + 7]}, hi[ph], mid[ph], lo[ph]);
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) s += x[j];
+#pragma unroll
+  for (int tj = 0; tj < 4; ++tj) {
+    if (tj + 1 < 4) {
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) b[(tj + 1) & 1][pl] = *reinterpret_cast<const vu4x*>(fy + pl * 8192 + (tj + 1) * 512);
+    }
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0};   // small terms first (x3_mfma)
+    constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti)
+        acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(x3bf8, a[ti][PA[t]]),
+                                                              __builtin_bit_cast(x3bf8, b[tj & 1][PB[t]]), acc[ti][tj], 0, 0, 0);
+  }
+  // schedule of the region: fragment reads of tile tj + 1, then tile tj's 12 MFMAs with the vector work between them
+  __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);   // a and b[0]
+#pragma unroll
+  for (int tj = 0; tj < 4; ++tj) {
+    if (tj + 1 < 4) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+#pragma unroll
+    for (int m = 0; m < 12; ++m) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int ph = 0; ph < 2; ++ph) {
+    *reinterpret_cast<vu4x*>(w + ph * 4096) = hi[ph];
+    *reinterpret_cast<vu4x*>(w + ph * 4096 + 8192) = mid[ph];
+    *reinterpret_cast<vu4x*>(w + ph * 4096 + 16384) = lo[ph];
+  }
+  return s;
+}
+__device__ inline float dw_x3_split_store(const float (&x)[16], char* w) {   // prologue: no MFMAs to hide behind
+  float s = 0.f;
+#pragma unroll
+  for (int ph = 0; ph < 2; ++ph) {
+    vu4x hi, mid, lo;
+    x3_split8(vf4{x[8 * ph], x[8 * ph + 1], x[8 * ph + 2], x[8 * ph + 3]},
+              vf4{x[8 * ph + 4], x[8 * ph + 5], x[8 * ph + 6], x[8 * ph + 7]}, hi, mid, lo);
+    *reinterpret_cast<vu4x*>(w + ph * 4096) = hi;
+    *reinterpret_cast<vu4x*>(w + ph * 4096 + 8192) = mid;
+    *reinterpret_cast<vu4x*>(w + ph * 4096 + 16384) = lo;
+  }
+#pragma unroll
+  for (int j = 0; j < 16; ++j) s += x[j];
+  return s;
+}
+
+template <int DUMMY>
+__global__ __launch_bounds__(512, 1) void gemm_dw_x3_kernel(const DwGroup g) {
+  __shared__ __attribute__((aligned(16))) char lds[2 * kX3BufBytes];   // 96 KB
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = wave_id();
+  const int wm = wave >> 1, wn = wave & 1;
+  int ji = 0, begin = 0;
+  for (int q = 0; q + 1 < g.njobs; ++q)
+    if ((int)blockIdx.x >= g.job[q].block_end) { ji = q + 1; begin = g.job[q].block_end; }
+  const DwJob& J = g.job[ji];
+  const int split = (int)blockIdx.x - begin;
+  if (split >= J.splits) return;
+  const int m_begin = split * J.rows_per_split;
+  const int m_end = min(g.M, m_begin + J.rows_per_split);
+  if (m_begin >= m_end) return;
+  const int nchunks = (m_end - m_begin) / kX3Chunk;   // even: ranges are multiples of 32 points (host)
+  // staging role of this thread: column sc of operand sop
+  const int sc = tid & 255, sop = tid >> 8;
+  char* const swr = lds + sop * kX3OpBytes + sc * 16;   // + buffer * kX3BufBytes + half * 4096 + plane * 8192
+  // fragment addresses of this lane: column 64 wm (128 wn) + 32 t + i of the operand, point half h
+  const int i = lane & 31, h = lane >> 5;
+  const char* const fx = lds + (h * 256 + wm * 64 + i) * 16;
+  const char* const fy = lds + kX3OpBytes + (h * 256 + wn * 128 + i) * 16;
+  v16f acc[2][4];
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ti][tj][r] = 0.f;
+  double bsum = 0.0;
+  for (int pi = 0; pi < J.npairs; ++pi) {
+    const DwPair p = pi == 0 ? J.p1 : J.p2;
+    const float* src = sop == 0 ? p.X : p.Y;
+    const int ld = sop == 0 ? p.ldx : p.ldy;
+    const bool do_bias = J.db != nullptr && pi == J.bias_pair && sop == 0;
+    const int last = nchunks - 1;
+    float x0[16], x1[16];   // raw rows of an even / odd chunk
+    dw_x3_load(src, ld, m_begin, sc, x0);
+    dw_x3_load(src, ld, m_begin + min(1, last) * kX3Chunk, sc, x1);
+    __builtin_amdgcn_s_barrier();   // every wave is done with the buffers of the previous pair
+    {
+      const float s = dw_x3_split_store(x0, swr);
+      if (do_bias) bsum += (double)s;
+    }
+    dw_x3_load(src, ld, m_begin + min(2, last) * kX3Chunk, sc, x0);
+    for (int c = 0; c < nchunks; c += 2) {
+      // even chunk c from buffer 0; chunk c + 1 (x1) -> buffer 1; x1 <- chunk c + 3
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      {
+        const float s = dw_x3_chunk(fx, fy, acc, x1, swr + kX3BufBytes);
+        if (do_bias) bsum += (double)s;   // (nchunks even: chunk c + 1 always exists)
+      }
+      dw_x3_load(src, ld, m_begin + min(c + 3, last) * kX3Chunk, sc, x1);
+      // odd chunk c + 1 from buffer 1; chunk c + 2 (x0) -> buffer 0 (past the end: a re-split of the last chunk that
+      // nobody reads); x0 <- chunk c + 4
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      {
+        const float s = dw_x3_chunk(fx + kX3BufBytes, fy + kX3BufBytes, acc, x0, swr);
+        if (do_bias) bsum += (double)(c + 2 < nchunks ? s : 0.f);
+      }
+      dw_x3_load(src, ld, m_begin + min(c + 4, last) * kX3Chunk, sc, x0);
+    }
+  }
+  // accumulator (ti, tj, r) of lane (i, h) is dW[64 wm + 32 ti + rho][128 wn + 32 tj + i], rho = (r & 3) + 8 (r >> 2) + 4 h
+  const int lddw = J.lddw;
+  float* __restrict__ pdst = J.part ? J.part + (size_t)split * J.N * lddw : nullptr;
+#pragma unroll
+  for (int tj = 0; tj < 4; ++tj) {
+    const int col = wn * 128 + tj * 32 + i;
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * 64 + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (pdst) pdst[(size_t)row * lddw + col] = acc[ti][tj][r];
+        else atomicAdd(J.dW + (size_t)row * lddw + col, acc[ti][tj][r]);
+      }
+  }
+  if (J.db != nullptr && sop == 0) {   // column sums of the bias pair's X operand
+    if (J.partb) J.partb[(size_t)split * J.N + sc] = (float)bsum;
+    else atomicAdd(J.db + sc, (float)bsum);
   }
 }
 

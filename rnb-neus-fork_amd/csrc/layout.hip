@@ -44,7 +44,7 @@ int make_layout(const rnb_model_desc* d, Layout* L) {
   if (d->sdf_multires < 0 || d->sdf_multires > 16) RNB_FAIL(RNB_E_INVALID, "bad sdf_multires");
   if (!(d->sdf_scale > 0.f)) RNB_FAIL(RNB_E_INVALID, "sdf_scale must be positive");
   L->variant = d->variant;
-  if (d->variant & ~0xFF1F) RNB_FAIL(RNB_E_INVALID, "unknown bits in rnb_model_desc.variant (0x%x)", d->variant);
+  if (d->variant & ~0xFF7F) RNB_FAIL(RNB_E_INVALID, "unknown bits in rnb_model_desc.variant (0x%x)", d->variant);
   L->nh = d->sdf_n_layers;
   L->multires = d->sdf_multires;
   L->pe = 3 * (1 + 2 * d->sdf_multires);
@@ -112,6 +112,16 @@ int make_layout(const rnb_model_desc* d, Layout* L) {
     if (d->variant & RNB_VARIANT_GENERIC) RNB_FAIL(RNB_E_INVALID, "RNB_VARIANT_BF16 and RNB_VARIANT_GENERIC exclude each other");
     L->total_all = L->total + L->total / 2;   // bf16 mirror of the weights behind the fp32 ones
   }
+  if (d->variant & RNB_VARIANT_X3) {
+    if (d->variant & (RNB_VARIANT_BF16 | RNB_VARIANT_GENERIC | RNB_VARIANT_F32_MFMA))
+      RNB_FAIL(RNB_E_INVALID, "RNB_VARIANT_X3 excludes RNB_VARIANT_BF16, RNB_VARIANT_GENERIC and RNB_VARIANT_F32_MFMA");
+    if (!fused_supported(*L)) RNB_FAIL(RNB_E_INVALID, "RNB_VARIANT_X3 needs the 256-wide SDF network shape");
+  }
+  // the fused fp32 path multiplies on the bf16 matrix pipe (x3) unless the native fp32 MFMA is asked for
+  if (!(d->variant & (RNB_VARIANT_BF16 | RNB_VARIANT_GENERIC | RNB_VARIANT_F32_MFMA)) && fused_supported(*L))
+    L->variant |= RNB_VARIANT_X3;
+  if (L->variant & RNB_VARIANT_X3)
+    L->total_all = L->total + L->total / 2 * 3;   // hi / mid / lo bf16 mirror of the weights behind the fp32 ones
   return RNB_OK;
 }
 

@@ -637,6 +637,7 @@ struct DwBatch {
   hipStream_t s;
   bool lds_path;      // RNB_VARIANT_DW_LDS: staged-through-LDS kernels (A/B switch)
   bool no_staged = true;    // RNB_VARIANT_DW_STAGED clears it: 256 x 256 jobs through the LDS-DMA staged kernel
+  bool x3 = false;          // RNB_VARIANT_X3: 256 x 256 jobs through gemm_dw_x3_kernel (same split plan and slabs)
   float* part;        // RNB_VARIANT_DETERMINISTIC: bump allocator over the zeroed partial-slab workspace (or nullptr)
   int64_t part_left;
   float* slab;        // slabs of the staged 256 x 256 kernel (always; the tail of the same workspace)
@@ -686,7 +687,8 @@ struct DwBatch {
     }
     {
       ProfScope prof(flops[3], s);
-      hipLaunchKernelGGL(gemm_dw_staged_kernel<0>, dim3((unsigned)end), dim3(1024), 0, s, g);
+      if (x3) hipLaunchKernelGGL(gemm_dw_x3_kernel<0>, dim3((unsigned)end), dim3(512), 0, s, g);
+      else hipLaunchKernelGGL(gemm_dw_staged_kernel<0>, dim3((unsigned)end), dim3(1024), 0, s, g);
       RNB_CHECK_LAUNCH();
       hipLaunchKernelGGL(dw_reduce_kernel<0>, dim3(64, g.njobs), dim3(256), 0, s, g);
     }
@@ -929,7 +931,8 @@ int sweep_backward(const Layout& L, const float* packed, PointBufs& pb, bool wit
   if (det) RNB_CHECK_HIP(hipMemsetAsync(pb.dw_part, 0, (size_t)det_floats * sizeof(float), s));
   DwBatch dw(M, s, (L.variant & RNB_VARIANT_DW_LDS) != 0, det ? pb.dw_part : nullptr, det ? det_floats : 0,
              pb.dw_part + det_floats, staged_floats);
-  dw.no_staged = (L.variant & RNB_VARIANT_DW_STAGED) == 0;
+  dw.x3 = is_x3(L);
+  dw.no_staged = (L.variant & RNB_VARIANT_DW_STAGED) == 0 && !dw.x3;
   const bool color_bf16 = is_bf16(L) && with_color && bf16_color_supported(L) && pb.cin8 != nullptr;
   // ---- C': albedo network backward ---------------------------------------------------------------
   if (color_bf16) {

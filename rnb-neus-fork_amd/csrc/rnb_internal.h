@@ -172,6 +172,10 @@ int fused_forward(const Layout& L, const float* packed, const float* pts, int64_
 int launch_grid_points(const GridGen& g, int64_t first, int64_t n, float* pts, hipStream_t s);
 int launch_scale_copy(const float* src, float scale, int64_t n, float* dst, hipStream_t s);
 
+// ---- RNB_VARIANT_X3: fp32 products as six bf16 MFMA terms (fused_common.hip.h); the split weight mirror ----
+inline bool is_x3(const Layout& L) { return (L.variant & RNB_VARIANT_X3) != 0; }
+int x3_pack_weights(const Layout& L, float* packed, hipStream_t s);
+
 // ---- RNB_VARIANT_BF16 (bf16.hip): bf16-operand sweeps of the 256-wide network, saved state in bf16 "K8" layout ----
 inline bool is_bf16(const Layout& L) { return (L.variant & RNB_VARIANT_BF16) != 0; }
 int bf16_pack_weights(const Layout& L, float* packed, hipStream_t s);

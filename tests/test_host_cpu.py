@@ -50,7 +50,14 @@ def test_packed_layout_size_and_workspace_queries():
     # + albedo net, all padded to multiples of 32
     expect = (2 * 256 * 64 + 256) + 7 * (2 * 256 * 256 + 256) + (2 * 256 * 256 + 256) + 256 + 32 \
         + (2 * 256 * 320 + 256) + (2 * 256 * 256 + 256) + (32 * 256 + 32)
-    assert n.value == expect
+    # the default variant of this shape multiplies fp32 operands as three bf16 terms (x3): a split mirror of 1.5 x the
+    # floats follows the fp32 weights; the native-fp32-MFMA and generic variants carry no mirror, bf16 one of 0.5 x
+    assert n.value == expect + expect // 2 * 3
+    for kw, extra in ((dict(f32_mfma=True), 0), (dict(generic=True), 0), (dict(bf16=True), expect // 2)):
+        d2 = _desc()
+        d2.variant = R.native.variant_bits(**kw)
+        R.native.check(lib.rnb_packed_floats(C.byref(d2), C.byref(n)))
+        assert n.value == expect + extra, kw
     b = C.c_int64()
     R.native.check(lib.rnb_render_workspace_bytes(C.byref(d), 512, 128, R.native.MODE_MVPS, C.byref(b)))
     fwd_bwd = b.value
