@@ -112,9 +112,13 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_forward_kernel
 
   const int h = lane >> 5, cl = lane & 31;
   v16f acc[TI][TJ];
+  [[maybe_unused]] X3Mma<TI, TJ> mm;
+  if constexpr (X3) mm.request(g.w3 + 3 * g.w_off[0], g.Kp[0], n0, lane);
   for (int l = 0; l < g.nh; ++l) {
-    if constexpr (X3) layer_mma_x3<TI, TJ>(X, g.w3 + 3 * g.w_off[l], g.Kp[l], n0, lane, acc);
-    else layer_mma_nt<TI, NoHook, TJ>(X, g.packed + g.w_off[l], g.Kp[l], n0, lane, acc);
+    if constexpr (X3) {   // the next product's first weight steps are requested before this layer's epilogue
+      const x3raw* wn = l + 1 < g.nh ? g.w3 + 3 * g.w_off[l + 1] : (g.with_feat ? g.w3 + 3 * g.wf_off : nullptr);
+      mm.run(X, g.w3 + 3 * g.w_off[l], g.Kp[l], n0, lane, acc, wn, FH, n0);
+    } else layer_mma_nt<TI, NoHook, TJ>(X, g.packed + g.w_off[l], g.Kp[l], n0, lane, acc);
     if constexpr (NBUF == 1) lds_barrier();   // every wave has finished reading the input activations
     const float* bias = g.packed + g.b_off[l];
     // saved state goes out through buffer stores: one 32-bit lane offset per column tile plus a
@@ -190,7 +194,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_forward_kernel
   }
   // ---- feature head: rows 1.. of the output layer, written into the albedo network's input ------------
   if (g.with_feat) {
-    if constexpr (X3) layer_mma_x3<TI, TJ>(X, g.w3 + 3 * g.wf_off, FH, n0, lane, acc);
+    if constexpr (X3) mm.run(X, g.w3 + 3 * g.wf_off, FH, n0, lane, acc, nullptr, 0, 0);   // (requested by the last hidden layer)
     else layer_mma_nt<TI, NoHook, TJ>(X, g.packed + g.wf_off, FH, n0, lane, acc);
     const float* bias = g.packed + g.bf_off;
     const BufRsrc rc = tile_rsrc(g.cin + (size_t)row0 * g.Cinp, FT * g.Cinp * 4);

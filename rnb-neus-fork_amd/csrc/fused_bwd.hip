@@ -113,8 +113,11 @@ __device__ inline void prefetch_tile(const float* base, int64_t row0, int n0, in
 // product as six bf16 MFMA terms per 16 k (fused_common.hip.h).
 template <int TI, int TJ = 2, bool X3 = false, class Hook = NoHook>
 __device__ inline void layer_mma(const float* __restrict__ X, const FusedBwdArgs& g, long long off, int K, int n0, int lane,
-                                 v16f (&acc)[TI][TJ], Hook hook = Hook(), int hook_late = 0) {
-  if constexpr (X3) layer_mma_x3<TI, TJ, Hook>(X, g.w3 + 3 * off, K, n0, lane, acc, hook);
+                                 v16f (&acc)[TI][TJ], X3Mma<TI, TJ>& mm, long long off_next, Hook hook = Hook(),
+                                 int hook_late = 0) {
+  // X3: this product's first weight steps were requested through `mm` (before the previous epilogue); off_next >= 0
+  // names the product that follows (K = 256), whose first steps are requested as this one finishes
+  if constexpr (X3) mm.run(X, g.w3 + 3 * off, K, n0, lane, acc, off_next >= 0 ? g.w3 + 3 * off_next : nullptr, FH, n0, hook);
   else if constexpr (TI == 2 && TJ == 2) layer_mma_nt_ring<TI>(X, g.packed + off, K, n0, lane, acc, hook);
   else layer_mma_nt<TI, Hook, TJ>(X, g.packed + off, K, n0, lane, acc, hook, hook_late);
 }
@@ -159,8 +162,13 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TI == 2) ? 1 : 2) void fused_r
 
   v16f acc[TI][TJ];
   AuxTile<TI, TJ> aD;
+  [[maybe_unused]] X3Mma<TI, TJ> mm;
+  if constexpr (X3) {
+    if (g.nh > 1 || n0 < 64) mm.request(g.w3 + 3 * g.wT_off[g.nh - 1], FH, n0, lane);
+  }
   for (int l = g.nh - 1; l >= 1; --l) {
-    layer_mma<TI, TJ, X3>(X, g, g.wT_off[l], FH, n0, lane, acc,   // g = gz_l W_l  (columns = inputs of layer l)
+    const long long nxt = (l > 1 || n0 < 64) ? g.wT_off[l - 1] : -1;   // layer 0's product: the waves of columns 0..63
+    layer_mma<TI, TJ, X3>(X, g, g.wT_off[l], FH, n0, lane, acc, mm, nxt,   // g = gz_l W_l  (columns = inputs of layer l)
                      [&]() { prefetch_tile<TI, TJ>(g.D[l - 1], row0, n0, lane, aD); });
     if constexpr (NBUF == 1) lds_barrier();   // every wave has finished reading the tile
     const bool is_skip = (l == g.skip);
@@ -190,7 +198,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TI == 2) ? 1 : 2) void fused_r
   }
   // layer 0: g_e += gz_0 W_0 (Ep = 64 columns: the waves that own columns 0..63)
   if (n0 < 64) {
-    layer_mma<TI, TJ, X3>(X, g, g.wT_off[0], FH, n0, lane, acc);
+    layer_mma<TI, TJ, X3>(X, g, g.wT_off[0], FH, n0, lane, acc, mm, -1);
     for_each_acc<TI, TJ>(n0, lane, [&](int tj, int ti, int r, int col, int rowc, int row) {
       if (col < g.pe) GE[row * FEP + col] += acc[ti][tj][r];
     });
@@ -248,10 +256,12 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TI == 2) ? 1 : 2) void fused_r
 
   v16f acc[TI][TJ];
   AuxTile<TI, TJ> aD, aG;
+  [[maybe_unused]] X3Mma<TI, TJ> mm;
+  if constexpr (X3) mm.request(g.w3 + 3 * g.w_off[0], g.Kp[0], n0, lane);
   for (int l = 0; l < g.nh; ++l) {
     // TI == 2: only one operand tile fits next to the weight fragments during the matrix loop; the second
     // one is requested right after it, into the registers the weight fragments leave behind
-    layer_mma<TI, TJ, X3>(X, g, g.w_off[l], g.Kp[l], n0, lane, acc,   // gzb = u_l W_l^T
+    layer_mma<TI, TJ, X3>(X, g, g.w_off[l], g.Kp[l], n0, lane, acc, mm, l + 1 < g.nh ? g.w_off[l + 1] : -1,   // gzb = u_l W_l^T
                      [&]() {
                        prefetch_tile<TI, TJ>(g.D[l], row0, n0, lane, aD);
                        if constexpr (BOTH_IN_LOOP) prefetch_tile<TI, TJ>(g.gz[l], row0, n0, lane, aG);
@@ -317,6 +327,11 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TI == 2) ? 1 : 2) void fused_f
 
   v16f acc[TI][TJ];
   AuxTile<TI, TJ> aD, aZ;
+  [[maybe_unused]] X3Mma<TI, TJ> mm;
+  if constexpr (X3) {
+    if (g.fbar != nullptr) mm.request(g.w3 + 3 * g.wfT_off, FH, n0, lane);
+    else if (g.nh > 1) mm.request(g.w3 + 3 * g.wT_off[g.nh - 1], FH, n0, lane);
+  }
   prefetch_tile<TI, TJ>(g.D[g.nh - 1], row0, n0, lane, aD);
   prefetch_tile<TI, TJ>(g.zR[g.nh - 1], row0, n0, lane, aZ);
   for (int ti_ = 0; ti_ < TI; ++ti_) for (int tj_ = 0; tj_ < TJ; ++tj_) for (int r_ = 0; r_ < 16; ++r_) acc[ti_][tj_][r_] = 0.f;
@@ -327,7 +342,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TI == 2) ? 1 : 2) void fused_f
       *reinterpret_cast<vf4*>(X + r * FP + c4 * 4) = *reinterpret_cast<const vf4*>(fb + (size_t)r * g.ld_fbar + c4 * 4);
     }
     __syncthreads();
-    layer_mma<TI, TJ, X3>(X, g, g.wfT_off, FH, n0, lane, acc);
+    layer_mma<TI, TJ, X3>(X, g, g.wfT_off, FH, n0, lane, acc, mm, g.nh > 1 ? g.wT_off[g.nh - 1] : -1);
     if constexpr (NBUF == 1) lds_barrier();
   }
   for (int l = g.nh - 1; l >= 0; --l) {
@@ -355,7 +370,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TI == 2) ? 1 : 2) void fused_f
     if (l == 0) break;
     lds_barrier();
     if constexpr (NBUF == 2) { float* t = X; X = Y; Y = t; }
-    layer_mma<TI, TJ, X3>(X, g, g.wT_off[l], FH, n0, lane, acc,   // ab_{l-1} = zb_l W_l
+    layer_mma<TI, TJ, X3>(X, g, g.wT_off[l], FH, n0, lane, acc, mm, l > 1 ? g.wT_off[l - 1] : -1,   // ab_{l-1} = zb_l W_l
                      [&]() {
                        prefetch_tile<TI, TJ>(g.D[l - 1], row0, n0, lane, aD);
                        if constexpr (BOTH_IN_LOOP) prefetch_tile<TI, TJ>(g.zR[l - 1], row0, n0, lane, aZ);
@@ -403,6 +418,8 @@ static void fill_args(const Layout& L, const float* packed, PointBufs& pb, Fused
 //   TI=1 NW=8: 603 / 671 / 669      two workgroups per CU, 4 waves per SIMD (<= 128 registers)   <- default
 // More resident waves beat larger tiles: what limits these kernels is waiting (operand tiles from HBM, weight
 // fragments from L2), which only other waves' MFMAs can fill.  RNB_VARIANT_BWD_TI / _NW (rnb_model_desc.variant) override all three.
+// x3 (the default arithmetic): TI=1 NW=4, 489 / 600 / 537 us against 525 / 678 / 527 for TI=1 NW=8 — the split of an A
+// row serves two column tiles instead of one, which keeps the vector work inside the MFMA gaps.
 static int bwd_nw(const Layout& L, int dflt) {
   const int v = L.knob(RNB_VARIANT_BWD_NW_SHIFT);
   return v == 1 ? 4 : v == 2 ? 8 : dflt;
@@ -423,7 +440,7 @@ int fused_reverse(const Layout& L, const float* packed, PointBufs& pb, hipStream
   FusedBwdArgs g;
   fill_args(L, packed, pb, g);
   ProfScope prof(hidden_flops(L, pb.M, 0), s);
-  const int ti = bwd_ti(L, 1), nw = bwd_nw(L, 8);
+  const int ti = bwd_ti(L, 1), nw = bwd_nw(L, is_x3(L) ? 4 : 8);
   const dim3 grid((unsigned)(pb.Mp / (32 * ti))), block(64 * nw);
   if (is_x3(L)) {
     if (ti == 2 && nw == 8) hipLaunchKernelGGL((fused_reverse_kernel<2, 8, true>), grid, block, 0, s, g);
@@ -442,7 +459,7 @@ int fused_ra(const Layout& L, const float* packed, PointBufs& pb, hipStream_t s)
   FusedBwdArgs g;
   fill_args(L, packed, pb, g);
   ProfScope prof(hidden_flops(L, pb.M, 0), s);
-  const int ti = bwd_ti(L, 1), nw = bwd_nw(L, 8);
+  const int ti = bwd_ti(L, 1), nw = bwd_nw(L, is_x3(L) ? 4 : 8);
   const dim3 grid((unsigned)(pb.Mp / (32 * ti))), block(64 * nw);
   if (is_x3(L)) {
     if (ti == 2 && nw == 8) hipLaunchKernelGGL((fused_ra_kernel<2, 8, true>), grid, block, 0, s, g);
@@ -463,7 +480,7 @@ int fused_fb(const Layout& L, const float* packed, PointBufs& pb, bool with_colo
   g.fbar = with_color ? pb.cinb : nullptr;
   g.ld_fbar = L.Cinp;
   ProfScope prof(hidden_flops(L, pb.M, 1) + (with_color ? 2.0 * (double)pb.M * L.F * L.H : 0.0), s);
-  const int ti = bwd_ti(L, 1), nw = bwd_nw(L, 8);
+  const int ti = bwd_ti(L, 1), nw = bwd_nw(L, is_x3(L) ? 4 : 8);
   const dim3 grid((unsigned)(pb.Mp / (32 * ti))), block(64 * nw);
   if (is_x3(L)) {
     if (ti == 2 && nw == 8) hipLaunchKernelGGL((fused_fb_kernel<2, 8, true>), grid, block, 0, s, g);

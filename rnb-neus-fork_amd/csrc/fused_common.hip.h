@@ -210,34 +210,54 @@ __device__ inline void x3_stage(const float* __restrict__ xp, int ks_next_raw, v
 // acc = X W^T (overwritten) for one wave: rows = the TI 32-row tiles at X, columns n0 .. n0 + 32 TJ.  X: LDS fp32, pitch
 // FP.  W3: the layer's x3 mirror.  K a multiple of 32.  Weight fragments run one 16-k step ahead in a second register
 // set; the split A operands likewise.  `hook` runs once, inside step 1 (the epilogue's operand loads).
+// The weight fragments of steps 0 and 1 are REQUESTED by the caller (`request`) — for the next layer's product before
+// the epilogue of this one, so that they land during the epilogue instead of costing an exposed L2 round trip (and, the
+// memory counter retiring in order, a wait for the epilogue's stores) at the top of every layer.
+template <int TI, int TJ = 2>
+struct X3Mma {
+  vu4x b0[TJ][3], b1[TJ][3];
+  __device__ inline void request(const x3raw* __restrict__ W3, int K, int n0, int lane) {
+    x3_load_b<TJ>(W3, K >> 4, n0, 0, lane, b0);
+    x3_load_b<TJ>(W3, K >> 4, n0, 1, lane, b1);
+  }
+  // W3n / Kn / n0n: the product that follows (nullptr: none); its first two weight steps are requested as soon as the
+  // registers are free
+  template <class Hook = NoHook>
+  __device__ inline void run(const float* __restrict__ X, const x3raw* __restrict__ W3, int K, int n0, int lane,
+                             v16f (&acc)[TI][TJ], const x3raw* __restrict__ W3n, int Kn, int n0n, Hook hook = Hook()) {
+    const int i = lane & 31, h = lane >> 5;
+    const float* xp = X + i * FP + h * 8;
+    const int nks = K >> 4;   // even
+    vu4x a0[TI][3], a1[TI][3];
+    vf4 raw[TI][2];
+    x3_read_a<TI>(xp, 0, raw);
+    x3_split<TI>(raw, a0);
+    x3_read_a<TI>(xp, 1, raw);
+    __builtin_amdgcn_sched_barrier(0);
+    const int last = nks - 1;
+    x3_stage<TI, TJ, true>(xp, min(2, last), raw, a0, a1, b0, acc);   // step 0 (splits step 1)
+    hook();
+    for (int ks = 1; ks + 1 < nks; ks += 2) {   // (nks even: ks + 2 <= last inside the loop)
+      x3_load_b<TJ>(W3, nks, n0, ks + 1, lane, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      x3_stage<TI, TJ, false>(xp, ks + 2, raw, a1, a0, b1, acc);
+      x3_load_b<TJ>(W3, nks, n0, ks + 2, lane, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      x3_stage<TI, TJ, false>(xp, min(ks + 3, last), raw, a0, a1, b0, acc);
+    }
+    if (W3n) x3_load_b<TJ>(W3n, Kn >> 4, n0n, 0, lane, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    x3_mfma<TI, TJ, false>(a1, b1, acc);   // the last step: nothing left to split
+    __builtin_amdgcn_sched_barrier(0);
+    if (W3n) x3_load_b<TJ>(W3n, Kn >> 4, n0n, 1, lane, b1);
+  }
+};
 template <int TI, int TJ = 2, class Hook = NoHook>
 __device__ inline void layer_mma_x3(const float* __restrict__ X, const x3raw* __restrict__ W3, int K, int n0, int lane,
                                     v16f (&acc)[TI][TJ], Hook hook = Hook()) {
-  const int i = lane & 31, h = lane >> 5;
-  const float* xp = X + i * FP + h * 8;
-  const int nks = K >> 4;   // even
-  vu4x b0[TJ][3], b1[TJ][3];
-  vu4x a0[TI][3], a1[TI][3];
-  vf4 raw[TI][2];
-  x3_load_b<TJ>(W3, nks, n0, 0, lane, b0);
-  x3_read_a<TI>(xp, 0, raw);
-  x3_load_b<TJ>(W3, nks, n0, 1, lane, b1);
-  x3_split<TI>(raw, a0);
-  x3_read_a<TI>(xp, 1, raw);
-  __builtin_amdgcn_sched_barrier(0);
-  // step 0 (splits step 1), then pairs
-  const int last = nks - 1;
-  x3_stage<TI, TJ, true>(xp, min(2, last), raw, a0, a1, b0, acc);
-  hook();
-  for (int ks = 1; ks + 1 < nks; ks += 2) {   // (nks even: ks + 2 <= last inside the loop)
-    x3_load_b<TJ>(W3, nks, n0, ks + 1, lane, b0);
-    __builtin_amdgcn_sched_barrier(0);
-    x3_stage<TI, TJ, false>(xp, ks + 2, raw, a1, a0, b1, acc);
-    x3_load_b<TJ>(W3, nks, n0, ks + 2, lane, b1);
-    __builtin_amdgcn_sched_barrier(0);
-    x3_stage<TI, TJ, false>(xp, min(ks + 3, last), raw, a0, a1, b0, acc);
-  }
-  x3_mfma<TI, TJ, false>(a1, b1, acc);   // the last step: nothing left to split
+  X3Mma<TI, TJ> m;
+  m.request(W3, K, n0, lane);
+  m.run(X, W3, K, n0, lane, acc, nullptr, 0, 0, hook);
 }
 
 template <int TI>

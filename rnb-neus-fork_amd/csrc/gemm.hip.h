@@ -747,6 +747,127 @@ __global__ __launch_bounds__(1024, 1) void gemm_dw_staged_kernel(const DwGroup g
   }
 }
 
+// ---- C[M x N] = A[M x K] W[N][K]^T as six bf16 MFMA terms (RNB_VARIANT_X3; the albedo network's GEMMs) -------------
+// Same tiling and epilogues as gemm_rows_kernel (128 x BN output tile, 4 waves of 64 x BN/2), but the 16-k staging
+// tiles are split into hi / mid / lo bf16 planes on their way into LDS (once per workgroup: every staged fp32 value
+// is split by the thread that loaded it), and the waves multiply plane fragments: lane (row i, half h) reads 16 bytes
+// = k 8h .. 8h + 7 of its row.  Plane tile: [rows][48 bytes] (16 bf16 + pad: conflict-free ds_read_b128).
+constexpr int XK = 16;   // k per staging tile = one MFMA k-step
+constexpr int XP = 48;   // bytes per row of a plane tile
+
+typedef unsigned vu2x __attribute__((ext_vector_type(2)));
+__device__ inline void x3_split4(const vf4& x, vu2x& hi, vu2x& mid, vu2x& lo) {
+  const float v[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const float a = v[2 * p], b = v[2 * p + 1];
+    unsigned uh = x3_pack2(a, b);
+    asm("" : "+v"(uh));
+    const float ra = a - __builtin_bit_cast(float, uh << 16);
+    const float rb = __builtin_fmaf(__builtin_bit_cast(float, uh & 0xffff0000u), -1.f, b);
+    unsigned um = x3_pack2(ra, rb);
+    asm("" : "+v"(um));
+    const float sa = ra - __builtin_bit_cast(float, um << 16);
+    const float sb = __builtin_fmaf(__builtin_bit_cast(float, um & 0xffff0000u), -1.f, rb);
+    hi[p] = uh;
+    mid[p] = um;
+    lo[p] = x3_pack2(sa, sb);
+  }
+}
+// ROWS x 16 k of a k-contiguous source -> ROWS / 64 float4 per thread (row idx >> 2, k quad idx & 3)
+template <int ROWS, bool GUARD>
+__device__ inline void x3_load_rows(const float* __restrict__ src, int ld, int r0, int k0, int rmax, int tid,
+                                    vf4 (&v)[ROWS / 64]) {
+#pragma unroll
+  for (int i = 0; i < ROWS / 64; ++i) {
+    const int idx = tid + 256 * i;
+    const int r = idx >> 2, c4 = idx & 3;
+    if constexpr (!GUARD) {
+      v[i] = *reinterpret_cast<const vf4*>(src + (size_t)(r0 + r) * ld + k0 + c4 * 4);
+    } else {
+      const bool ok = r0 + r < rmax;
+      const int rr = ok ? r0 + r : rmax - 1;
+      const vf4 t = *reinterpret_cast<const vf4*>(src + (size_t)rr * ld + k0 + c4 * 4);
+      v[i] = make_vf4(ok ? t.x : 0.f, ok ? t.y : 0.f, ok ? t.z : 0.f, ok ? t.w : 0.f);
+    }
+  }
+}
+template <int ROWS>
+__device__ inline void x3_store_rows(char* __restrict__ P, int tid, const vf4 (&v)[ROWS / 64]) {
+#pragma unroll
+  for (int i = 0; i < ROWS / 64; ++i) {
+    const int idx = tid + 256 * i;
+    const int r = idx >> 2, c4 = idx & 3;
+    vu2x hi, mid, lo;
+    x3_split4(v[i], hi, mid, lo);
+    char* w = P + r * XP + c4 * 8;
+    *reinterpret_cast<vu2x*>(w) = hi;
+    *reinterpret_cast<vu2x*>(w + ROWS * XP) = mid;
+    *reinterpret_cast<vu2x*>(w + 2 * ROWS * XP) = lo;
+  }
+}
+
+template <int BN, bool GUARD, class Epi>
+__global__ __launch_bounds__(256, 2) void gemm_rows_x3_kernel(const float* __restrict__ A, int lda,
+                                                              const float* __restrict__ W, int ldw, int N, int K, Epi epi) {
+  constexpr int TN = BN / 64;
+  __shared__ __attribute__((aligned(16))) char smem[3 * (BM + BN) * XP];
+  char* Ap = smem;
+  char* Bp = smem + 3 * BM * XP;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = wave_id();
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m_blk = blockIdx.x * BM, n_blk = blockIdx.y * BN;
+  unsigned mask = 0;
+#pragma unroll
+  for (int tj = 0; tj < TN; ++tj)
+    if (n_blk + wn * (BN / 2) + tj * 32 < N) mask |= 1u << tj;
+  const int i = lane & 31, h = lane >> 5;
+  const char* fa = Ap + (wm * 64 + i) * XP + h * 16;
+  const char* fb = Bp + (wn * (BN / 2) + i) * XP + h * 16;
+
+  v16f acc[2][TN];
+  zero_acc<TN>(acc);
+  vf4 ra[BM / 64], rb[BN / 64];
+  const int nk = K / XK;
+  x3_load_rows<BM, false>(A, lda, m_blk, 0, 0, tid, ra);
+  x3_load_rows<BN, GUARD>(W, ldw, n_blk, 0, N, tid, rb);
+  for (int kt = 0; kt < nk; ++kt) {
+    x3_store_rows<BM>(Ap, tid, ra);
+    x3_store_rows<BN>(Bp, tid, rb);
+    lds_barrier();
+    {
+      const int k0 = min(kt + 1, nk - 1) * XK;   // past the end: a harmless re-load
+      x3_load_rows<BM, false>(A, lda, m_blk, k0, 0, tid, ra);
+      x3_load_rows<BN, GUARD>(W, ldw, n_blk, k0, N, tid, rb);
+    }
+    vu4x a[2][3];
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) a[ti][pl] = *reinterpret_cast<const vu4x*>(fa + pl * BM * XP + ti * 32 * XP);
+#pragma unroll
+    for (int tj = 0; tj < TN; ++tj) {
+      if (GUARD && !((mask >> tj) & 1u)) continue;
+      vu4x b[3];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) b[pl] = *reinterpret_cast<const vu4x*>(fb + pl * BN * XP + tj * 32 * XP);
+      constexpr int PA[6] = {2, 0, 1, 1, 0, 0};   // small terms first (x3_mfma)
+      constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+          acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(x3bf8, a[ti][PA[t]]),
+                                                                __builtin_bit_cast(x3bf8, b[PB[t]]), acc[ti][tj], 0, 0, 0);
+    }
+    lds_barrier();
+  }
+  static_assert(4 * 16 * (32 * TN + 4) * 4 <= 3 * (BM + BN) * XP, "epilogue strips must fit in the staging LDS");
+  run_epilogue<TN, Epi>(acc, reinterpret_cast<float*>(smem) + wave * 16 * (32 * TN + 4), m_blk + wm * 64,
+                        n_blk + wn * (BN / 2), lane, mask, epi);
+}
+
 // ---- dW for 256 x 256 weight matrices as six bf16 MFMA terms (RNB_VARIANT_X3) --------------------------------------
 // Same ownership as the staged kernel (one workgroup = the whole 256 x 256 gradient of a point range, slabs + ordered
 // reduction), but the operands are split ONCE per workgroup on their way into LDS: thread (column c, operand o) loads

@@ -569,10 +569,20 @@ struct EpiStore {
 // algorithmic FLOPs of one layer-shaped GEMM over M points: real (unpadded) layer shape
 static inline double mm_flops(int64_t M, const Lin& ln) { return 2.0 * (double)M * ln.N * ln.K; }
 
+// x3: the product as six bf16 MFMA terms (RNB_VARIANT_X3; k-contiguous weights, N >= 256, K % 16 == 0)
 template <bool B_KMAJOR, class Epi>
 static int launch_rows(const float* A, int lda, const float* W, int ldw, int64_t Mp, int N, int K, const Epi& epi,
-                       double flops, hipStream_t s) {
+                       double flops, hipStream_t s, bool x3 = false) {
   ProfScope prof(flops, s);
+  if constexpr (!B_KMAJOR) {
+    if (x3 && N >= 256 && K % XK == 0) {
+      dim3 grid((unsigned)(Mp / BM), (unsigned)((N + 255) / 256));
+      if (N % 256 == 0) hipLaunchKernelGGL((gemm_rows_x3_kernel<256, false, Epi>), grid, dim3(256), 0, s, A, lda, W, ldw, N, K, epi);
+      else hipLaunchKernelGGL((gemm_rows_x3_kernel<256, true, Epi>), grid, dim3(256), 0, s, A, lda, W, ldw, N, K, epi);
+      RNB_CHECK_LAUNCH();
+      return RNB_OK;
+    }
+  }
   if (N >= 256) {   // 128 x 256 tiles: the 256-wide layers of the full model run as one wave of 2 blocks / CU
     dim3 grid((unsigned)(Mp / BM), (unsigned)((N + 255) / 256));
     if (N % 256 == 0)
@@ -910,7 +920,7 @@ int sweep_color(const Layout& L, const float* packed, PointBufs& pb, const float
     const float* in = l == 0 ? pb.cin : pb.ac[l - 1];
     const int lda = l == 0 ? L.Cinp : L.Hcp;
     EpiRelu epi{packed + ln.b_off, pb.ac[l], L.Hcp, ln.N};
-    RNB_TRY((launch_rows<false, EpiRelu>(in, lda, packed + ln.w_off, ln.Kp, pb.Mp, ln.Np, ln.Kp, epi, mm_flops(pb.M, ln), s)));
+    RNB_TRY((launch_rows<false, EpiRelu>(in, lda, packed + ln.w_off, ln.Kp, pb.Mp, ln.Np, ln.Kp, epi, mm_flops(pb.M, ln), s, is_x3(L))));
   }
   hipLaunchKernelGGL(color_out_kernel, dim3(blocks_for(pb.Mp * 32, 256)), dim3(256), 0, s, pb.ac[L.nc - 1], L.Hcp,
                      L.Hc, packed + L.colo.w_off, L.colo.Kp, packed + L.colo.b_off, L.Co, L.squeeze, pb.Mp, pb.alb);
@@ -955,10 +965,10 @@ int sweep_backward(const Layout& L, const float* packed, PointBufs& pb, bool wit
       if (l > 0) {
         EpiReluMask epi{pb.ac[l - 1], pb.zc[l - 1], L.Hcp, L.col[l - 1].N};
         // zc_{l-1} = (zc_l W_l) * relu': k-contiguous product against the transposed copy W_l^T [Kp x Np]
-        RNB_TRY((launch_rows<false, EpiReluMask>(pb.zc[l], L.Hcp, packed + ln.wT_off, ln.Np, Mp, ln.Kp, ln.Np, epi, mm_flops(M, ln), s)));
+        RNB_TRY((launch_rows<false, EpiReluMask>(pb.zc[l], L.Hcp, packed + ln.wT_off, ln.Np, Mp, ln.Kp, ln.Np, epi, mm_flops(M, ln), s, is_x3(L))));
       } else {
         EpiStore epi{pb.cinb, L.Cinp};
-        RNB_TRY((launch_rows<false, EpiStore>(pb.zc[0], L.Hcp, packed + ln.wT_off, ln.Np, Mp, ln.Kp, ln.Np, epi, mm_flops(M, ln), s)));
+        RNB_TRY((launch_rows<false, EpiStore>(pb.zc[0], L.Hcp, packed + ln.wT_off, ln.Np, Mp, ln.Kp, ln.Np, epi, mm_flops(M, ln), s, is_x3(L))));
       }
     }
   }
