@@ -117,7 +117,11 @@ __device__ inline void layer_mma(const float* __restrict__ X, const FusedBwdArgs
                                  int hook_late = 0) {
   // X3: this product's first weight steps were requested through `mm` (before the previous epilogue); off_next >= 0
   // names the product that follows (K = 256), whose first steps are requested as this one finishes
-  if constexpr (X3) mm.run(X, g.w3 + 3 * off, K, n0, lane, acc, off_next >= 0 ? g.w3 + 3 * off_next : nullptr, FH, n0, hook);
+  // (64 x 64-output waves keep no weight registers across the epilogue: its two operand tiles need them)
+  if constexpr (X3 && TI == 2 && TJ == 2) {
+    mm.request(g.w3 + 3 * off, K, n0, lane);
+    mm.run(X, g.w3 + 3 * off, K, n0, lane, acc, nullptr, 0, 0, hook);
+  } else if constexpr (X3) mm.run(X, g.w3 + 3 * off, K, n0, lane, acc, off_next >= 0 ? g.w3 + 3 * off_next : nullptr, FH, n0, hook);
   else if constexpr (TI == 2 && TJ == 2) layer_mma_nt_ring<TI>(X, g.packed + off, K, n0, lane, acc, hook);
   else layer_mma_nt<TI, Hook, TJ>(X, g.packed + off, K, n0, lane, acc, hook, hook_late);
 }
@@ -163,19 +167,25 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TI == 2) ? 1 : 2) void fused_r
   v16f acc[TI][TJ];
   AuxTile<TI, TJ> aD;
   [[maybe_unused]] X3Mma<TI, TJ> mm;
-  if constexpr (X3) {
+  if constexpr (X3 && !(TI == 2 && TJ == 2)) {
     if (g.nh > 1 || n0 < 64) mm.request(g.w3 + 3 * g.wT_off[g.nh - 1], FH, n0, lane);
   }
   for (int l = g.nh - 1; l >= 1; --l) {
     const long long nxt = (l > 1 || n0 < 64) ? g.wT_off[l - 1] : -1;   // layer 0's product: the waves of columns 0..63
+    // x3, 64 x 64-output waves: the operand tile is requested AFTER the matrix loop, into the registers the loop's
+    // fragments leave behind; the other workgroup of the CU multiplies while it travels
+    constexpr bool LATE = X3 && TI == 2 && TJ == 2;
     layer_mma<TI, TJ, X3>(X, g, g.wT_off[l], FH, n0, lane, acc, mm, nxt,   // g = gz_l W_l  (columns = inputs of layer l)
-                     [&]() { prefetch_tile<TI, TJ>(g.D[l - 1], row0, n0, lane, aD); });
+                     [&]() { if constexpr (!LATE) prefetch_tile<TI, TJ>(g.D[l - 1], row0, n0, lane, aD); });
+    const int lane_e = opaque_lane(lane);   // the epilogue's per-lane offsets are rebuilt here, not carried through the loop
+    const int h = lane_e >> 5;
+    if constexpr (LATE) prefetch_tile<TI, TJ>(g.D[l - 1], row0, n0, lane_e, aD);
     if constexpr (NBUF == 1) lds_barrier();   // every wave has finished reading the tile
     const bool is_skip = (l == g.skip);
     const int ksplit = is_skip ? FH - g.pe : FH;   // columns that belong to layer l-1's output
     const BufRsrc rg = tile_rsrc(g.gz[l - 1] + (size_t)row0 * FH, BT * FH * 4);
     for_each_acc_split<TI, TJ>(
-        n0, lane, ksplit,
+        n0, lane_e, ksplit,
         [&](int tj, int ti, int r, int col, int rowc, int row) {
           const float gzv = acc[ti][tj][r] * aD.v[ti][tj][r];
           Y[row * FP + col] = gzv;
@@ -257,23 +267,26 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TI == 2) ? 1 : 2) void fused_r
   v16f acc[TI][TJ];
   AuxTile<TI, TJ> aD, aG;
   [[maybe_unused]] X3Mma<TI, TJ> mm;
-  if constexpr (X3) mm.request(g.w3 + 3 * g.w_off[0], g.Kp[0], n0, lane);
+  if constexpr (X3 && !(TI == 2 && TJ == 2)) mm.request(g.w3 + 3 * g.w_off[0], g.Kp[0], n0, lane);
   for (int l = 0; l < g.nh; ++l) {
     // TI == 2: only one operand tile fits next to the weight fragments during the matrix loop; the second
     // one is requested right after it, into the registers the weight fragments leave behind
     layer_mma<TI, TJ, X3>(X, g, g.w_off[l], g.Kp[l], n0, lane, acc, mm, l + 1 < g.nh ? g.w_off[l + 1] : -1,   // gzb = u_l W_l^T
                      [&]() {
-                       prefetch_tile<TI, TJ>(g.D[l], row0, n0, lane, aD);
+                       if constexpr (!(X3 && !BOTH_IN_LOOP)) prefetch_tile<TI, TJ>(g.D[l], row0, n0, lane, aD);
                        if constexpr (BOTH_IN_LOOP) prefetch_tile<TI, TJ>(g.gz[l], row0, n0, lane, aG);
                      });
-    if constexpr (!BOTH_IN_LOOP) prefetch_tile<TI, TJ>(g.gz[l], row0, n0, lane, aG);
+    const int lane_e = opaque_lane(lane);   // (see fused_reverse_kernel)
+    const int h = lane_e >> 5;
+    if constexpr (X3 && !BOTH_IN_LOOP) prefetch_tile<TI, TJ>(g.D[l], row0, n0, lane_e, aD);   // (x3: both after the loop)
+    if constexpr (!BOTH_IN_LOOP) prefetch_tile<TI, TJ>(g.gz[l], row0, n0, lane_e, aG);
     if constexpr (NBUF == 1) lds_barrier();
     const int n_real = g.n_real[l];
     const bool pe_tail = (l + 1 == g.skip);
     const BufRsrc rzR = tile_rsrc(g.zR[l] + (size_t)row0 * FH, BT * FH * 4);
     const BufRsrc ru = tile_rsrc(g.u[l + 1] + (size_t)row0 * FH, BT * FH * 4);
     for_each_acc_split<TI, TJ>(
-        n0, lane, n_real,
+        n0, lane_e, n_real,
         [&](int tj, int ti, int r, int col, int rowc, int row) {
           const unsigned voff = (unsigned)(4 * h * FH + col) * 4u;
           const unsigned soff = rowc * FH * 4;
@@ -328,12 +341,15 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TI == 2) ? 1 : 2) void fused_f
   v16f acc[TI][TJ];
   AuxTile<TI, TJ> aD, aZ;
   [[maybe_unused]] X3Mma<TI, TJ> mm;
-  if constexpr (X3) {
+  if constexpr (X3 && !(TI == 2 && TJ == 2)) {
     if (g.fbar != nullptr) mm.request(g.w3 + 3 * g.wfT_off, FH, n0, lane);
     else if (g.nh > 1) mm.request(g.w3 + 3 * g.wT_off[g.nh - 1], FH, n0, lane);
   }
-  prefetch_tile<TI, TJ>(g.D[g.nh - 1], row0, n0, lane, aD);
-  prefetch_tile<TI, TJ>(g.zR[g.nh - 1], row0, n0, lane, aZ);
+  constexpr bool LATE = X3 && TI == 2 && TJ == 2;   // operand tiles requested after the matrix loop (see fused_reverse_kernel)
+  if constexpr (!LATE) {
+    prefetch_tile<TI, TJ>(g.D[g.nh - 1], row0, n0, lane, aD);
+    prefetch_tile<TI, TJ>(g.zR[g.nh - 1], row0, n0, lane, aZ);
+  }
   for (int ti_ = 0; ti_ < TI; ++ti_) for (int tj_ = 0; tj_ < TJ; ++tj_) for (int r_ = 0; r_ < 16; ++r_) acc[ti_][tj_][r_] = 0.f;
   if (g.fbar != nullptr) {   // ab_{nh-1} = fbar W_feat (+ the sdf-head term below)
     const float* fb = g.fbar + (size_t)row0 * g.ld_fbar;
@@ -345,18 +361,24 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TI == 2) ? 1 : 2) void fused_f
     layer_mma<TI, TJ, X3>(X, g, g.wfT_off, FH, n0, lane, acc, mm, g.nh > 1 ? g.wT_off[g.nh - 1] : -1);
     if constexpr (NBUF == 1) lds_barrier();
   }
+  if constexpr (LATE) {
+    prefetch_tile<TI, TJ>(g.D[g.nh - 1], row0, n0, lane, aD);
+    prefetch_tile<TI, TJ>(g.zR[g.nh - 1], row0, n0, lane, aZ);
+  }
   for (int l = g.nh - 1; l >= 0; --l) {
     // epilogue of the product that produced ab_l: zb_l = ab_l * D_l + zR_l
+    const int lane_e = opaque_lane(lane);   // (see fused_reverse_kernel)
+    const int h = lane_e >> 5;
     const int n_real = g.n_real[l];
     const bool head = (l == g.nh - 1);
     const BufRsrc rzb = tile_rsrc(g.zb[l] + (size_t)row0 * FH, BT * FH * 4);
     if (head) {   // + sbar / scale * w_sdf  (the sdf head's contribution to ab_{nh-1}); once per launch
-      for_each_acc<TI, TJ>(n0, lane, [&](int tj, int ti, int r, int col, int rowc, int row) {
+      for_each_acc<TI, TJ>(n0, lane_e, [&](int tj, int ti, int r, int col, int rowc, int row) {
         acc[ti][tj][r] = fmaf(g.sbar[row0 + row] * g.inv_scale, g.packed[g.wsdf_off + col], acc[ti][tj][r]);
       });
     }
     for_each_acc_split<TI, TJ>(
-        n0, lane, n_real,
+        n0, lane_e, n_real,
         [&](int tj, int ti, int r, int col, int rowc, int row) {
           const float zb = fmaf(acc[ti][tj][r], aD.v[ti][tj][r], aZ.v[ti][tj][r]);
           Y[row * FP + col] = zb;
@@ -372,10 +394,11 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TI == 2) ? 1 : 2) void fused_f
     if constexpr (NBUF == 2) { float* t = X; X = Y; Y = t; }
     layer_mma<TI, TJ, X3>(X, g, g.wT_off[l], FH, n0, lane, acc, mm, l > 1 ? g.wT_off[l - 1] : -1,   // ab_{l-1} = zb_l W_l
                      [&]() {
-                       prefetch_tile<TI, TJ>(g.D[l - 1], row0, n0, lane, aD);
+                       if constexpr (!(X3 && !BOTH_IN_LOOP)) prefetch_tile<TI, TJ>(g.D[l - 1], row0, n0, lane, aD);
                        if constexpr (BOTH_IN_LOOP) prefetch_tile<TI, TJ>(g.zR[l - 1], row0, n0, lane, aZ);
                      });
-    if constexpr (!BOTH_IN_LOOP) prefetch_tile<TI, TJ>(g.zR[l - 1], row0, n0, lane, aZ);
+    if constexpr (X3 && !BOTH_IN_LOOP) prefetch_tile<TI, TJ>(g.D[l - 1], row0, n0, opaque_lane(lane), aD);
+    if constexpr (!BOTH_IN_LOOP) prefetch_tile<TI, TJ>(g.zR[l - 1], row0, n0, opaque_lane(lane), aZ);
     if constexpr (NBUF == 1) lds_barrier();   // every wave has finished reading the tile
   }
 }
@@ -418,8 +441,11 @@ static void fill_args(const Layout& L, const float* packed, PointBufs& pb, Fused
 //   TI=1 NW=8: 603 / 671 / 669      two workgroups per CU, 4 waves per SIMD (<= 128 registers)   <- default
 // More resident waves beat larger tiles: what limits these kernels is waiting (operand tiles from HBM, weight
 // fragments from L2), which only other waves' MFMAs can fill.  RNB_VARIANT_BWD_TI / _NW (rnb_model_desc.variant) override all three.
-// x3 (the default arithmetic): TI=1 NW=4, 489 / 600 / 537 us against 525 / 678 / 527 for TI=1 NW=8 — the split of an A
-// row serves two column tiles instead of one, which keeps the vector work inside the MFMA gaps.
+// x3 (the default arithmetic) runs TI=2 NW=4: 436 / 536 / 480 us against 503 / 602 / 555 (TI=1 NW=4), 483 / 619 / 666
+// (TI=1 NW=8) and 493 / 630 / 590 (TI=2 NW=8).  64 x 64 outputs per wave halve both the weight bytes pulled from L2 per
+// point (32-point tiles ran at the CU's 64 B/clk fill rate, the matrix pipe 28-34 % busy) and the split work per MFMA;
+// the operand tiles of the epilogue are requested after the matrix loop, into the registers it frees, and travel while
+// the CU's other workgroup multiplies.
 static int bwd_nw(const Layout& L, int dflt) {
   const int v = L.knob(RNB_VARIANT_BWD_NW_SHIFT);
   return v == 1 ? 4 : v == 2 ? 8 : dflt;
@@ -440,7 +466,7 @@ int fused_reverse(const Layout& L, const float* packed, PointBufs& pb, hipStream
   FusedBwdArgs g;
   fill_args(L, packed, pb, g);
   ProfScope prof(hidden_flops(L, pb.M, 0), s);
-  const int ti = bwd_ti(L, 1), nw = bwd_nw(L, is_x3(L) ? 4 : 8);
+  const int ti = bwd_ti(L, is_x3(L) ? 2 : 1), nw = bwd_nw(L, is_x3(L) ? 4 : 8);
   const dim3 grid((unsigned)(pb.Mp / (32 * ti))), block(64 * nw);
   if (is_x3(L)) {
     if (ti == 2 && nw == 8) hipLaunchKernelGGL((fused_reverse_kernel<2, 8, true>), grid, block, 0, s, g);
@@ -459,7 +485,7 @@ int fused_ra(const Layout& L, const float* packed, PointBufs& pb, hipStream_t s)
   FusedBwdArgs g;
   fill_args(L, packed, pb, g);
   ProfScope prof(hidden_flops(L, pb.M, 0), s);
-  const int ti = bwd_ti(L, 1), nw = bwd_nw(L, is_x3(L) ? 4 : 8);
+  const int ti = bwd_ti(L, is_x3(L) ? 2 : 1), nw = bwd_nw(L, is_x3(L) ? 4 : 8);
   const dim3 grid((unsigned)(pb.Mp / (32 * ti))), block(64 * nw);
   if (is_x3(L)) {
     if (ti == 2 && nw == 8) hipLaunchKernelGGL((fused_ra_kernel<2, 8, true>), grid, block, 0, s, g);
@@ -480,7 +506,7 @@ int fused_fb(const Layout& L, const float* packed, PointBufs& pb, bool with_colo
   g.fbar = with_color ? pb.cinb : nullptr;
   g.ld_fbar = L.Cinp;
   ProfScope prof(hidden_flops(L, pb.M, 1) + (with_color ? 2.0 * (double)pb.M * L.F * L.H : 0.0), s);
-  const int ti = bwd_ti(L, 1), nw = bwd_nw(L, is_x3(L) ? 4 : 8);
+  const int ti = bwd_ti(L, is_x3(L) ? 2 : 1), nw = bwd_nw(L, is_x3(L) ? 4 : 8);
   const dim3 grid((unsigned)(pb.Mp / (32 * ti))), block(64 * nw);
   if (is_x3(L)) {
     if (ti == 2 && nw == 8) hipLaunchKernelGGL((fused_fb_kernel<2, 8, true>), grid, block, 0, s, g);

@@ -26,6 +26,10 @@ __device__ inline void load_b_block(const float* __restrict__ W, int K, int n0, 
   }
 }
 
+// A value the optimiser cannot see through: per-lane offsets derived from it are rebuilt where they are used instead of
+// being hoisted out of the layer loop and kept live across the matrix loop (where they spill).
+__device__ inline int opaque_lane(int v) { asm volatile("" : "+v"(v)); return v; }
+
 struct NoHook {
   __device__ void operator()() const {}
 };
