@@ -348,7 +348,9 @@ def run_train(args):
         value = B * world * args.steps / elapsed
         bf16 = args.dtype == "bf16"
         roof = None
-        tr = measured_traffic("hbm_traffic_bf16.json" if bf16 else "hbm_traffic.json", world, B, S)
+        traffic_file = ("hbm_traffic_bf16.json" if bf16 else
+                        ("r02_hbm_traffic_f32_mfma.json" if args.f32_mfma else "hbm_traffic.json"))
+        tr = measured_traffic(traffic_file, world, B, S)
         if use_events and gemm_n.value > 0:
             ach = gemm_fl.value / (gemm_ms.value * 1e-3) / 1e12
             step_tf = tf.value / (ms_per_step * 1e-3) / 1e12
@@ -358,16 +360,28 @@ def run_train(args):
                       "gemm_ms_per_step": round(gemm_ms.value / args.steps, 3),
                       "step_algorithmic_tflops": round(step_tf, 3)}
             if not bf16:
-                roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+                # dtype f32.  Default arithmetic ("x3"): every fp32 product as six v_mfma_f32_32x32x16_bf16 terms on
+                # three-way split operands, so the matrix-pipe ceiling of an fp32 FLOP is the dense bf16 peak / 6;
+                # --f32-mfma: v_mfma_f32_32x32x2_f32 against the fp32 MFMA peak.  `achieved` counts ALGORITHMIC fp32
+                # FLOPs (2 M N K of the real layer shapes), never the six terms.
+                x3 = not args.f32_mfma
+                peak = BF16_MFMA_PEAK_TFLOPS / 6.0 if x3 else FP32_MFMA_PEAK_TFLOPS
+                roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
+                        "frac": round(ach / peak, 4),
+                        "peak_basis": ("2500 TFLOP/s dense bf16 MFMA / 6 bf16 terms per fp32 product (x3 arithmetic)" if x3
+                                       else "157.3 TFLOP/s dense fp32 MFMA"),
+                        "frac_of_fp32_mfma_peak": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
                         "traffic": round(tr["hbm_bytes_per_launch"]) if tr else None,
                         "traffic_unit": "HBM bytes per launch",
                         "traffic_detail": ({"hbm_bytes_per_step": round(tr["hbm_bytes_per_step"]),
                                             "launches_per_step": tr["launches_per_step"],
-                                            "source": "profiles/hbm_traffic.json"} if tr else None),
-                        "kernel": "fp32-MFMA family: fused_forward/reverse/ra/fb_kernel, gemm_dw_direct_kernel, "
-                                  "gemm_rows_kernel<*>",
-                        "step_frac": round(step_tf / FP32_MFMA_PEAK_TFLOPS, 4)}
+                                            "source": "profiles/" + traffic_file} if tr else None),
+                        "kernel": ("x3 MFMA family: fused_forward/reverse/ra/fb_kernel<.., true>, gemm_dw_x3_kernel, "
+                                   "gemm_rows_x3_kernel<*> (+ gemm_dw_direct_kernel<64> for the K = 64 / 320 gradients)" if x3 else
+                                   "fp32-MFMA family: fused_forward/reverse/ra/fb_kernel, gemm_dw_direct_kernel, "
+                                   "gemm_rows_kernel<*>"),
+                        "step_frac": round(step_tf / peak, 4),
+                        "step_frac_of_fp32_mfma_peak": round(step_tf / FP32_MFMA_PEAK_TFLOPS, 4)}
                 roof.update(common)
             else:
                 # bf16 sweeps: 1/16 of the fp32 matrix time, so the per-point saved state decides: the bound is HBM.
@@ -477,9 +491,15 @@ def run_mesh(args):
         roof = None
         if use_events and gemm_n.value > 0:
             ach = gemm_fl.value / (gemm_ms.value * 1e-3) / 1e12
-            peak = BF16_MFMA_PEAK_TFLOPS if args.dtype == "bf16" else FP32_MFMA_PEAK_TFLOPS
-            roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s",
+            x3 = args.dtype != "bf16" and not args.f32_mfma   # fp32 products as six bf16 MFMA terms (see bench_train)
+            peak = (BF16_MFMA_PEAK_TFLOPS if args.dtype == "bf16" else
+                    (BF16_MFMA_PEAK_TFLOPS / 6.0 if x3 else FP32_MFMA_PEAK_TFLOPS))
+            roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
                     "frac": round(ach / peak, 4), "traffic": None,
+                    "peak_basis": ("2500 TFLOP/s dense bf16 MFMA" if args.dtype == "bf16" else
+                                   ("2500 TFLOP/s dense bf16 MFMA / 6 bf16 terms per fp32 product (x3 arithmetic)" if x3
+                                    else "157.3 TFLOP/s dense fp32 MFMA")),
+                    "frac_of_fp32_mfma_peak": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
                     "kernel": "fused forward-only SDF sweep with in-kernel grid-point generation",
                     "launches_per_step": gemm_n.value / args.steps,
                     "avg_launch_us": round(1e3 * gemm_ms.value / gemm_n.value, 2),
