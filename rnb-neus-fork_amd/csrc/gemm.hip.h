@@ -607,9 +607,16 @@ __global__ __launch_bounds__(256) void dw_reduce_kernel(const DwGroup g) {
   const DwJob& J = g.job[blockIdx.y];
   const size_t n = (size_t)J.N * J.lddw;
   for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (size_t)gridDim.x * 256) {
-    double s = 0.0;
-    for (int sp = 0; sp < J.splits; ++sp) s += (double)J.part[(size_t)sp * n + idx];
-    J.dW[idx] = (float)s;
+    // four interleaved running sums (splits 0, 4, 8 .. / 1, 5, .. / ..) combined in a fixed order: as reproducible as one
+    // chain, but four loads in flight instead of one
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    int sp = 0;
+    for (; sp + 4 <= J.splits; sp += 4) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s[u] += (double)J.part[(size_t)(sp + u) * n + idx];
+    }
+    for (int u = 0; sp < J.splits; ++sp, ++u) s[u] += (double)J.part[(size_t)sp * n + idx];
+    J.dW[idx] = (float)((s[0] + s[1]) + (s[2] + s[3]));
   }
   if (J.db != nullptr && J.partb != nullptr) {
     for (int r = blockIdx.x * 256 + threadIdx.x; r < J.N; r += gridDim.x * 256) {
@@ -870,48 +877,55 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_x3_kernel(const float* __res
 
 // ---- dW for 256 x 256 weight matrices as six bf16 MFMA terms (RNB_VARIANT_X3) --------------------------------------
 // Same ownership as the staged kernel (one workgroup = the whole 256 x 256 gradient of a point range, slabs + ordered
-// reduction), but the operands are split ONCE per workgroup on their way into LDS: thread (column c, operand o) loads
-// X_o[m .. m + 16][c] (sixteen coalesced dword loads: a wave reads 64 consecutive columns of one row), splits each
-// group of eight points into hi / mid / lo (x3_split8) and writes six 16-byte units.  LDS image of a 16-point chunk:
-// [operand][plane][point half][column] x 16 bytes (48 KB, two buffers) — exactly the MFMA operand of lane (column, half),
-// read back by conflict-free ds_read_b128.  8 waves: wave (wm, wn) owns rows 64 wm .. + 64, columns 128 wn .. + 128 of
-// dW (128 accumulator registers; two waves per SIMD leave each 256).  Per chunk a wave issues 18 fragment reads and 48
-// MFMAs; the split of the next chunk (72 vector instructions per thread) rides in the MFMA gaps; the raw rows run TWO
-// chunks ahead in two register sets (one chunk of matrix work is shorter than an HBM round trip under load).
-// 2.1 GB of operands per step at HBM speed is the bound, not the matrix pipe (6 x 32 cycles per 16 points against
-// 8 x 64 for the fp32 MFMA).
+// reduction), but the operands are split ONCE per workgroup on their way into LDS.  Staging: wave (operand o, point
+// quad q) loads rows m + 4q .. + 4 of X_o, one dwordx4 per lane = ONE whole 1 KB row per instruction (thread = 4
+// consecutive columns x 4 points; 4 loads per 16-point chunk — sixteen dword loads per thread, the first version,
+// filled the vector-memory queue: half of every chunk's time went into issuing them, tools/dwx3_bench), splits each
+// column's four points into hi / mid / lo (x3_split4) and writes 8-byte half units.  LDS image of a chunk:
+// [operand][plane][point half][unit(column)] x 16 bytes with unit(c) = 68 (c & 3) + (c >> 2): the writer's lanes (column
+// group c >> 2, fixed c & 3) and the reader's lanes (32 consecutive columns, ds_read_b128 of the MFMA operand of lane
+// (column, half)) are both conflict-free.  8 waves: wave (wm, wn) owns rows 64 wm .. + 64, columns 128 wn .. + 128 of dW
+// (128 accumulator registers; two waves per SIMD leave each 256).  Per chunk a wave issues 18 fragment reads and 48
+// MFMAs; the split of the next chunk rides in the MFMA gaps; the raw rows run TWO chunks ahead in two register sets.
 constexpr int kX3Chunk = 16;
-constexpr int kX3OpBytes = 3 * 2 * 256 * 16;    // one operand of one chunk: 24 KB
+constexpr int kX3Half = 4 * 68 * 16;            // one point half of one plane: 272 units (4 column residues x 68)
+constexpr int kX3Plane = 2 * kX3Half;
+constexpr int kX3OpBytes = 3 * kX3Plane;        // one operand of one chunk: 25.5 KB
 constexpr int kX3BufBytes = 2 * kX3OpBytes;     // both operands
 
-__device__ inline void dw_x3_load(const float* __restrict__ src, int ld, int row0, int c, float (&x)[16]) {
+__device__ inline void dw_x3_load(const float* __restrict__ src, int ld, int row0, int c4, vf4 (&x)[4]) {
 #pragma unroll
-  for (int j = 0; j < 16; ++j) x[j] = src[(size_t)(row0 + j) * ld + c];
+  for (int p = 0; p < 4; ++p) x[p] = *reinterpret_cast<const vf4*>(src + (size_t)(row0 + p) * ld + c4);
+}
+// 4 columns x 4 points of one thread -> 12 half units at w (+ 68 * 16 per column, + kX3Plane per plane)
+__device__ inline void dw_x3_split(const vf4 (&x)[4], vu2x (&hi)[4], vu2x (&mid)[4], vu2x (&lo)[4]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) x3_split4(vf4{x[0][j], x[1][j], x[2][j], x[3][j]}, hi[j], mid[j], lo[j]);
+}
+__device__ inline void dw_x3_store(char* w, const vu2x (&hi)[4], const vu2x (&mid)[4], const vu2x (&lo)[4]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    *reinterpret_cast<vu2x*>(w + j * 68 * 16) = hi[j];
+    *reinterpret_cast<vu2x*>(w + j * 68 * 16 + kX3Plane) = mid[j];
+    *reinterpret_cast<vu2x*>(w + j * 68 * 16 + 2 * kX3Plane) = lo[j];
+  }
 }
 // One chunk of one wave: the 48 MFMAs on the fragments at fx / fy (one column tile of Y at a time, the next tile's
 // fragments requested before the current tile's MFMAs), and — in the MFMA gaps, three vector instructions behind each
-// MFMA — the split of the raw rows `x` of a later chunk, written to `w` at the end.  Returns the sum of x (bias).
-__device__ inline float dw_x3_chunk(const char* fx, const char* fy, v16f (&acc)[2][4], const float (&x)[16], char* w) {
+// MFMA — the split of the raw rows `x` of a later chunk, written to `w` at the end.
+__device__ inline void dw_x3_chunk(const char* fx, const char* fy, v16f (&acc)[2][4], const vf4 (&x)[4], char* w) {
   vu4x a[2][3], b[2][3];
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) a[t][pl] = *reinterpret_cast<const vu4x*>(fx + pl * 8192 + t * 512);
+    for (int pl = 0; pl < 3; ++pl) a[t][pl] = *reinterpret_cast<const vu4x*>(fx + pl * kX3Plane + t * 128);
 #pragma unroll
-  for (int pl = 0; pl < 3; ++pl) b[0][pl] = *reinterpret_cast<const vu4x*>(fy + pl * 8192);
-  vu4x hi[2], mid[2], lo[2];
-#pragma unroll
-  for (int ph = 0; ph < 2; ++ph)
-    x3_split8(vf4{x[8 * ph], x[8 * ph + 1], x[8 * ph + 2], x[8 * ph + 3]},
-              vf4{x[8 * ph + 4], x[8 * ph + 5], x[8 * ph + 6], x[8 * ph + 7]}, hi[ph], mid[ph], lo[ph]);
-  float s = 0.f;
-#pragma unroll
-  for (int j = 0; j < 16; ++j) s += x[j];
+  for (int pl = 0; pl < 3; ++pl) b[0][pl] = *reinterpret_cast<const vu4x*>(fy + pl * kX3Plane);
 #pragma unroll
   for (int tj = 0; tj < 4; ++tj) {
     if (tj + 1 < 4) {
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) b[(tj + 1) & 1][pl] = *reinterpret_cast<const vu4x*>(fy + pl * 8192 + (tj + 1) * 512);
+      for (int pl = 0; pl < 3; ++pl) b[(tj + 1) & 1][pl] = *reinterpret_cast<const vu4x*>(fy + pl * kX3Plane + (tj + 1) * 128);
     }
     constexpr int PA[6] = {2, 0, 1, 1, 0, 0};   // small terms first (x3_mfma)
     constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
@@ -921,8 +935,16 @@ __device__ inline float dw_x3_chunk(const char* fx, const char* fy, v16f (&acc)[
       for (int ti = 0; ti < 2; ++ti)
         acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(x3bf8, a[ti][PA[t]]),
                                                               __builtin_bit_cast(x3bf8, b[tj & 1][PB[t]]), acc[ti][tj], 0, 0, 0);
+    {   // column tj of this thread's 4 x 4 raw block: split and stored while tile tj multiplies
+      vu2x hi, mid, lo;
+      x3_split4(vf4{x[0][tj], x[1][tj], x[2][tj], x[3][tj]}, hi, mid, lo);
+      *reinterpret_cast<vu2x*>(w + tj * 68 * 16) = hi;
+      *reinterpret_cast<vu2x*>(w + tj * 68 * 16 + kX3Plane) = mid;
+      *reinterpret_cast<vu2x*>(w + tj * 68 * 16 + 2 * kX3Plane) = lo;
+    }
   }
-  // schedule of the region: fragment reads of tile tj + 1, then tile tj's 12 MFMAs with the vector work between them
+  // schedule of the region: per column tile its fragment reads (of the NEXT tile), its 12 MFMAs with the vector work of
+  // one raw column between them, then that column's three stores
   __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);   // a and b[0]
 #pragma unroll
   for (int tj = 0; tj < 4; ++tj) {
@@ -930,37 +952,23 @@ __device__ inline float dw_x3_chunk(const char* fx, const char* fy, v16f (&acc)[
 #pragma unroll
     for (int m = 0; m < 12; ++m) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
     }
+    __builtin_amdgcn_sched_group_barrier(0x200, 3, 0);
   }
   __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int ph = 0; ph < 2; ++ph) {
-    *reinterpret_cast<vu4x*>(w + ph * 4096) = hi[ph];
-    *reinterpret_cast<vu4x*>(w + ph * 4096 + 8192) = mid[ph];
-    *reinterpret_cast<vu4x*>(w + ph * 4096 + 16384) = lo[ph];
-  }
-  return s;
 }
-__device__ inline float dw_x3_split_store(const float (&x)[16], char* w) {   // prologue: no MFMAs to hide behind
-  float s = 0.f;
+__device__ inline void dw_x3_colsum(const vf4 (&x)[4], bool on, double (&bs)[4]) {
+  if (!on) return;
 #pragma unroll
-  for (int ph = 0; ph < 2; ++ph) {
-    vu4x hi, mid, lo;
-    x3_split8(vf4{x[8 * ph], x[8 * ph + 1], x[8 * ph + 2], x[8 * ph + 3]},
-              vf4{x[8 * ph + 4], x[8 * ph + 5], x[8 * ph + 6], x[8 * ph + 7]}, hi, mid, lo);
-    *reinterpret_cast<vu4x*>(w + ph * 4096) = hi;
-    *reinterpret_cast<vu4x*>(w + ph * 4096 + 8192) = mid;
-    *reinterpret_cast<vu4x*>(w + ph * 4096 + 16384) = lo;
-  }
-#pragma unroll
-  for (int j = 0; j < 16; ++j) s += x[j];
-  return s;
+  for (int j = 0; j < 4; ++j) bs[j] += (double)((x[0][j] + x[1][j]) + (x[2][j] + x[3][j]));
 }
 
+// DUMMY == 1 (tools/dwx3_bench only): wave 0 sums the clocks it spends waiting at the barrier / issuing a chunk's
+// reads, MFMAs, split and stores / issuing the next loads, and leaves them in J.db (as uint64[8] per workgroup)
 template <int DUMMY>
 __global__ __launch_bounds__(512, 1) void gemm_dw_x3_kernel(const DwGroup g) {
-  __shared__ __attribute__((aligned(16))) char lds[2 * kX3BufBytes];   // 96 KB
+  __shared__ __attribute__((aligned(16))) char lds[2 * kX3BufBytes];   // 102 KB
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = wave_id();
   const int wm = wave >> 1, wn = wave & 1;
@@ -974,13 +982,14 @@ __global__ __launch_bounds__(512, 1) void gemm_dw_x3_kernel(const DwGroup g) {
   const int m_end = min(g.M, m_begin + J.rows_per_split);
   if (m_begin >= m_end) return;
   const int nchunks = (m_end - m_begin) / kX3Chunk;   // even: ranges are multiples of 32 points (host)
-  // staging role of this thread: column sc of operand sop
-  const int sc = tid & 255, sop = tid >> 8;
-  char* const swr = lds + sop * kX3OpBytes + sc * 16;   // + buffer * kX3BufBytes + half * 4096 + plane * 8192
+  // staging role of this thread: columns 4 cg .. + 4, points 4 pq .. + 4 of operand sop
+  const int cg = lane, pq = wave & 3, sop = wave >> 2;
+  char* const swr = lds + sop * kX3OpBytes + (pq >> 1) * kX3Half + cg * 16 + (pq & 1) * 8;   // + buffer, column, plane
   // fragment addresses of this lane: column 64 wm (128 wn) + 32 t + i of the operand, point half h
   const int i = lane & 31, h = lane >> 5;
-  const char* const fx = lds + (h * 256 + wm * 64 + i) * 16;
-  const char* const fy = lds + kX3OpBytes + (h * 256 + wn * 128 + i) * 16;
+  const int ui = (i & 3) * 68 + (i >> 2);
+  const char* const fx = lds + h * kX3Half + (ui + 16 * wm) * 16;
+  const char* const fy = lds + kX3OpBytes + h * kX3Half + (ui + 32 * wn) * 16;
   v16f acc[2][4];
 #pragma unroll
   for (int ti = 0; ti < 2; ++ti)
@@ -988,40 +997,49 @@ __global__ __launch_bounds__(512, 1) void gemm_dw_x3_kernel(const DwGroup g) {
     for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[ti][tj][r] = 0.f;
-  double bsum = 0.0;
+  double bs[4] = {0.0, 0.0, 0.0, 0.0};
+  [[maybe_unused]] unsigned long long t_bar = 0, t_chunk = 0, t_load = 0, t_all = 0;
+  [[maybe_unused]] const unsigned long long t_begin = DUMMY == 1 ? __builtin_amdgcn_s_memtime() : 0;
+  [[maybe_unused]] const unsigned long long r_begin = DUMMY == 1 ? __builtin_amdgcn_s_memrealtime() : 0;
   for (int pi = 0; pi < J.npairs; ++pi) {
     const DwPair p = pi == 0 ? J.p1 : J.p2;
-    const float* src = sop == 0 ? p.X : p.Y;
+    const float* src = (sop == 0 ? p.X : p.Y) + 4 * cg;
     const int ld = sop == 0 ? p.ldx : p.ldy;
-    const bool do_bias = J.db != nullptr && pi == J.bias_pair && sop == 0;
+    const bool do_bias = DUMMY == 0 && J.db != nullptr && pi == J.bias_pair && sop == 0;
     const int last = nchunks - 1;
-    float x0[16], x1[16];   // raw rows of an even / odd chunk
-    dw_x3_load(src, ld, m_begin, sc, x0);
-    dw_x3_load(src, ld, m_begin + min(1, last) * kX3Chunk, sc, x1);
+    const int r0 = m_begin + 4 * pq;
+    vf4 x0[4], x1[4];   // raw rows of an even / odd chunk
+    dw_x3_load(src, ld, r0, 0, x0);
+    dw_x3_load(src, ld, r0 + min(1, last) * kX3Chunk, 0, x1);
     __builtin_amdgcn_s_barrier();   // every wave is done with the buffers of the previous pair
     {
-      const float s = dw_x3_split_store(x0, swr);
-      if (do_bias) bsum += (double)s;
+      vu2x hi[4], mid[4], lo[4];
+      dw_x3_split(x0, hi, mid, lo);
+      dw_x3_store(swr, hi, mid, lo);
+      dw_x3_colsum(x0, do_bias, bs);
     }
-    dw_x3_load(src, ld, m_begin + min(2, last) * kX3Chunk, sc, x0);
+    dw_x3_load(src, ld, r0 + min(2, last) * kX3Chunk, 0, x0);
     for (int c = 0; c < nchunks; c += 2) {
       // even chunk c from buffer 0; chunk c + 1 (x1) -> buffer 1; x1 <- chunk c + 3
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      [[maybe_unused]] const unsigned long long s0 = DUMMY == 1 ? __builtin_amdgcn_s_memtime() : 0;
       __builtin_amdgcn_s_barrier();
-      {
-        const float s = dw_x3_chunk(fx, fy, acc, x1, swr + kX3BufBytes);
-        if (do_bias) bsum += (double)s;   // (nchunks even: chunk c + 1 always exists)
+      [[maybe_unused]] const unsigned long long s1 = DUMMY == 1 ? __builtin_amdgcn_s_memtime() : 0;
+      dw_x3_chunk(fx, fy, acc, x1, swr + kX3BufBytes);
+      dw_x3_colsum(x1, do_bias, bs);   // (nchunks even: chunk c + 1 always exists)
+      [[maybe_unused]] const unsigned long long s2 = DUMMY == 1 ? __builtin_amdgcn_s_memtime() : 0;
+      dw_x3_load(src, ld, r0 + min(c + 3, last) * kX3Chunk, 0, x1);
+      if constexpr (DUMMY == 1) {
+        const unsigned long long s3 = __builtin_amdgcn_s_memtime();
+        t_bar += s1 - s0; t_chunk += s2 - s1; t_load += s3 - s2;
       }
-      dw_x3_load(src, ld, m_begin + min(c + 3, last) * kX3Chunk, sc, x1);
       // odd chunk c + 1 from buffer 1; chunk c + 2 (x0) -> buffer 0 (past the end: a re-split of the last chunk that
       // nobody reads); x0 <- chunk c + 4
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      {
-        const float s = dw_x3_chunk(fx + kX3BufBytes, fy + kX3BufBytes, acc, x0, swr);
-        if (do_bias) bsum += (double)(c + 2 < nchunks ? s : 0.f);
-      }
-      dw_x3_load(src, ld, m_begin + min(c + 4, last) * kX3Chunk, sc, x0);
+      dw_x3_chunk(fx + kX3BufBytes, fy + kX3BufBytes, acc, x0, swr);
+      dw_x3_colsum(x0, do_bias && c + 2 < nchunks, bs);
+      dw_x3_load(src, ld, r0 + min(c + 4, last) * kX3Chunk, 0, x0);
     }
   }
   // accumulator (ti, tj, r) of lane (i, h) is dW[64 wm + 32 ti + rho][128 wn + 32 tj + i], rho = (r & 3) + 8 (r >> 2) + 4 h
@@ -1039,9 +1057,27 @@ __global__ __launch_bounds__(512, 1) void gemm_dw_x3_kernel(const DwGroup g) {
         else atomicAdd(J.dW + (size_t)row * lddw + col, acc[ti][tj][r]);
       }
   }
-  if (J.db != nullptr && sop == 0) {   // column sums of the bias pair's X operand
-    if (J.partb) J.partb[(size_t)split * J.N + sc] = (float)bsum;
-    else atomicAdd(J.db + sc, (float)bsum);
+  if constexpr (DUMMY == 1) {
+    if (tid == 0) {
+      unsigned long long* o = reinterpret_cast<unsigned long long*>(J.db) + 8 * (size_t)blockIdx.x;
+      t_all = __builtin_amdgcn_s_memtime() - t_begin;
+      o[0] = t_bar; o[1] = t_chunk; o[2] = t_load; o[3] = t_all;
+      o[4] = __builtin_amdgcn_s_memrealtime() - r_begin;   // 100 MHz
+    }
+  }
+  if (DUMMY == 0 && J.db != nullptr) {   // column sums of the bias pair's X operand: the four point quads of a column meet in LDS
+    double* bx = reinterpret_cast<double*>(lds);
+    __syncthreads();
+    if (sop == 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bx[pq * 256 + 4 * cg + j] = bs[j];
+    }
+    __syncthreads();
+    if (tid < 256) {
+      const float v = (float)((bx[tid] + bx[256 + tid]) + (bx[512 + tid] + bx[768 + tid]));
+      if (J.partb) J.partb[(size_t)split * J.N + tid] = v;
+      else atomicAdd(J.db + tid, v);
+    }
   }
 }
 

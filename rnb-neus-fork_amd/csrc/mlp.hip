@@ -700,7 +700,7 @@ struct DwBatch {
       if (x3) hipLaunchKernelGGL(gemm_dw_x3_kernel<0>, dim3((unsigned)end), dim3(512), 0, s, g);
       else hipLaunchKernelGGL(gemm_dw_staged_kernel<0>, dim3((unsigned)end), dim3(1024), 0, s, g);
       RNB_CHECK_LAUNCH();
-      hipLaunchKernelGGL(dw_reduce_kernel<0>, dim3(64, g.njobs), dim3(256), 0, s, g);
+      hipLaunchKernelGGL(dw_reduce_kernel<0>, dim3(256, g.njobs), dim3(256), 0, s, g);
     }
     g.njobs = 0;
     flops[3] = 0.0;
@@ -738,7 +738,7 @@ struct DwBatch {
       else hipLaunchKernelGGL((gemm_dw_kernel<true, 64>), grid, dim3(256), 0, s, g);
       if (part != nullptr) {   // ordered reduction of the partial slabs
         RNB_CHECK_LAUNCH();
-        hipLaunchKernelGGL(dw_reduce_kernel<0>, dim3(64, g.njobs), dim3(256), 0, s, g);
+        hipLaunchKernelGGL(dw_reduce_kernel<0>, dim3(256, g.njobs), dim3(256), 0, s, g);
       }
     }
     g.njobs = 0;
