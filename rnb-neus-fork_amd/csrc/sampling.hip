@@ -75,7 +75,9 @@ __global__ __launch_bounds__(64) void up_sample_kernel(UpArgs a) {
     z[j] = zz;
     float s;
     if (a.gather_index != nullptr) {
-      const int idx = a.gather_index[b * n + j];
+      // clamped: with NaN depths the merge below leaves slots of sort_index unwritten (every comparison false), and a
+      // stray index must not become a stray address — the reference yields NaNs there, not a fault
+      const int idx = min(max(a.gather_index[b * n + j], 0), n - 1);
       s = idx < a.n_old ? a.sdf_old[b * a.n_old + idx] : a.sdf_new[b * (n - a.n_old) + (idx - a.n_old)];
     } else {
       s = a.sdf_old[b * n + j];
@@ -188,7 +190,7 @@ __global__ void gather_sdf_kernel(const float* __restrict__ sdf_old, const float
   const int nt = n + n_new;
   if (i >= B * nt) return;
   const int64_t b = i / nt;
-  const int idx = index[i];
+  const int idx = min(max(index[i], 0), nt - 1);   // (see up_sample_kernel: NaN depths can leave index slots unwritten)
   out[i] = idx < n ? sdf_old[b * n + idx] : sdf_new[b * n_new + (idx - n)];
 }
 

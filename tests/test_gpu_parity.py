@@ -548,3 +548,23 @@ def test_wrong_device_is_rejected(R):
     o0 = ren.render_rnb(*(b[k].to(_dev()) for k in ("rays_o", "rays_d", "near", "far", "lights_dir")), t_rand=b["t_rand"].to(_dev()))
     o1 = ren1.render_rnb(b1["rays_o"], b1["rays_d"], b1["near"], b1["far"], b1["lights_dir"], t_rand=b1["t_rand"])
     torch.testing.assert_close(o0["color_fine"].cpu(), o1["color_fine"].cpu(), rtol=1e-5, atol=1e-6)
+
+
+def test_nan_parameters_give_nan_outputs_not_a_fault(R):
+    """A diverged model (NaN weights) must come back as NaNs, as it does in the reference: with NaN depths every
+    comparison of the importance-sampling merge is false, slots of its index buffer stay unwritten, and a stray index must
+    not become a stray address (sampling.hip clamps what it gathers by)."""
+    mc = O.ModelConf()
+    torch.manual_seed(4)
+    p = O.init_params(mc)
+    sdf, devn, col, ren = R.build_from_named_params(mc, p, _dev())
+    with torch.no_grad():
+        sdf.lin3.bias[7] = float("nan")
+    b = {k: v.to(_dev()) for k, v in O.synthetic_batch(64, seed=8, step=3).items()}
+    out = ren.render_rnb(b["rays_o"], b["rays_d"], b["near"], b["far"], b["lights_dir"], cos_anneal_ratio=1.0,
+                         t_rand=b["t_rand"])
+    loss = O.rnb_loss(out, b["true_rgb"], b["mask"])[0]
+    loss.backward()
+    torch.cuda.synchronize()
+    assert not torch.isfinite(out["color_fine"]).all()
+    assert not torch.isfinite(loss)
