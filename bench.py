@@ -449,7 +449,8 @@ def run_mesh(args):
     world, rank, dev, backend, rehearsal = init_distributed(args)
     import rnb_neus_fork_amd as R
     lib = R.native.load()
-    sdf, devnet, col, ren = build_model(R, dev, 128, args.dtype, False, x3=args.x3, f32_mfma=args.f32_mfma)
+    sdf, devnet, col, ren = build_model(R, dev, 128, args.dtype, False, x3=args.x3, f32_mfma=args.f32_mfma, fwd_ti=args.fwd_ti,
+                                        fwd_nw=args.fwd_nw)
     if world > 1:
         from rnb_neus_fork_amd import parallel as P
         P.broadcast_parameters([sdf, devnet, col])

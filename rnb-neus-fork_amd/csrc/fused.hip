@@ -9,6 +9,13 @@
 //                          models/embedder.py:40-46, models/fields.py:82-104
 #include "fused_common.hip.h"
 
+// A/B switch (compile time): scalar instead of packed fp32 math in the x3 forward epilogue.  Measured on one box, two
+// runs each: packed 3.694 / 3.684 ms per step, scalar 3.71 / 3.78 — the epilogue runs beside ANOTHER wave's MFMAs, where
+// the packed forms keep their halved issue count.
+#ifndef RNB_X3_SCALAR_EPI
+#define RNB_X3_SCALAR_EPI 0
+#endif
+
 namespace rnb {
 
 struct FusedFwdArgs {
@@ -145,8 +152,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_forward_kernel
           const int rowc = ti * 32 + (r & 3) + 8 * (r >> 2);   // compile-time part of the row
           const int row = rowc + 4 * h;
           vf2 a, D;
-          if constexpr (SAVE) softplus_aD(vf2{acc[ti][tj][r] + bc, acc[ti][tj][r + 1] + bc}, a, D);
-          else a = softplus_a(vf2{acc[ti][tj][r] + bc, acc[ti][tj][r + 1] + bc});
+          if constexpr (SAVE) softplus_aD_sel<X3 && RNB_X3_SCALAR_EPI>(vf2{acc[ti][tj][r] + bc, acc[ti][tj][r + 1] + bc}, a, D);
+          else a = softplus_a_sel<X3 && RNB_X3_SCALAR_EPI>(vf2{acc[ti][tj][r] + bc, acc[ti][tj][r + 1] + bc});
           if (!tile_full && col >= n_real) {   // only the tile straddling the skip connection's PE columns
             const bool pe_col = pe_tail && col < n_real + g.pe;
             a = vf2{pe_col ? E[row * FEP + (col - n_real)] : 0.f, pe_col ? E[(row + 1) * FEP + (col - n_real)] : 0.f};
@@ -214,6 +221,232 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_forward_kernel
           }
         }
       }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// x3 forward with the activations PRE-SPLIT in LDS ("p3"; A/B variant: fwd_ti = 2, fwd_nw = 8)
+// ---------------------------------------------------------------------------------------------------------------
+// fused_forward_kernel<.., X3> keeps the tile fp32 in LDS and lets each of the four waves of a workgroup split the A rows
+// it reads: 4 x redundant, and the term that saturates the vector-issue port.  Here the producer of an
+// activation splits it once and the tile lives in LDS as three bf16 planes [64][264] (6 bytes per element: ONE 8-wave
+// workgroup per CU, each wave 64 rows x 32 columns), so the matrix loop is fragment reads + MFMAs only.
+constexpr int PP = 264;            // plane pitch in bf16 elements (528 B = 132 dwords = 4 mod 64: conflict-free b128 reads)
+constexpr int PPLANE = 64 * PP;    // elements of one plane
+
+// rows r and r + 1 of one column (what an accumulator register pair holds): split the pair, six 2-byte stores
+__device__ inline void p3_put2(x3raw* __restrict__ P, int idx, float a, float b) {
+  unsigned uh = x3_pack2(a, b);
+  asm("" : "+v"(uh));
+  const float ra = a - __builtin_bit_cast(float, uh << 16);
+  const float rb = __builtin_fmaf(__builtin_bit_cast(float, uh & 0xffff0000u), -1.f, b);
+  unsigned um = x3_pack2(ra, rb);
+  asm("" : "+v"(um));
+  const float sa = ra - __builtin_bit_cast(float, um << 16);
+  const float sb = __builtin_fmaf(__builtin_bit_cast(float, um & 0xffff0000u), -1.f, rb);
+  const unsigned ul = x3_pack2(sa, sb);
+  P[idx] = (x3raw)uh;               P[idx + PP] = (x3raw)(uh >> 16);
+  P[idx + PPLANE] = (x3raw)um;      P[idx + PPLANE + PP] = (x3raw)(um >> 16);
+  P[idx + 2 * PPLANE] = (x3raw)ul;  P[idx + 2 * PPLANE + PP] = (x3raw)(ul >> 16);
+}
+__device__ inline void p3_put(x3raw* __restrict__ P, int idx, float a) {
+  const unsigned uh = x3_pack2(a, 0.f);
+  const float ra = a - __builtin_bit_cast(float, uh << 16);
+  const unsigned um = x3_pack2(ra, 0.f);
+  const float sa = ra - __builtin_bit_cast(float, um << 16);
+  P[idx] = (x3raw)uh;
+  P[idx + PPLANE] = (x3raw)um;
+  P[idx + 2 * PPLANE] = (x3raw)x3_pack2(sa, 0.f);
+}
+__device__ inline float p3_get(const x3raw* __restrict__ P, int idx) {
+  return (__builtin_bit_cast(float, (unsigned)P[idx] << 16) + __builtin_bit_cast(float, (unsigned)P[idx + PPLANE] << 16)) +
+         __builtin_bit_cast(float, (unsigned)P[idx + 2 * PPLANE] << 16);
+}
+// acc = X W^T for one wave: rows 0..63 of the plane tile, columns n0 .. n0 + 32; fragments one 16-k step ahead
+__device__ inline void layer_mma_p3(const x3raw* __restrict__ P, const x3raw* __restrict__ W3, int K, int n0, int lane,
+                                    v16f (&acc)[2][1]) {
+  const int i = lane & 31, h = lane >> 5;
+  const x3raw* ap = P + i * PP + h * 8;
+  const int nks = K >> 4;   // even
+  vu4x a0[2][3], a1[2][3], b0[1][3], b1[1][3];
+  auto read_a = [&](int ks, vu4x (&a)[2][3]) {
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) a[ti][pl] = *reinterpret_cast<const vu4x*>(ap + ti * 32 * PP + pl * PPLANE + ks * 16);
+  };
+  x3_load_b<1>(W3, nks, n0, 0, lane, b0);
+  read_a(0, a0);
+  x3_load_b<1>(W3, nks, n0, 1, lane, b1);
+  read_a(1, a1);
+  __builtin_amdgcn_sched_barrier(0);
+  x3_mfma<2, 1, true>(a0, b0, acc);
+  __builtin_amdgcn_sched_barrier(0);
+  const int last = nks - 1;
+  for (int ks = 1; ks + 1 < nks; ks += 2) {
+    x3_load_b<1>(W3, nks, n0, ks + 1, lane, b0);
+    read_a(ks + 1, a0);
+    __builtin_amdgcn_sched_barrier(0);
+    x3_mfma<2, 1, false>(a1, b1, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    x3_load_b<1>(W3, nks, n0, min(ks + 2, last), lane, b1);
+    read_a(min(ks + 2, last), a1);
+    __builtin_amdgcn_sched_barrier(0);
+    x3_mfma<2, 1, false>(a0, b0, acc);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  x3_mfma<2, 1, false>(a1, b1, acc);
+}
+
+template <bool SAVE>
+__global__ __launch_bounds__(512, 1) void fused_forward_p3_kernel(FusedFwdArgs g) {
+  constexpr int FT = 64, NT = 512, NW = 8;
+  __shared__ __attribute__((aligned(16))) x3raw P[3 * PPLANE];   // 101,376 B
+  __shared__ float E[FT * FEP];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = wave_id();
+  const int64_t row0 = (int64_t)blockIdx.x * FT;
+  const int n0 = wave * 32;
+
+  // ---- positional encoding of the tile ---------------------------------------------------------------------
+  {
+    constexpr int PARTS = NT / FT;
+    const int p = tid % FT, part = tid / FT;
+    const int64_t row = row0 + p;
+    float x[3] = {0.f, 0.f, 0.f};
+    if (row < g.M) {
+      if (g.grid.on) {
+        const int res = g.grid.res;
+        int64_t r = row;
+        const int iz = (int)(r % res);
+        r /= res;
+        const int iy = (int)(r % res);
+        const int ix = (int)(r / res) + g.grid.x_begin;
+        x[0] = linspace_at(g.grid.bmin[0], g.grid.bmax[0], res, ix) * g.scale;
+        x[1] = linspace_at(g.grid.bmin[1], g.grid.bmax[1], res, iy) * g.scale;
+        x[2] = linspace_at(g.grid.bmin[2], g.grid.bmax[2], res, iz) * g.scale;
+      } else {
+        x[0] = g.pts[row * 3] * g.scale;
+        x[1] = g.pts[row * 3 + 1] * g.scale;
+        x[2] = g.pts[row * 3 + 2] * g.scale;
+      }
+    }
+    x3raw* xr = P + p * PP;
+    float* er = E + p * FEP;
+    if (part == 0) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { p3_put(xr, d, x[d]); er[d] = x[d]; }
+      for (int c = g.pe; c < g.Ep; ++c) { xr[c] = 0; xr[c + PPLANE] = 0; xr[c + 2 * PPLANE] = 0; }
+      if (SAVE) {
+        g.x4[row * 4] = x[0]; g.x4[row * 4 + 1] = x[1]; g.x4[row * 4 + 2] = x[2]; g.x4[row * 4 + 3] = 0.f;
+      }
+    }
+    for (int k = part; k < g.multires; k += PARTS) {
+      const float f = (float)(1 << k);
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        float sn, co;
+        sincosf(x[d] * f, &sn, &co);
+        const int c = 3 + 6 * k + d;
+        p3_put(xr, c, sn); p3_put(xr, c + 3, co);
+        er[c] = sn; er[c + 3] = co;
+      }
+    }
+  }
+  __syncthreads();
+  if (SAVE) {   // e (fp32): the PE columns live in E, the padding is zero
+    for (int idx = tid; idx < FT * g.Ep; idx += NT) {
+      const int r = idx / g.Ep, c = idx - r * g.Ep;
+      g.e[(row0 + r) * g.Ep + c] = c < g.pe ? E[r * FEP + c] : 0.f;
+    }
+  }
+
+  const int h = lane >> 5, cl = lane & 31;
+  v16f acc[2][1];
+  for (int l = 0; l < g.nh; ++l) {
+    layer_mma_p3(P, g.w3 + 3 * g.w_off[l], g.Kp[l], n0, lane, acc);
+    lds_barrier();   // every wave has finished reading the input activations (the tile is updated in place)
+    const float* bias = g.packed + g.b_off[l];
+    const BufRsrc ra = tile_rsrc(SAVE ? g.a[l] + (size_t)row0 * FH : nullptr, FT * FH * 4);
+    const BufRsrc rD = tile_rsrc(SAVE ? g.D[l] + (size_t)row0 * FH : nullptr, FT * FH * 4);
+    const BufRsrc rg = tile_rsrc((SAVE && g.gz_last) ? g.gz_last + (size_t)row0 * FH : nullptr, FT * FH * 4);
+    const int n_real = g.n_real[l];
+    const bool pe_tail = (l + 1 == g.skip);
+    const bool last = (l + 1 == g.nh);
+    const int col = n0 + cl;
+    const float bc = bias[col];
+    const float ws = (SAVE && last && g.gz_last) ? g.packed[g.wsdf_off + col] : 0.f;
+    const bool tile_full = n0 + 32 <= n_real;   // wave-uniform
+    const unsigned voff = (unsigned)(4 * h * FH + col) * 4u;
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) {
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const int rowc = ti * 32 + (r & 3) + 8 * (r >> 2);
+        const int row = rowc + 4 * h;
+        vf2 a, D;
+        if constexpr (SAVE) softplus_aD(vf2{acc[ti][0][r] + bc, acc[ti][0][r + 1] + bc}, a, D);
+        else a = softplus_a(vf2{acc[ti][0][r] + bc, acc[ti][0][r + 1] + bc});
+        if (!tile_full && col >= n_real) {
+          const bool pe_col = pe_tail && col < n_real + g.pe;
+          a = vf2{pe_col ? E[row * FEP + (col - n_real)] : 0.f, pe_col ? E[(row + 1) * FEP + (col - n_real)] : 0.f};
+          D = vf2{0.f, 0.f};
+        }
+        p3_put2(P, row * PP + col, a.x, a.y);
+        if (SAVE) {
+          bstore(ra, voff, rowc * FH * 4, a.x);
+          bstore(ra, voff, (rowc + 1) * FH * 4, a.y);
+          bstore(rD, voff, rowc * FH * 4, D.x);
+          bstore(rD, voff, (rowc + 1) * FH * 4, D.y);
+          if (last && g.gz_last) {
+            bstore(rg, voff, rowc * FH * 4, ws * D.x);
+            bstore(rg, voff, (rowc + 1) * FH * 4, ws * D.y);
+          }
+        }
+      }
+    }
+    lds_barrier();   // the new activations are visible to every wave
+  }
+
+  // ---- sdf head -----------------------------------------------------------------------------------------------
+  {
+    const float* ws = g.packed + g.wsdf_off;
+    float w[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) w[u] = ws[lane + 64 * u];
+    const float bs = g.packed[g.bsdf_off];
+    for (int rr = 0; rr < FT / NW; ++rr) {
+      const int row = wave * (FT / NW) + rr;
+      float s = 0.f;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s = fmaf(p3_get(P, row * PP + lane + 64 * u), w[u], s);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+      if (lane == 0) {
+        const float v = (s + bs) / g.scale;
+        if (!g.grid.on) g.sdf[row0 + row] = v;
+        else if (row0 + row < g.M) g.sdf[row0 + row] = v * g.grid.out_scale;
+      }
+    }
+  }
+  // ---- feature head ---------------------------------------------------------------------------------------------
+  if (g.with_feat) {
+    layer_mma_p3(P, g.w3 + 3 * g.wf_off, FH, n0, lane, acc);
+    const float* bias = g.packed + g.bf_off;
+    const BufRsrc rc = tile_rsrc(g.cin + (size_t)row0 * g.Cinp, FT * g.Cinp * 4);
+    const unsigned rowb = (unsigned)g.Cinp * 4u;
+    const int col = n0 + cl;
+    if (col < g.F) {
+      const float bc = bias[col];
+      const unsigned voff = (unsigned)(4 * h) * rowb + (unsigned)col * 4u;
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rowc = ti * 32 + (r & 3) + 8 * (r >> 2);
+          bstore(rc, voff, rowc * rowb, acc[ti][0][r] + bc);
+        }
     }
   }
 }
@@ -323,6 +556,13 @@ int fused_forward(const Layout& L, const float* packed, const float* pts, int64_
   const bool small = force_ti ? (force_ti == 1) : (pb.Mp / 64 < 512);
   const int force_nw = L.knob(RNB_VARIANT_FWD_NW_SHIFT);   // tuning knob: 1 = 4 waves, 2 = 8 waves (small batches)
   const bool x3 = is_x3(L);
+  if (x3 && force_ti == 2 && force_nw == 2) {   // A/B: activations pre-split in LDS, one 8-wave workgroup per CU
+    const unsigned blocks = (unsigned)(pb.Mp / 64);
+    if (save) hipLaunchKernelGGL(fused_forward_p3_kernel<true>, dim3(blocks), dim3(512), 0, s, g);
+    else hipLaunchKernelGGL(fused_forward_p3_kernel<false>, dim3(blocks), dim3(512), 0, s, g);
+    RNB_CHECK_LAUNCH();
+    return RNB_OK;
+  }
   if (small) {
     const unsigned blocks = (unsigned)(pb.Mp / 32);
     const bool wide = force_nw ? (force_nw == 2) : (blocks <= 256);   // at most one workgroup per CU

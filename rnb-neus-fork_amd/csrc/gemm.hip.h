@@ -1147,6 +1147,39 @@ __device__ inline vf2 softplus_a(vf2 z) {
   const vf2 zp = {fmaxf(z.x, 0.f), fmaxf(z.y, 0.f)};
   return __builtin_elementwise_fma(l1p, vf2{0.01f, 0.01f}, zp);
 }
+// The same two functions on scalars, for the x3 kernels: there the epilogue of one wave runs beside the other wave's bf16
+// MFMAs, where packed fp32 instructions are an anti-lever (MI355X_MICROARCH.md: a v_pk_* costs ~13 cycles more than the
+// two scalar instructions it replaces).  Bit-identical results (same operations, element-wise).
+__device__ inline float softplus_a(float z) {
+  constexpr float L2E = 1.44269504088896341f, LN2 = 0.693147180559945309f;
+  const float t = z * 100.f;
+  const float nt = -fabsf(t);
+  const float p = nt * L2E;
+  const float q = __builtin_fmaf(nt, L2E, -p);
+  const float w0 = __builtin_amdgcn_exp2f(p);
+  const float w = __builtin_fmaf(w0, q * LN2, w0);
+  const float u = w + 1.f;
+  const float lg = __builtin_amdgcn_logf(u);
+  const float d = w - (u - 1.f);
+  const float l1p = __builtin_fmaf(lg, LN2, __builtin_fmaf(-d, w, d));
+  return __builtin_fmaf(l1p, 0.01f, fmaxf(z, 0.f));
+}
+template <bool SCALAR>
+__device__ inline vf2 softplus_a_sel(vf2 z) {
+  if constexpr (SCALAR) return vf2{softplus_a(z.x), softplus_a(z.y)};
+  else return softplus_a(z);
+}
+template <bool SCALAR>
+__device__ inline void softplus_aD_sel(vf2 z, vf2& a, vf2& D) {
+  if constexpr (SCALAR) {
+    float a0, a1, D0, D1;
+    softplus_aD(z.x, a0, D0);
+    softplus_aD(z.y, a1, D1);
+    a = vf2{a0, a1};
+    D = vf2{D0, D1};
+  }
+  else softplus_aD(z, a, D);
+}
 // D = d softplus / dz = sigmoid(100 z) expressed through a = softplus(z):  D = 1 - exp(-100 a)
 // (exactly 1 above the threshold, where a == z); E = 1 - D, and softplus'' = 100 D E.
 __device__ inline void softplus_DE(float a, float& D, float& E) {

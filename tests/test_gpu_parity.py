@@ -464,7 +464,7 @@ def test_fused_and_generic_paths_agree(R):
                     ("bwd_ti1", dict(bwd_ti=1, bwd_nw=4)), ("bwd_ti2", dict(bwd_ti=2, bwd_nw=4)),
                     ("bwd_ti2_nw8", dict(bwd_ti=2, bwd_nw=8)), ("fwd_ti1", dict(fwd_ti=1, fwd_nw=4)),
                     ("deterministic", dict(deterministic=True)), ("x3", dict(x3=True)),
-                    ("f32_mfma", dict(f32_mfma=True)), ("f32_mfma_ti2", dict(f32_mfma=True, bwd_ti=2, bwd_nw=4)),
+                    ("p3_forward", dict(fwd_ti=2, fwd_nw=8)), ("f32_mfma", dict(f32_mfma=True)), ("f32_mfma_ti2", dict(f32_mfma=True, bwd_ti=2, bwd_nw=4)),
                     ("x3_ti1_nw4", dict(x3=True, bwd_ti=1, bwd_nw=4, fwd_ti=1, fwd_nw=4)),
                     ("x3_ti2_nw8", dict(x3=True, bwd_ti=2, bwd_nw=8, fwd_ti=2))):
         ren.set_variant(**kw)

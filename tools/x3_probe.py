@@ -19,10 +19,10 @@ p64 = {k: v.double() for k, v in p.items()}
 with torch.no_grad():
     ref = -O.sdf_only(p64, mc.sdf, pts).reshape(res, res, res)
 out = {}
-for tag, kw in (("f32", {}), ("x3", dict(x3=True))):
+for tag, kw in (("f32", dict(f32_mfma=True)), ("x3", dict(x3=True)), ("p3", dict(x3=True, fwd_ti=2, fwd_nw=8))):
     ren.set_variant(**kw)
     u = ren.extract_fields(bmin, bmax, res)
     out[tag] = torch.as_tensor(u).double()
     e = (out[tag] - ref).abs()
     print(f"{tag}: max abs err vs fp64 {e.max():.3e}  rms {e.pow(2).mean().sqrt():.3e}   (|sdf| max {ref.abs().max():.3f})")
-print("x3 vs f32 max abs", float((out["x3"] - out["f32"]).abs().max()))
+print("x3 vs f32 max abs", float((out["x3"] - out["f32"]).abs().max()), " p3 vs x3 max abs", float((out["p3"] - out["x3"]).abs().max()))
