@@ -233,9 +233,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_forward_kernel
 // activation splits it once and the tile lives in LDS as three bf16 planes [64][264] (6 bytes per element: ONE 8-wave
 // workgroup per CU, each wave 64 rows x 32 columns), so the matrix loop is fragment reads + MFMAs only.
 constexpr int PP = 264;            // plane pitch in bf16 elements (528 B = 132 dwords = 4 mod 64: conflict-free b128 reads)
-constexpr int PPLANE = 64 * PP;    // elements of one plane
 
 // rows r and r + 1 of one column (what an accumulator register pair holds): split the pair, six 2-byte stores
+template <int PPLANE>
 __device__ inline void p3_put2(x3raw* __restrict__ P, int idx, float a, float b) {
   unsigned uh = x3_pack2(a, b);
   asm("" : "+v"(uh));
@@ -250,6 +250,7 @@ __device__ inline void p3_put2(x3raw* __restrict__ P, int idx, float a, float b)
   P[idx + PPLANE] = (x3raw)um;      P[idx + PPLANE + PP] = (x3raw)(um >> 16);
   P[idx + 2 * PPLANE] = (x3raw)ul;  P[idx + 2 * PPLANE + PP] = (x3raw)(ul >> 16);
 }
+template <int PPLANE>
 __device__ inline void p3_put(x3raw* __restrict__ P, int idx, float a) {
   const unsigned uh = x3_pack2(a, 0.f);
   const float ra = a - __builtin_bit_cast(float, uh << 16);
@@ -259,50 +260,55 @@ __device__ inline void p3_put(x3raw* __restrict__ P, int idx, float a) {
   P[idx + PPLANE] = (x3raw)um;
   P[idx + 2 * PPLANE] = (x3raw)x3_pack2(sa, 0.f);
 }
+template <int PPLANE>
 __device__ inline float p3_get(const x3raw* __restrict__ P, int idx) {
   return (__builtin_bit_cast(float, (unsigned)P[idx] << 16) + __builtin_bit_cast(float, (unsigned)P[idx + PPLANE] << 16)) +
          __builtin_bit_cast(float, (unsigned)P[idx + 2 * PPLANE] << 16);
 }
-// acc = X W^T for one wave: rows 0..63 of the plane tile, columns n0 .. n0 + 32; fragments one 16-k step ahead
+// acc = X W^T for one wave: rows 0 .. 32 TI of the plane tile (plane stride PL elements), columns n0 .. n0 + 32;
+// fragments one 16-k step ahead
+template <int TI>
 __device__ inline void layer_mma_p3(const x3raw* __restrict__ P, const x3raw* __restrict__ W3, int K, int n0, int lane,
-                                    v16f (&acc)[2][1]) {
+                                    v16f (&acc)[TI][1]) {
+  constexpr int PL = 32 * TI * PP;
   const int i = lane & 31, h = lane >> 5;
   const x3raw* ap = P + i * PP + h * 8;
   const int nks = K >> 4;   // even
-  vu4x a0[2][3], a1[2][3], b0[1][3], b1[1][3];
-  auto read_a = [&](int ks, vu4x (&a)[2][3]) {
+  vu4x a0[TI][3], a1[TI][3], b0[1][3], b1[1][3];
+  auto read_a = [&](int ks, vu4x (&a)[TI][3]) {
 #pragma unroll
-    for (int ti = 0; ti < 2; ++ti)
+    for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) a[ti][pl] = *reinterpret_cast<const vu4x*>(ap + ti * 32 * PP + pl * PPLANE + ks * 16);
+      for (int pl = 0; pl < 3; ++pl) a[ti][pl] = *reinterpret_cast<const vu4x*>(ap + ti * 32 * PP + pl * PL + ks * 16);
   };
   x3_load_b<1>(W3, nks, n0, 0, lane, b0);
   read_a(0, a0);
   x3_load_b<1>(W3, nks, n0, 1, lane, b1);
   read_a(1, a1);
   __builtin_amdgcn_sched_barrier(0);
-  x3_mfma<2, 1, true>(a0, b0, acc);
+  x3_mfma<TI, 1, true>(a0, b0, acc);
   __builtin_amdgcn_sched_barrier(0);
   const int last = nks - 1;
   for (int ks = 1; ks + 1 < nks; ks += 2) {
     x3_load_b<1>(W3, nks, n0, ks + 1, lane, b0);
     read_a(ks + 1, a0);
     __builtin_amdgcn_sched_barrier(0);
-    x3_mfma<2, 1, false>(a1, b1, acc);
+    x3_mfma<TI, 1, false>(a1, b1, acc);
     __builtin_amdgcn_sched_barrier(0);
     x3_load_b<1>(W3, nks, n0, min(ks + 2, last), lane, b1);
     read_a(min(ks + 2, last), a1);
     __builtin_amdgcn_sched_barrier(0);
-    x3_mfma<2, 1, false>(a0, b0, acc);
+    x3_mfma<TI, 1, false>(a0, b0, acc);
     __builtin_amdgcn_sched_barrier(0);
   }
-  x3_mfma<2, 1, false>(a1, b1, acc);
+  x3_mfma<TI, 1, false>(a1, b1, acc);
 }
 
-template <bool SAVE>
-__global__ __launch_bounds__(512, 1) void fused_forward_p3_kernel(FusedFwdArgs g) {
-  constexpr int FT = 64, NT = 512, NW = 8;
-  __shared__ __attribute__((aligned(16))) x3raw P[3 * PPLANE];   // 101,376 B
+template <bool SAVE, int TI>
+__global__ __launch_bounds__(512, TI == 1 ? 2 : 1) void fused_forward_p3_kernel(FusedFwdArgs g) {
+  constexpr int FT = 32 * TI, NT = 512, NW = 8;
+  constexpr int PPLANE = FT * PP;    // elements of one plane
+  __shared__ __attribute__((aligned(16))) x3raw P[3 * PPLANE];   // 101,376 B (TI = 2) / 50,688 B (TI = 1)
   __shared__ float E[FT * FEP];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = wave_id();
@@ -336,7 +342,7 @@ __global__ __launch_bounds__(512, 1) void fused_forward_p3_kernel(FusedFwdArgs g
     float* er = E + p * FEP;
     if (part == 0) {
 #pragma unroll
-      for (int d = 0; d < 3; ++d) { p3_put(xr, d, x[d]); er[d] = x[d]; }
+      for (int d = 0; d < 3; ++d) { p3_put<PPLANE>(xr, d, x[d]); er[d] = x[d]; }
       for (int c = g.pe; c < g.Ep; ++c) { xr[c] = 0; xr[c + PPLANE] = 0; xr[c + 2 * PPLANE] = 0; }
       if (SAVE) {
         g.x4[row * 4] = x[0]; g.x4[row * 4 + 1] = x[1]; g.x4[row * 4 + 2] = x[2]; g.x4[row * 4 + 3] = 0.f;
@@ -349,7 +355,7 @@ __global__ __launch_bounds__(512, 1) void fused_forward_p3_kernel(FusedFwdArgs g
         float sn, co;
         sincosf(x[d] * f, &sn, &co);
         const int c = 3 + 6 * k + d;
-        p3_put(xr, c, sn); p3_put(xr, c + 3, co);
+        p3_put<PPLANE>(xr, c, sn); p3_put<PPLANE>(xr, c + 3, co);
         er[c] = sn; er[c + 3] = co;
       }
     }
@@ -363,9 +369,9 @@ __global__ __launch_bounds__(512, 1) void fused_forward_p3_kernel(FusedFwdArgs g
   }
 
   const int h = lane >> 5, cl = lane & 31;
-  v16f acc[2][1];
+  v16f acc[TI][1];
   for (int l = 0; l < g.nh; ++l) {
-    layer_mma_p3(P, g.w3 + 3 * g.w_off[l], g.Kp[l], n0, lane, acc);
+    layer_mma_p3<TI>(P, g.w3 + 3 * g.w_off[l], g.Kp[l], n0, lane, acc);
     lds_barrier();   // every wave has finished reading the input activations (the tile is updated in place)
     const float* bias = g.packed + g.b_off[l];
     const BufRsrc ra = tile_rsrc(SAVE ? g.a[l] + (size_t)row0 * FH : nullptr, FT * FH * 4);
@@ -380,7 +386,7 @@ __global__ __launch_bounds__(512, 1) void fused_forward_p3_kernel(FusedFwdArgs g
     const bool tile_full = n0 + 32 <= n_real;   // wave-uniform
     const unsigned voff = (unsigned)(4 * h * FH + col) * 4u;
 #pragma unroll
-    for (int ti = 0; ti < 2; ++ti) {
+    for (int ti = 0; ti < TI; ++ti) {
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
         const int rowc = ti * 32 + (r & 3) + 8 * (r >> 2);
@@ -393,7 +399,7 @@ __global__ __launch_bounds__(512, 1) void fused_forward_p3_kernel(FusedFwdArgs g
           a = vf2{pe_col ? E[row * FEP + (col - n_real)] : 0.f, pe_col ? E[(row + 1) * FEP + (col - n_real)] : 0.f};
           D = vf2{0.f, 0.f};
         }
-        p3_put2(P, row * PP + col, a.x, a.y);
+        p3_put2<PPLANE>(P, row * PP + col, a.x, a.y);
         if (SAVE) {
           bstore(ra, voff, rowc * FH * 4, a.x);
           bstore(ra, voff, (rowc + 1) * FH * 4, a.y);
@@ -420,7 +426,7 @@ __global__ __launch_bounds__(512, 1) void fused_forward_p3_kernel(FusedFwdArgs g
       const int row = wave * (FT / NW) + rr;
       float s = 0.f;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) s = fmaf(p3_get(P, row * PP + lane + 64 * u), w[u], s);
+      for (int u = 0; u < 4; ++u) s = fmaf(p3_get<PPLANE>(P, row * PP + lane + 64 * u), w[u], s);
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
       if (lane == 0) {
@@ -432,7 +438,7 @@ __global__ __launch_bounds__(512, 1) void fused_forward_p3_kernel(FusedFwdArgs g
   }
   // ---- feature head ---------------------------------------------------------------------------------------------
   if (g.with_feat) {
-    layer_mma_p3(P, g.w3 + 3 * g.wf_off, FH, n0, lane, acc);
+    layer_mma_p3<TI>(P, g.w3 + 3 * g.wf_off, FH, n0, lane, acc);
     const float* bias = g.packed + g.bf_off;
     const BufRsrc rc = tile_rsrc(g.cin + (size_t)row0 * g.Cinp, FT * g.Cinp * 4);
     const unsigned rowb = (unsigned)g.Cinp * 4u;
@@ -441,7 +447,7 @@ __global__ __launch_bounds__(512, 1) void fused_forward_p3_kernel(FusedFwdArgs g
       const float bc = bias[col];
       const unsigned voff = (unsigned)(4 * h) * rowb + (unsigned)col * 4u;
 #pragma unroll
-      for (int ti = 0; ti < 2; ++ti)
+      for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int rowc = ti * 32 + (r & 3) + 8 * (r >> 2);
@@ -558,11 +564,14 @@ int fused_forward(const Layout& L, const float* packed, const float* pts, int64_
   const bool x3 = is_x3(L);
   if (x3 && force_ti == 2 && force_nw == 2) {   // A/B: activations pre-split in LDS, one 8-wave workgroup per CU
     const unsigned blocks = (unsigned)(pb.Mp / 64);
-    if (save) hipLaunchKernelGGL(fused_forward_p3_kernel<true>, dim3(blocks), dim3(512), 0, s, g);
-    else hipLaunchKernelGGL(fused_forward_p3_kernel<false>, dim3(blocks), dim3(512), 0, s, g);
+    if (save) hipLaunchKernelGGL((fused_forward_p3_kernel<true, 2>), dim3(blocks), dim3(512), 0, s, g);
+    else hipLaunchKernelGGL((fused_forward_p3_kernel<false, 2>), dim3(blocks), dim3(512), 0, s, g);
     RNB_CHECK_LAUNCH();
     return RNB_OK;
   }
+  // (Measured and not kept: the 32-point form of the pre-split kernel for the sampling passes, and weight fragments four
+  // steps ahead in the small-batch kernel: both 60 us per 8,192-point pass like the default — 256 workgroups each stream the
+  // whole 3.5 MB of weight planes from L2, 0.9 GB per pass at the ~16 TB/s the L2s deliver for shared rows.)
   if (small) {
     const unsigned blocks = (unsigned)(pb.Mp / 32);
     const bool wide = force_nw ? (force_nw == 2) : (blocks <= 256);   // at most one workgroup per CU
