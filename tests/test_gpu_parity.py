@@ -568,3 +568,26 @@ def test_nan_parameters_give_nan_outputs_not_a_fault(R):
     torch.cuda.synchronize()
     assert not torch.isfinite(out["color_fine"]).all()
     assert not torch.isfinite(loss)
+
+
+def test_x3_weight_mirror_is_an_exact_three_way_split(R):
+    """The default arithmetic multiplies fp32 operands as hi + mid + lo bf16 terms.  The mirror that
+    rnb_weightnorm_fwd writes behind the fp32 weights must hold, in MFMA-fragment order, three round-to-nearest bf16 planes
+    whose sum is the fp32 weight EXACTLY (8 + 8 + 8 mantissa bits) — checked on the first matrix (layer 0: 256 x 64, at
+    float offset 0; fragment (32 rows, 16 k) = planes hi, mid, lo of 64 lanes x 8 values, lane (c, h) = W[32 nt + c][16 ks + 8 h ..])."""
+    mc = O.ModelConf()
+    torch.manual_seed(9)
+    p = O.init_params(mc)
+    sdf, devn, col, ren = R.build_from_named_params(mc, p, _dev())
+    packed = ren._pack(True)
+    total = packed.numel() * 2 // 5                      # fp32 part: total + 1.5 total floats in all
+    assert packed.numel() == total + total // 2 * 3
+    W0 = packed[:256 * 64].reshape(256, 64).cpu()
+    mirror = packed[total:].view(torch.int16)[:3 * 256 * 64].cpu().to(torch.int32) & 0xFFFF
+    planes = (mirror << 16).view(torch.float32).reshape(8, 4, 3, 2, 32, 8)   # nt, ks, plane, h, c, j
+    rec = planes.permute(2, 0, 4, 1, 3, 5).reshape(3, 256, 64)               # plane, row = 32 nt + c, k = 16 ks + 8 h + j
+    hi, mid, lo = rec[0], rec[1], rec[2]
+    assert torch.equal((hi + mid) + lo, W0), "hi + mid + lo must reproduce the fp32 weight bit for bit"
+    assert torch.equal(hi, W0.to(torch.bfloat16).to(torch.float32)), "hi = bf16(w), round to nearest even"
+    assert torch.equal(mid, (W0 - hi).to(torch.bfloat16).to(torch.float32))
+    assert float((lo.abs() - W0.abs() * 2.0 ** -17).clamp_min(0).max()) == 0.0
