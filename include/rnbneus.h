@@ -136,7 +136,11 @@ const char* rnb_last_error_string(void);
  * "packed" buffer (tile-padded, skip-layer 1/sqrt(2) folded in, layout private to the library) that
  * all compute entry points consume; the backward maps a gradient buffer of the same layout back to
  * the leaves. `color`/`color_grads` may be NULL (no_albedo training, exp_runner.py:111-112); `sdf` may be
- * NULL when only the albedo network is evaluated (rnb_color_forward). */
+ * NULL when only the albedo network is evaluated (rnb_color_forward).
+ * rnb_packed_floats is the size of `packed` in floats: the fp32 weights plus, behind them, the MFMA-operand mirror of
+ * the variant in use (written by rnb_weightnorm_fwd: hi / mid / lo bf16 planes for the default x3 arithmetic, a bf16
+ * copy for RNB_VARIANT_BF16).  A gradient buffer (`packed_grad`) needs the same allocation size; only its fp32 part is
+ * written and read. */
 int rnb_packed_floats(const rnb_model_desc* desc, int64_t* n_floats);
 int rnb_weightnorm_fwd(const rnb_model_desc* desc, const rnb_mlp_params* sdf, const rnb_mlp_params* color,
                        float* packed, rnb_stream_t stream);
