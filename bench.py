@@ -52,6 +52,25 @@ def measured_traffic(name, n_gpus, rays, samples):
     return None
 
 
+def kernel_classes(lib, steps, peak_tflops):
+    """Per kernel class of the last rnb_profile_collect (HIP events on the launch stream): ms per step, launches per step,
+    algorithmic TFLOP/s and its fraction of `peak_tflops`; sorted by time."""
+    need = lib.rnb_profile_report(None, 0)
+    buf = C.create_string_buffer(int(need) + 16)
+    lib.rnb_profile_report(buf, len(buf))
+    out = []
+    for ln in buf.value.decode().splitlines():
+        tag, ms, n, fl = ln.rsplit(" ", 3)
+        ms, n, fl = float(ms), int(n), float(fl)
+        if ms <= 0:
+            continue
+        tf = fl / (ms * 1e-3) / 1e12
+        out.append({"kernel_class": tag, "ms_per_step": round(ms / steps, 4), "launches_per_step": n / steps,
+                    "tflops": round(tf, 2), "frac": round(tf / peak_tflops, 4)})
+    out.sort(key=lambda d: -d["ms_per_step"])
+    return out
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -383,6 +402,10 @@ def run_train(args):
                         "step_frac": round(step_tf / peak, 4),
                         "step_frac_of_fp32_mfma_peak": round(step_tf / FP32_MFMA_PEAK_TFLOPS, 4)}
                 roof.update(common)
+                by = kernel_classes(lib, args.steps, peak)
+                if by:
+                    roof["dominant_kernel"] = by[0]     # the class with the largest share of the step
+                    roof["by_kernel_class"] = by
             else:
                 # bf16 sweeps: 1/16 of the fp32 matrix time, so the per-point saved state decides: the bound is HBM.
                 # achieved = algorithmic bytes of the MFMA-family launches (each saved-state matrix written once and
@@ -404,6 +427,9 @@ def run_train(args):
                         "mfma_tflops": round(ach, 2), "mfma_frac_of_bf16_peak": round(ach / BF16_MFMA_PEAK_TFLOPS, 4),
                         "step_frac_of_bf16_peak": round(step_tf / BF16_MFMA_PEAK_TFLOPS, 4)}
                 roof.update(common)
+                by = kernel_classes(lib, args.steps, BF16_MFMA_PEAK_TFLOPS)
+                if by:
+                    roof["by_kernel_class"] = by
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(B, S, args.cpu_steps, args.warmup_mode, args.no_albedo)

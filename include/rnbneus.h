@@ -334,6 +334,9 @@ int rnb_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
  * last enable/collect.  This is the only mutable global state of the library; it is off by default. */
 int rnb_profile_enable(int on);
 int rnb_profile_collect(double* gemm_ms, int64_t* gemm_launches, double* gemm_flops);
+/* Per kernel class of the last rnb_profile_collect: one text line "<class> <ms> <launches> <flops>" each, written to
+ * `out` (NUL-terminated, at most `capacity` bytes; out may be NULL); returns the number of bytes the full text needs. */
+int64_t rnb_profile_report(char* out, int64_t capacity);
 
 #ifdef __cplusplus
 }

@@ -512,6 +512,7 @@ RNB_API int rnb_profile_enable(int on) { return profile_enable(on); }
 RNB_API int rnb_profile_collect(double* gemm_ms, int64_t* gemm_launches, double* gemm_flops) {
   return profile_collect(gemm_ms, gemm_launches, gemm_flops);
 }
+RNB_API int64_t rnb_profile_report(char* out, int64_t capacity) { return profile_report(out, capacity); }
 
 RNB_API int rnb_algorithmic_bytes(const rnb_model_desc* desc, int64_t B, int32_t flags, double* train_bytes) {
   RNB_REQUIRE(train_bytes, "train_bytes");

@@ -1391,7 +1391,7 @@ static double color_flops(const Layout& L, int64_t M, int first) {
 int bf16_color_forward(const Layout& L, const float* packed, PointBufs& pb, const float* pts, hipStream_t s) {
   BfColArgs g;
   fill_col(L, packed, pts, pb, g);
-  ProfScope prof(color_flops(L, pb.M, 0) + 2.0 * (double)pb.M * L.colo.N * L.colo.K, s);
+  ProfScope prof(color_flops(L, pb.M, 0) + 2.0 * (double)pb.M * L.colo.N * L.colo.K, s, "albedo_fwd");
   hipLaunchKernelGGL(bf_color_fwd_kernel, dim3((unsigned)(pb.Mp / BT)), dim3(256), 0, s, g);
   RNB_CHECK_LAUNCH();
   return RNB_OK;
@@ -1404,7 +1404,7 @@ int bf16_color_backward(const Layout& L, const float* packed, PointBufs& pb, flo
   fill_col(L, packed, nullptr, pb, g);
   const bool det = (L.variant & RNB_VARIANT_DETERMINISTIC) != 0;
   {
-    ProfScope prof(color_flops(L, pb.M, 0) + 2.0 * (double)pb.M * L.colo.N * L.colo.K, s);
+    ProfScope prof(color_flops(L, pb.M, 0) + 2.0 * (double)pb.M * L.colo.N * L.colo.K, s, "albedo_bwd");
     hipLaunchKernelGGL(bf_color_bwd_kernel, dim3((unsigned)(pb.Mp / BT)), dim3(256), 0, s, g);
     RNB_CHECK_LAUNCH();
   }
@@ -1496,7 +1496,7 @@ int bf16_forward(const Layout& L, const float* packed, const float* pts, int64_t
   g.e = reinterpret_cast<bfraw*>(pb.e);
   double fl = hidden_flops_bf(L, M, 0) + 2.0 * (double)M * L.H;
   if (need_feat) fl += 2.0 * (double)M * L.F * L.H;
-  ProfScope prof(fl, s);
+  ProfScope prof(fl, s, save ? "F_sweep(save)" : "F_sweep(forward_only)");
   const unsigned blocks = (unsigned)(pb.Mp / BT);
   const int ti = bf_ti(L, RNB_VARIANT_FWD_TI_SHIFT);
   if (save && ti == 1) hipLaunchKernelGGL((bf_forward_kernel<true, 1>), dim3(blocks), dim3(512), 0, s, g);
@@ -1538,7 +1538,7 @@ static void fill_bwd(const Layout& L, const float* packed, PointBufs& pb, BfBwdA
 int bf16_reverse(const Layout& L, const float* packed, PointBufs& pb, hipStream_t s) {
   BfBwdArgs g;
   fill_bwd(L, packed, pb, g);
-  ProfScope prof(hidden_flops_bf(L, pb.M, 0), s);
+  ProfScope prof(hidden_flops_bf(L, pb.M, 0), s, "R_sweep");
   if (bf_ti(L, RNB_VARIANT_BWD_TI_SHIFT) == 1) hipLaunchKernelGGL(bf_reverse_kernel<1>, dim3((unsigned)(pb.Mp / BT)), dim3(512), 0, s, g);
   else hipLaunchKernelGGL(bf_reverse_kernel<2>, dim3((unsigned)(pb.Mp / BT)), dim3(256), 0, s, g);
   RNB_CHECK_LAUNCH();
@@ -1555,7 +1555,7 @@ int bf16_backward(const Layout& L, const float* packed, PointBufs& pb, bool with
   const unsigned blocks = (unsigned)(pb.Mp / BT);
   const int bti = bf_ti(L, RNB_VARIANT_BWD_TI_SHIFT);
   {
-    ProfScope prof(hidden_flops_bf(L, M, 0), s);
+    ProfScope prof(hidden_flops_bf(L, M, 0), s, "RA_sweep");
     if (bti == 1) hipLaunchKernelGGL(bf_ra_kernel<1>, dim3(blocks), dim3(512), 0, s, g);
     else hipLaunchKernelGGL(bf_ra_kernel<2>, dim3(blocks), dim3(256), 0, s, g);
     RNB_CHECK_LAUNCH();
@@ -1573,7 +1573,7 @@ int bf16_backward(const Layout& L, const float* packed, PointBufs& pb, bool with
     g.fbar = (with_color && !color_bf16) ? pb.cinb : nullptr;
     g.ld_fbar = L.Cinp;
     g.fbar_in_k8 = (with_color && color_bf16) ? 1 : 0;
-    ProfScope prof(hidden_flops_bf(L, M, 1) + (with_color ? 2.0 * (double)M * L.F * L.H : 0.0), s);
+    ProfScope prof(hidden_flops_bf(L, M, 1) + (with_color ? 2.0 * (double)M * L.F * L.H : 0.0), s, "FB_sweep");
     if (bti == 1) hipLaunchKernelGGL(bf_fb_kernel<1>, dim3(blocks), dim3(512), 0, s, g);
     else hipLaunchKernelGGL(bf_fb_kernel<2>, dim3(blocks), dim3(256), 0, s, g);
     RNB_CHECK_LAUNCH();
@@ -1637,7 +1637,7 @@ int bf16_backward(const Layout& L, const float* packed, PointBufs& pb, bool with
     }
   }
   {
-    ProfScope prof(fl, s);
+    ProfScope prof(fl, s, "dW(all)");
     hipLaunchKernelGGL(bf_dw_kernel, dim3((unsigned)(grp.njobs * splits)), dim3(512), 0, s, grp);
     RNB_CHECK_LAUNCH();
     if (det) {

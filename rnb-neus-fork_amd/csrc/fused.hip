@@ -556,7 +556,7 @@ int fused_forward(const Layout& L, const float* packed, const float* pts, int64_
   for (int l = 0; l < L.nh; ++l) fl += 2.0 * (double)M * L.hid[l].N * L.hid[l].K;
   fl += 2.0 * (double)M * L.H;
   if (need_feat) fl += 2.0 * (double)M * L.F * L.H;
-  ProfScope prof(fl, s);
+  ProfScope prof(fl, s, save ? "F_sweep(save)" : "F_sweep(forward_only)");
   // 64-point tiles when that still gives every CU >= 2 workgroups, 32-point tiles for small batches
   const int force_ti = L.knob(RNB_VARIANT_FWD_TI_SHIFT);   // tuning knob: 1 or 2 forces the tile height
   const bool small = force_ti ? (force_ti == 1) : (pb.Mp / 64 < 512);

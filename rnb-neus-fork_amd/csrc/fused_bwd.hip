@@ -465,7 +465,7 @@ static double hidden_flops(const Layout& L, int64_t M, int first) {
 int fused_reverse(const Layout& L, const float* packed, PointBufs& pb, hipStream_t s) {
   FusedBwdArgs g;
   fill_args(L, packed, pb, g);
-  ProfScope prof(hidden_flops(L, pb.M, 0), s);
+  ProfScope prof(hidden_flops(L, pb.M, 0), s, "R_sweep");
   const int ti = bwd_ti(L, is_x3(L) ? 2 : 1), nw = bwd_nw(L, is_x3(L) ? 4 : 8);
   const dim3 grid((unsigned)(pb.Mp / (32 * ti))), block(64 * nw);
   if (is_x3(L)) {
@@ -484,7 +484,7 @@ int fused_reverse(const Layout& L, const float* packed, PointBufs& pb, hipStream
 int fused_ra(const Layout& L, const float* packed, PointBufs& pb, hipStream_t s) {
   FusedBwdArgs g;
   fill_args(L, packed, pb, g);
-  ProfScope prof(hidden_flops(L, pb.M, 0), s);
+  ProfScope prof(hidden_flops(L, pb.M, 0), s, "RA_sweep");
   const int ti = bwd_ti(L, is_x3(L) ? 2 : 1), nw = bwd_nw(L, is_x3(L) ? 4 : 8);
   const dim3 grid((unsigned)(pb.Mp / (32 * ti))), block(64 * nw);
   if (is_x3(L)) {
@@ -505,7 +505,7 @@ int fused_fb(const Layout& L, const float* packed, PointBufs& pb, bool with_colo
   fill_args(L, packed, pb, g);
   g.fbar = with_color ? pb.cinb : nullptr;
   g.ld_fbar = L.Cinp;
-  ProfScope prof(hidden_flops(L, pb.M, 1) + (with_color ? 2.0 * (double)pb.M * L.F * L.H : 0.0), s);
+  ProfScope prof(hidden_flops(L, pb.M, 1) + (with_color ? 2.0 * (double)pb.M * L.F * L.H : 0.0), s, "FB_sweep");
   const int ti = bwd_ti(L, is_x3(L) ? 2 : 1), nw = bwd_nw(L, is_x3(L) ? 4 : 8);
   const dim3 grid((unsigned)(pb.Mp / (32 * ti))), block(64 * nw);
   if (is_x3(L)) {

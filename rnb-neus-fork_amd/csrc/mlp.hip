@@ -573,7 +573,7 @@ static inline double mm_flops(int64_t M, const Lin& ln) { return 2.0 * (double)M
 template <bool B_KMAJOR, class Epi>
 static int launch_rows(const float* A, int lda, const float* W, int ldw, int64_t Mp, int N, int K, const Epi& epi,
                        double flops, hipStream_t s, bool x3 = false) {
-  ProfScope prof(flops, s);
+  ProfScope prof(flops, s, "layer_gemm");
   if constexpr (!B_KMAJOR) {
     if (x3 && N >= 256 && K % XK == 0) {
       dim3 grid((unsigned)(Mp / BM), (unsigned)((N + 255) / 256));
@@ -696,7 +696,7 @@ struct DwBatch {
       slab_left -= need;
     }
     {
-      ProfScope prof(flops[3], s);
+      ProfScope prof(flops[3], s, "dW(256x256)");
       if (x3) hipLaunchKernelGGL(gemm_dw_x3_kernel<0>, dim3((unsigned)end), dim3(512), 0, s, g);
       else hipLaunchKernelGGL(gemm_dw_staged_kernel<0>, dim3((unsigned)end), dim3(1024), 0, s, g);
       RNB_CHECK_LAUNCH();
@@ -730,7 +730,7 @@ struct DwBatch {
     }
     const dim3 grid((unsigned)g.job[g.njobs - 1].block_end);
     {
-      ProfScope prof(flops[v], s);
+      ProfScope prof(flops[v], s, "dW(other)");
       if (v == 0 && !lds_path) hipLaunchKernelGGL((gemm_dw_direct_kernel<128, 3>), grid, dim3(256), 0, s, g);
       else if (v == 1 && !lds_path) hipLaunchKernelGGL((gemm_dw_direct_kernel<64, 3>), grid, dim3(256), 0, s, g);
       else if (v == 0) hipLaunchKernelGGL((gemm_dw_kernel<false, 128>), grid, dim3(256), 0, s, g);

@@ -264,15 +264,17 @@ const char* last_error();
 
 // ---- optional GEMM event instrumentation (prof.hip) ----------------------------------------------
 bool prof_enabled();
-void prof_begin(double flops, hipStream_t s);
+void prof_begin(double flops, hipStream_t s, const char* tag);
 void prof_end(hipStream_t s);
 int profile_enable(int on);
 int profile_collect(double* ms, int64_t* launches, double* flops);
+int64_t profile_report(char* out, int64_t cap);
 struct ProfScope {
   hipStream_t s;
   bool on;
-  ProfScope(double flops, hipStream_t st) : s(st), on(prof_enabled()) {
-    if (on) prof_begin(flops, s);
+  // tag: kernel class for the per-class report (a string literal: it is kept by pointer)
+  ProfScope(double flops, hipStream_t st, const char* tag = nullptr) : s(st), on(prof_enabled()) {
+    if (on) prof_begin(flops, s, tag);
   }
   ~ProfScope() {
     if (on) prof_end(s);

@@ -122,6 +122,7 @@ _SIGNATURES = {
                                 C.c_double, C.c_double, C.c_double, C.c_int64, C.c_void_p]),
     "rnb_profile_enable": (C.c_int, [C.c_int]),
     "rnb_profile_collect": (C.c_int, [_P(C.c_double), _P(C.c_int64), _P(C.c_double)]),
+    "rnb_profile_report": (C.c_int64, [C.c_char_p, C.c_int64]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES.keys())
