@@ -317,7 +317,7 @@ def run_train(args):
         if args.torch_train_ops:
             loss, _ = torch_rnb_loss(out, b["true_rgb"], b["mask"])
         else:
-            loss, _ = R.rnb_loss(out, b["true_rgb"], b["mask"], group=group)
+            loss, _ = R.rnb_loss(out, b["true_rgb"], b["mask"], group=group, report_global=False)   # (no per-step logging here)
         opt.zero_grad(set_to_none=True)
         loss.backward()
         opt.step()

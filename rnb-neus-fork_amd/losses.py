@@ -27,7 +27,8 @@ from .parallel import global_mask_count
 
 class _RnbLoss(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, color_fine, weight_sum, gradient_error, true_rgb, mask, igr_weight, mask_weight, group):
+    def forward(ctx, color_fine, weight_sum, gradient_error, true_rgb, mask, igr_weight, mask_weight, group,
+                report_global=True):
         for name, t in (("color_fine", color_fine), ("weight_sum", weight_sum), ("true_rgb", true_rgb),
                         ("mask", mask)):
             if not t.is_cuda:
@@ -61,10 +62,12 @@ class _RnbLoss(torch.autograd.Function):
                     native.ptr(color), native.ptr(rgb), native.ptr(mk), native.ptr(ws), native.ptr(ge), L, B, Cd,
                     float(igr_weight), float(mask_weight), native.ptr(cnt), B_global, 1.0 / world, native.ptr(loss),
                     native.ptr(parts), native.ptr(d_color), native.ptr(d_ws), native.ptr(d_ge), stream))
-            # the loss VALUE of the whole batch on every rank (reporting only; gradients are already global-normalised)
-            rep = torch.cat([loss.reshape(1), parts])
-            dist.all_reduce(rep, op=dist.ReduceOp.SUM, group=group)
-            loss, parts = rep[0].clone(), rep[1:].clone()
+            # the loss VALUE of the whole batch on every rank (reporting only; gradients are already global-normalised).
+            # report_global=False keeps this rank's additive share instead and saves the collective.
+            if report_global:
+                rep = torch.cat([loss.reshape(1), parts])
+                dist.all_reduce(rep, op=dist.ReduceOp.SUM, group=group)
+                loss, parts = rep[0].clone(), rep[1:].clone()
         else:
             with native.on_device(color) as stream:
                 native.check(lib.rnb_loss_rnb(native.ptr(color), native.ptr(rgb), native.ptr(mk), native.ptr(ws),
@@ -83,12 +86,14 @@ class _RnbLoss(torch.autograd.Function):
                                "backward; re-run the forward)")
         ctx.grads = None
         out = torch._foreach_mul(list(grads), g_loss)      # one multi-tensor launch
-        return out[0], out[1], out[2], None, None, None, None, None
+        return out[0], out[1], out[2], None, None, None, None, None, None
 
 
-def rnb_loss(render_out, true_rgb, mask, igr_weight=0.1, mask_weight=0.1, group=None):
+def rnb_loss(render_out, true_rgb, mask, igr_weight=0.1, mask_weight=0.1, group=None, report_global=True):
     """exp_runner.py:229-258 (`train_rnb`).  Returns `(loss, {"color_loss", "eikonal_loss", "mask_loss"})`.
-    `group`: the data-parallel process group whose ranks share one global batch (see the module docstring)."""
+    `group`: the data-parallel process group whose ranks share one global batch (see the module docstring).
+    `report_global` (with a group): True returns the loss VALUE of the whole batch on every rank (one more 4-float
+    all-reduce per step); False returns this rank's additive share of it — the gradients are identical either way."""
     loss, parts = _RnbLoss.apply(render_out["color_fine"], render_out["weight_sum"], render_out["gradient_error"],
-                                 true_rgb, mask, igr_weight, mask_weight, group)
+                                 true_rgb, mask, igr_weight, mask_weight, group, report_global)
     return loss, {"color_loss": parts[0], "eikonal_loss": parts[1], "mask_loss": parts[2]}
