@@ -448,7 +448,7 @@ struct BfBwdArgs {
 // R: gz_l = g_l * D_l, g_{l-1} = gz_l W_l, normal = J_pe^T g_e
 template <int TI>
 __global__ __launch_bounds__(BfCfg<TI>::NT, TI == 1 ? 4 : 2) void bf_reverse_kernel(BfBwdArgs g) {
-  constexpr int NW = BfCfg<TI>::NW, NT = BfCfg<TI>::NT;
+  constexpr int NT = BfCfg<TI>::NT;
   __shared__ __attribute__((aligned(16))) bfraw X[BT * BP];
   __shared__ float GE[BT * FEP];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -562,7 +562,7 @@ __global__ __launch_bounds__(BfCfg<TI>::NT, TI == 1 ? 4 : 2) void bf_reverse_ker
 // RA: u_{l+1} = (u_l W_l^T) * D_l, zR_l = 100 (u_l W_l^T) gz_l (1 - D_l)
 template <int TI>
 __global__ __launch_bounds__(BfCfg<TI>::NT, TI == 1 ? 4 : 2) void bf_ra_kernel(BfBwdArgs g) {
-  constexpr int NW = BfCfg<TI>::NW, NT = BfCfg<TI>::NT;
+  constexpr int NT = BfCfg<TI>::NT;
   __shared__ __attribute__((aligned(16))) bfraw X[BT * BP];
   __shared__ float E[BT * FEP];   // adjoint of g_e of the tile (re-enters at the skip connection)
   const int tid = threadIdx.x, lane = tid & 63;
@@ -572,7 +572,6 @@ __global__ __launch_bounds__(BfCfg<TI>::NT, TI == 1 ? 4 : 2) void bf_ra_kernel(B
   const int rb = (wave >> 2) * 32;         // first row of the wave inside the tile (TI == 1: two row halves)
   const int64_t rowW = row0 + rb;
   const bfraw* Xw = X + rb * BP;
-  const int h = lane >> 5, cl = lane & 31;
 
   for (int idx = tid; idx < BT * g.Ep; idx += NT) {
     const int r = idx / g.Ep, c = idx - r * g.Ep;
@@ -652,7 +651,7 @@ __global__ __launch_bounds__(BfCfg<TI>::NT, TI == 1 ? 4 : 2) void bf_ra_kernel(B
 // FB: zb_{l-1} = (zb_l W_l) * D_{l-1} + zR_{l-1}, head: ab_{nh-1} = fbar W_feat + sbar / scale * w_sdf
 template <int TI>
 __global__ __launch_bounds__(BfCfg<TI>::NT, TI == 1 ? 4 : 2) void bf_fb_kernel(BfBwdArgs g) {
-  constexpr int NW = BfCfg<TI>::NW, NT = BfCfg<TI>::NT;
+  constexpr int NT = BfCfg<TI>::NT;
   __shared__ __attribute__((aligned(16))) bfraw X[BT * BP];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = wave_id();
@@ -661,7 +660,6 @@ __global__ __launch_bounds__(BfCfg<TI>::NT, TI == 1 ? 4 : 2) void bf_fb_kernel(B
   const int rb = (wave >> 2) * 32;         // first row of the wave inside the tile (TI == 1: two row halves)
   const int64_t rowW = row0 + rb;
   const bfraw* Xw = X + rb * BP;
-  const int h = lane >> 5, cl = lane & 31;
 
   v16f acc[TI][2];
   AuxBf<TI> aD, aZ;

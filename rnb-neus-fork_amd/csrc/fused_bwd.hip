@@ -145,7 +145,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TI == 2) ? 1 : 2) void fused_r
   const int wave = wave_id();
   const int64_t row0 = (int64_t)blockIdx.x * BT;
   const int n0 = wave * 32 * TJ;
-  const int h = lane >> 5;
 
   // seed: gz_{nh-1} = w_sdf * D_{nh-1}  (row 0 of the output layer is d sdf / d a_last)
   {
@@ -254,7 +253,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TI == 2) ? 1 : 2) void fused_r
   const int wave = wave_id();
   const int64_t row0 = (int64_t)blockIdx.x * BT;
   const int n0 = wave * 32 * TJ;
-  const int h = lane >> 5;
 
   for (int idx = tid; idx < BT * g.Ep; idx += NT) {
     const int r = idx / g.Ep, c = idx - r * g.Ep;
@@ -336,7 +334,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TI == 2) ? 1 : 2) void fused_f
   const int wave = wave_id();
   const int64_t row0 = (int64_t)blockIdx.x * BT;
   const int n0 = wave * 32 * TJ;
-  const int h = lane >> 5;
 
   v16f acc[TI][TJ];
   AuxTile<TI, TJ> aD, aZ;
