@@ -124,6 +124,7 @@ struct BfMma {
                                    v16f (&acc)[TI][2], const bfraw* __restrict__ Wnext, int Knext, int n0next) {
     bf_zero<TI>(acc);
     vu4 alt[KS][2];
+    __builtin_amdgcn_s_setprio(1);   // (the matrix loop outranks the other workgroup's epilogue on this SIMD)
 #pragma unroll
     for (int Q = 0; Q < NQ; ++Q) {
       // request the block after this one into the set that is not being multiplied
@@ -135,6 +136,7 @@ struct BfMma {
       __builtin_amdgcn_sched_barrier(0);
       if (Q & 1) bf_mma_block<TI, KS, PITCH>(X, Q, lane, alt, acc); else bf_mma_block<TI, KS, PITCH>(X, Q, lane, pre, acc);
     }
+    __builtin_amdgcn_s_setprio(0);
     if ((NQ & 1) && Wnext) {   // odd block count: the next product's block 0 sits in `alt`
 #pragma unroll
       for (int s = 0; s < KS; ++s) { pre[s][0] = alt[s][0]; pre[s][1] = alt[s][1]; }
