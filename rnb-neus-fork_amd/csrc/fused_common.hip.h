@@ -169,13 +169,18 @@ __device__ inline void layer_mma_nt_ring(const float* __restrict__ X, const floa
 // Weights are split once per step into a fragment-ordered mirror (x3_pack_weights): for W [N][K], fragment (nt, ks)
 // = rows 32 nt .. +32, k = 16 ks .. +16 is three consecutive 1 KB blocks (hi, mid, lo), each 64 lanes x 16 bytes with
 // lane (c, h) = W[32 nt + c][16 ks + 8 h .. +8].  Activations stay fp32 in LDS and are split as they are read.
+// (buffer loads: per-lane offset lane * 16 in one VGPR, the fragment's offset in the scalar operand, the plane in the
+// immediate — plain pointer arithmetic cost five 64-bit vector adds per step in front of the loads)
 template <int TJ>
 __device__ inline void x3_load_b(const x3raw* __restrict__ W3, int nks, int n0, int ks, int lane, vu4x (&b)[TJ][3]) {
+  const BufRsrc rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<x3raw*>(W3), 0, 0x4000000, 0x00020000);
+  const unsigned voff = (unsigned)lane * 16u;
 #pragma unroll
   for (int tj = 0; tj < TJ; ++tj) {
-    const x3raw* p = W3 + ((size_t)((n0 >> 5) + tj) * nks + ks) * (3 * 512) + lane * 8;
+    const unsigned soff = (unsigned)(((n0 >> 5) + tj) * nks + ks) * 3072u;
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) b[tj][pl] = *reinterpret_cast<const vu4x*>(p + pl * 512);
+    for (int pl = 0; pl < 3; ++pl)
+      b[tj][pl] = __builtin_bit_cast(vu4x, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff + pl * 1024, 0));
   }
 }
 template <int TI>
