@@ -65,14 +65,19 @@ __device__ inline size_t k8(int64_t row, int col, int C) { return ((size_t)(row 
 // One B-fragment load of a wave is then ONE contiguous 1 KB read (8 cache lines).  Row-major weights make the same
 // load touch 32 lines (32 bytes of each of 32 rows) — at 8 loads per 16 MFMAs that kept the L1 tag pipeline, not the
 // matrix cores, busy: the sweeps ran at 14 % of the bf16 MFMA rate.
+// (buffer loads: lane * 16 in one VGPR, the fragment's offset in the scalar operand, the step in the immediate — no
+// vector address arithmetic in front of the loads)
 template <int KS>
 __device__ inline void bf_load_b(const bfraw* __restrict__ W, int K, int n0, int Q, int lane, vu4 (&b)[KS][2]) {
   const int nks = K >> 4;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bfraw*>(W), 0, 0x4000000, 0x00020000);
+  const unsigned voff = (unsigned)lane * 16u;
 #pragma unroll
   for (int tj = 0; tj < 2; ++tj) {
-    const bfraw* p = W + ((size_t)((n0 >> 5) + tj) * nks + Q * KS) * 512 + lane * 8;
+    const unsigned soff = (unsigned)(((n0 >> 5) + tj) * nks + Q * KS) * 1024u;
 #pragma unroll
-    for (int s = 0; s < KS; ++s) b[s][tj] = *reinterpret_cast<const vu4*>(p + s * 512);
+    for (int s = 0; s < KS; ++s)
+      b[s][tj] = __builtin_bit_cast(vu4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff + s * 1024, 0));
   }
 }
 // One 16 KS-k block: the A fragments of step s + 1 are read from LDS while the MFMAs of step s run (explicit rotation +
