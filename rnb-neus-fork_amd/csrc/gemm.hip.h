@@ -781,22 +781,27 @@ __device__ inline void x3_split4(const vf4& x, vu2x& hi, vu2x& mid, vu2x& lo) {
     lo[p] = x3_pack2(sa, sb);
   }
 }
-// ROWS x 16 k of a k-contiguous source -> ROWS / 64 float4 per thread (row idx >> 2, k quad idx & 3)
+// ROWS x 16 k of a k-contiguous source -> ROWS / 64 float4 per thread (row idx >> 2, k quad idx & 3).  Buffer loads:
+// the thread's (row, k quad) offset is loop-invariant (one VGPR per float4), the k offset of the tile is scalar.
 template <int ROWS, bool GUARD>
-__device__ inline void x3_load_rows(const float* __restrict__ src, int ld, int r0, int k0, int rmax, int tid,
-                                    vf4 (&v)[ROWS / 64]) {
+__device__ inline void x3_rows_offsets(int ld, int r0, int rmax, int tid, unsigned (&off)[ROWS / 64], bool (&ok)[ROWS / 64]) {
 #pragma unroll
   for (int i = 0; i < ROWS / 64; ++i) {
     const int idx = tid + 256 * i;
     const int r = idx >> 2, c4 = idx & 3;
-    if constexpr (!GUARD) {
-      v[i] = *reinterpret_cast<const vf4*>(src + (size_t)(r0 + r) * ld + k0 + c4 * 4);
-    } else {
-      const bool ok = r0 + r < rmax;
-      const int rr = ok ? r0 + r : rmax - 1;
-      const vf4 t = *reinterpret_cast<const vf4*>(src + (size_t)rr * ld + k0 + c4 * 4);
-      v[i] = make_vf4(ok ? t.x : 0.f, ok ? t.y : 0.f, ok ? t.z : 0.f, ok ? t.w : 0.f);
-    }
+    ok[i] = !GUARD || r0 + r < rmax;
+    const int rr = ok[i] ? r0 + r : rmax - 1;   // GUARD: a clamped (valid) row, selected away below
+    off[i] = ((unsigned)rr * (unsigned)ld + (unsigned)c4 * 4u) * 4u;
+  }
+}
+template <int ROWS, bool GUARD>
+__device__ inline void x3_load_rows(BufRsrc rs, const unsigned (&off)[ROWS / 64], const bool (&ok)[ROWS / 64], int k0,
+                                    vf4 (&v)[ROWS / 64]) {
+#pragma unroll
+  for (int i = 0; i < ROWS / 64; ++i) {
+    const vf4 t = __builtin_bit_cast(vf4, __builtin_amdgcn_raw_buffer_load_b128(rs, off[i], (unsigned)k0 * 4u, 0));
+    if constexpr (!GUARD) v[i] = t;
+    else v[i] = make_vf4(ok[i] ? t.x : 0.f, ok[i] ? t.y : 0.f, ok[i] ? t.z : 0.f, ok[i] ? t.w : 0.f);
   }
 }
 template <int ROWS>
@@ -837,16 +842,23 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_x3_kernel(const float* __res
   zero_acc<TN>(acc);
   vf4 ra[BM / 64], rb[BN / 64];
   const int nk = K / XK;
-  x3_load_rows<BM, false>(A, lda, m_blk, 0, 0, tid, ra);
-  x3_load_rows<BN, GUARD>(W, ldw, n_blk, 0, N, tid, rb);
+  // resources based at the tile's first row (32-bit offsets stay inside the tile)
+  const BufRsrc rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A + (size_t)m_blk * lda), 0, 0xfffffffc, 0x00020000);
+  const BufRsrc rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W + (size_t)n_blk * ldw), 0, 0xfffffffc, 0x00020000);
+  unsigned oa[BM / 64], ob[BN / 64];
+  bool ka[BM / 64], kb[BN / 64];
+  x3_rows_offsets<BM, false>(lda, 0, 0, tid, oa, ka);
+  x3_rows_offsets<BN, GUARD>(ldw, 0, N - n_blk, tid, ob, kb);
+  x3_load_rows<BM, false>(rsA, oa, ka, 0, ra);
+  x3_load_rows<BN, GUARD>(rsW, ob, kb, 0, rb);
   for (int kt = 0; kt < nk; ++kt) {
     x3_store_rows<BM>(Ap, tid, ra);
     x3_store_rows<BN>(Bp, tid, rb);
     lds_barrier();
     {
       const int k0 = min(kt + 1, nk - 1) * XK;   // past the end: a harmless re-load
-      x3_load_rows<BM, false>(A, lda, m_blk, k0, 0, tid, ra);
-      x3_load_rows<BN, GUARD>(W, ldw, n_blk, k0, N, tid, rb);
+      x3_load_rows<BM, false>(rsA, oa, ka, k0, ra);
+      x3_load_rows<BN, GUARD>(rsW, ob, kb, k0, rb);
     }
     vu4x a[2][3];
 #pragma unroll
@@ -893,9 +905,11 @@ constexpr int kX3Plane = 2 * kX3Half;
 constexpr int kX3OpBytes = 3 * kX3Plane;        // one operand of one chunk: 25.5 KB
 constexpr int kX3BufBytes = 2 * kX3OpBytes;     // both operands
 
-__device__ inline void dw_x3_load(const float* __restrict__ src, int ld, int row0, int c4, vf4 (&x)[4]) {
+// (buffer loads: the lane's column offset in one VGPR, the wave-uniform row offset in the scalar operand)
+__device__ inline void dw_x3_load(BufRsrc rs, unsigned voff, int ld, int row0, vf4 (&x)[4]) {
 #pragma unroll
-  for (int p = 0; p < 4; ++p) x[p] = *reinterpret_cast<const vf4*>(src + (size_t)(row0 + p) * ld + c4);
+  for (int p = 0; p < 4; ++p)
+    x[p] = __builtin_bit_cast(vf4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (unsigned)(row0 + p) * (unsigned)ld * 4u, 0));
 }
 // 4 columns x 4 points of one thread -> 12 half units at w (+ 68 * 16 per column, + kX3Plane per plane)
 __device__ inline void dw_x3_split(const vf4 (&x)[4], vu2x (&hi)[4], vu2x (&mid)[4], vu2x (&lo)[4]) {
@@ -1003,14 +1017,17 @@ __global__ __launch_bounds__(512, 1) void gemm_dw_x3_kernel(const DwGroup g) {
   [[maybe_unused]] const unsigned long long r_begin = DUMMY == 1 ? __builtin_amdgcn_s_memrealtime() : 0;
   for (int pi = 0; pi < J.npairs; ++pi) {
     const DwPair p = pi == 0 ? J.p1 : J.p2;
-    const float* src = (sop == 0 ? p.X : p.Y) + 4 * cg;
     const int ld = sop == 0 ? p.ldx : p.ldy;
+    // resource based at this split's first row: 32-bit offsets stay inside the split whatever the total point count
+    const BufRsrc src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>((sop == 0 ? p.X : p.Y) + (size_t)m_begin * ld), 0,
+                                                          0xfffffffc, 0x00020000);
+    const unsigned voff = 16u * (unsigned)cg;
     const bool do_bias = DUMMY == 0 && J.db != nullptr && pi == J.bias_pair && sop == 0;
     const int last = nchunks - 1;
-    const int r0 = m_begin + 4 * pq;
+    const int r0 = 4 * pq;   // (rows relative to the split)
     vf4 x0[4], x1[4];   // raw rows of an even / odd chunk
-    dw_x3_load(src, ld, r0, 0, x0);
-    dw_x3_load(src, ld, r0 + min(1, last) * kX3Chunk, 0, x1);
+    dw_x3_load(src, voff, ld, r0, x0);
+    dw_x3_load(src, voff, ld, r0 + min(1, last) * kX3Chunk, x1);
     __builtin_amdgcn_s_barrier();   // every wave is done with the buffers of the previous pair
     {
       vu2x hi[4], mid[4], lo[4];
@@ -1018,7 +1035,7 @@ __global__ __launch_bounds__(512, 1) void gemm_dw_x3_kernel(const DwGroup g) {
       dw_x3_store(swr, hi, mid, lo);
       dw_x3_colsum(x0, do_bias, bs);
     }
-    dw_x3_load(src, ld, r0 + min(2, last) * kX3Chunk, 0, x0);
+    dw_x3_load(src, voff, ld, r0 + min(2, last) * kX3Chunk, x0);
     for (int c = 0; c < nchunks; c += 2) {
       // even chunk c from buffer 0; chunk c + 1 (x1) -> buffer 1; x1 <- chunk c + 3
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1028,7 +1045,7 @@ __global__ __launch_bounds__(512, 1) void gemm_dw_x3_kernel(const DwGroup g) {
       dw_x3_chunk(fx, fy, acc, x1, swr + kX3BufBytes);
       dw_x3_colsum(x1, do_bias, bs);   // (nchunks even: chunk c + 1 always exists)
       [[maybe_unused]] const unsigned long long s2 = DUMMY == 1 ? __builtin_amdgcn_s_memtime() : 0;
-      dw_x3_load(src, ld, r0 + min(c + 3, last) * kX3Chunk, 0, x1);
+      dw_x3_load(src, voff, ld, r0 + min(c + 3, last) * kX3Chunk, x1);
       if constexpr (DUMMY == 1) {
         const unsigned long long s3 = __builtin_amdgcn_s_memtime();
         t_bar += s1 - s0; t_chunk += s2 - s1; t_load += s3 - s2;
@@ -1039,7 +1056,7 @@ __global__ __launch_bounds__(512, 1) void gemm_dw_x3_kernel(const DwGroup g) {
       __builtin_amdgcn_s_barrier();
       dw_x3_chunk(fx + kX3BufBytes, fy + kX3BufBytes, acc, x0, swr);
       dw_x3_colsum(x0, do_bias && c + 2 < nchunks, bs);
-      dw_x3_load(src, ld, r0 + min(c + 4, last) * kX3Chunk, 0, x0);
+      dw_x3_load(src, voff, ld, r0 + min(c + 4, last) * kX3Chunk, x0);
     }
   }
   // accumulator (ti, tj, r) of lane (i, h) is dW[64 wm + 32 ti + rho][128 wn + 32 tj + i], rho = (r & 3) + 8 (r >> 2) + 4 h
