@@ -166,15 +166,22 @@ __device__ inline void bf_layer_mma(const bfraw* __restrict__ X, const bfraw* __
 
 // ---- accumulator-layout access to K8 matrices -------------------------------------------------------------------
 // One "quad" = registers 4g .. 4g+3 of one 32 x 32 accumulator tile = points 8g + 4h .. +3 of one column = 8 bytes.
+// Buffer accesses: resource based at the wave's first K8 block row (row0 is wave-uniform), the lane's (column, half)
+// offset in ONE VGPR, the quad's block row in the scalar operand — no 64-bit vector address per quad (the epilogues of
+// these sweeps are what the vector port is busy with).
 struct Quad { float v[4]; };
+__device__ inline __amdgpu_buffer_rsrc_t k8_rsrc(const bfraw* base, int64_t row0, int C) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<bfraw*>(base) + (size_t)(row0 >> 3) * C * 8, 0, 0x7ffffff0, 0x00020000);
+}
 __device__ inline Quad k8_load_quad(const bfraw* __restrict__ base, int64_t row0, int ti, int g, int col, int h) {
-  const vu2 u = *reinterpret_cast<const vu2*>(base + (((size_t)((row0 + ti * 32) >> 3) + g) * FH + col) * 8 + 4 * h);
+  const vu2 u = __builtin_bit_cast(vu2, __builtin_amdgcn_raw_buffer_load_b64(k8_rsrc(base, row0, FH), (unsigned)(col * 16 + 8 * h),
+                                                                               (unsigned)((ti * 4 + g) * FH * 16), 0));
   return Quad{{bf_lo(u.x), bf_hi(u.x), bf_lo(u.y), bf_hi(u.y)}};
 }
 __device__ inline void k8_store_quad(bfraw* __restrict__ base, int64_t row0, int ti, int g, int col, int h, float a, float b,
                                      float c, float d, int C = FH) {
   const vu2 u = {pack2(a, b), pack2(c, d)};
-  *reinterpret_cast<vu2*>(base + (((size_t)((row0 + ti * 32) >> 3) + g) * C + col) * 8 + 4 * h) = u;
+  __builtin_amdgcn_raw_buffer_store_b64(u, k8_rsrc(base, row0, C), (unsigned)(col * 16 + 8 * h), (unsigned)((ti * 4 + g) * C * 16), 0);
 }
 // 8 rows of one column of an LDS tile (row-major, pitch P) -> one 16-byte K8 unit
 template <int P>
@@ -197,13 +204,15 @@ template <int TI> struct AuxBf { vu2 q[TI][2][4]; };
 template <int TI>
 __device__ inline void k8_prefetch(const bfraw* __restrict__ base, int64_t row0, int n0, int lane, AuxBf<TI>& t) {
   const int c = lane & 31, h = lane >> 5;
+  const __amdgpu_buffer_rsrc_t rs = k8_rsrc(base, row0, FH);
 #pragma unroll
   for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
     for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
       for (int g = 0; g < 4; ++g)
-        t.q[ti][tj][g] = *reinterpret_cast<const vu2*>(base + (((size_t)((row0 + ti * 32) >> 3) + g) * FH + n0 + tj * 32 + c) * 8 + 4 * h);
+        t.q[ti][tj][g] = __builtin_bit_cast(vu2, __builtin_amdgcn_raw_buffer_load_b64(
+            rs, (unsigned)((n0 + c) * 16 + 8 * h), (unsigned)((ti * 4 + g) * FH * 16 + tj * 512), 0));
 }
 template <int TI>
 __device__ inline float aux_at(const AuxBf<TI>& t, int ti, int tj, int r) {
