@@ -149,27 +149,57 @@ __global__ __launch_bounds__(64) void color_input_kernel(const float* __restrict
 }
 
 // albedo output layer (d_out rows) + sigmoid: 32 lanes per point.
-__global__ void color_out_kernel(const float* __restrict__ ac, int Hcp, int Hc, const float* __restrict__ Wo,
+// One wave per 4 rows: lane l reads the float4 l (+ 64, ..) of a row — a whole 1 KB row per load instruction, four rows
+// in flight — and keeps the output layer's <= 4 weight rows for its columns in registers (Hcp <= 256 * 4).
+__global__ __launch_bounds__(256) void color_out_kernel(const float* __restrict__ ac, int Hcp, int Hc, const float* __restrict__ Wo,
                                  int ldwo, const float* __restrict__ bo, int Co, int squeeze, int64_t Mp,
                                  float* __restrict__ alb) {
-  const int sub = threadIdx.x & 31;
-  int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
-  if (row >= Mp) return;
-  const float* ar = ac + row * Hcp;
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int k = sub; k < Hc; k += 32) {
-    const float av = ar[k];
-    for (int c = 0; c < Co; ++c) acc[c] = fmaf(av, Wo[c * ldwo + k], acc[c]);
-  }
-  for (int c = 0; c < Co; ++c) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t row0 = wave * 4;
+  if (row0 >= Mp) return;
+  float acc[4][4];
 #pragma unroll
-    for (int o = 16; o > 0; o >>= 1) acc[c] += __shfl_xor(acc[c], o, 32);
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[r][c] = 0.f;
+  for (int k4 = lane; k4 * 4 < Hcp; k4 += 64) {
+    vf4 w[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      w[c] = make_vf4(0.f, 0.f, 0.f, 0.f);
+      if (c < Co) {
+        const float* wp = Wo + (size_t)c * ldwo + k4 * 4;
+        w[c] = make_vf4(k4 * 4 < Hc ? wp[0] : 0.f, k4 * 4 + 1 < Hc ? wp[1] : 0.f, k4 * 4 + 2 < Hc ? wp[2] : 0.f,
+                        k4 * 4 + 3 < Hc ? wp[3] : 0.f);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (row0 + r < Mp) {
+        const vf4 a = *reinterpret_cast<const vf4*>(ac + (row0 + r) * Hcp + k4 * 4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          acc[r][c] = fmaf(a.x, w[c].x, fmaf(a.y, w[c].y, fmaf(a.z, w[c].z, fmaf(a.w, w[c].w, acc[r][c]))));
+      }
+    }
   }
-  if (sub == 0) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) acc[r][c] += __shfl_xor(acc[r][c], o, 64);
+    }
+  if (lane < 4 && row0 + lane < Mp) {   // lane r finishes row r
+    const int64_t row = row0 + lane;
+    float mine[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) mine[c] = lane == 0 ? acc[0][c] : lane == 1 ? acc[1][c] : lane == 2 ? acc[2][c] : acc[3][c];
     for (int c = 0; c < 4; ++c) {
       float v = 0.f;
       if (c < Co) {
-        v = acc[c] + bo[c];
+        v = mine[c] + bo[c];
         if (squeeze) v = 1.f / (1.f + expf(-v));
       }
       alb[row * 4 + c] = v;
@@ -922,7 +952,7 @@ int sweep_color(const Layout& L, const float* packed, PointBufs& pb, const float
     EpiRelu epi{packed + ln.b_off, pb.ac[l], L.Hcp, ln.N};
     RNB_TRY((launch_rows<false, EpiRelu>(in, lda, packed + ln.w_off, ln.Kp, pb.Mp, ln.Np, ln.Kp, epi, mm_flops(pb.M, ln), s, is_x3(L))));
   }
-  hipLaunchKernelGGL(color_out_kernel, dim3(blocks_for(pb.Mp * 32, 256)), dim3(256), 0, s, pb.ac[L.nc - 1], L.Hcp,
+  hipLaunchKernelGGL(color_out_kernel, dim3(blocks_for(pb.Mp * 16, 256)), dim3(256), 0, s, pb.ac[L.nc - 1], L.Hcp,
                      L.Hc, packed + L.colo.w_off, L.colo.Kp, packed + L.colo.b_off, L.Co, L.squeeze, pb.Mp, pb.alb);
   RNB_CHECK_LAUNCH();
   return RNB_OK;
