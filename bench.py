@@ -112,14 +112,11 @@ def parse():
 # launcher: python bench.py --gpus N without a torchrun environment
 # -------------------------------------------------------------------------------------------------------
 def spawn_ranks(args):
-    """Starts one child process per rank BEFORE this process touches a GPU (a process that has initialised HIP
-    must not be replaced or forked on this pool) and waits for them.  With fewer devices than ranks (a one-GPU
-    development box) the ranks share device 0 over gloo: a functional rehearsal of the N > 1 path, flagged
-    `"rehearsal": true` in the JSON line — never a scaling measurement."""
-    import torch   # import only; torch.cuda.device_count() does not initialise the GPU on this image
+    """Starts one child process per rank and waits for them.  This launcher process never imports torch and makes no
+    GPU-adjacent call at all; each child decides by itself (init_distributed) whether the box has a device per rank
+    or the ranks must share device 0 over gloo (a one-GPU development box: a functional rehearsal of the N > 1 path,
+    flagged `"rehearsal": true` in the JSON line — never a scaling measurement)."""
     n = args.gpus
-    ndev = torch.cuda.device_count()
-    rehearsal = ndev < n
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -128,8 +125,6 @@ def spawn_ranks(args):
         env = dict(os.environ)
         env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        if rehearsal:
-            env.update(RNB_SHARE_GPU="1", RNB_DIST_BACKEND="gloo")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0
     for p in procs:
@@ -228,9 +223,12 @@ def init_distributed(args):
     assert torch.cuda.is_available(), "bench.py needs a GPU (the renderer has no CPU path)"
     # one process per GPU; RNB_SHARE_GPU=1 (functional rehearsal of the N>1 path on a one-GPU box, with
     # RNB_DIST_BACKEND=gloo) puts every rank on device 0
-    rehearsal = bool(os.environ.get("RNB_SHARE_GPU"))
+    # (also chosen by every rank on its own when the box has fewer devices than ranks; device_count() does not
+    # initialise the GPU, and every rank of one box sees the same count, so the ranks agree)
+    rehearsal = bool(os.environ.get("RNB_SHARE_GPU")) or torch.cuda.device_count() < world
     if rehearsal:
         local_rank = 0
+        os.environ.setdefault("RNB_DIST_BACKEND", "gloo")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     backend = None
@@ -447,7 +445,7 @@ def run_train(args):
                                    + (f"; strong scaling of a {args.global_rays}-ray global batch" if args.scaling == "strong" else ""),
                        "rays_per_gpu": B, "global_rays": B * world, "samples_per_ray": S, "n_lights": 3,
                        "no_albedo": bool(args.no_albedo), "parallelism": f"dp{world}", "final_loss": final_loss,
-                       "dp_loss": ("exact large-batch (3 all-reduced scalars + SUM of gradients)" if (world > 1 and exact_dp)
+                       "dp_loss": ("exact large-batch (one 4-float all-reduce of the normalisers + SUM of gradients)" if (world > 1 and exact_dp)
                                    else ("DDP mean of per-rank losses" if world > 1 else "single process")),
                        "backend": backend, "deterministic": bool(args.deterministic),
                        "train_ops": ("torch ops loss + torch.optim.Adam(fused)" if args.torch_train_ops

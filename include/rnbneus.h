@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RNB_ABI_VERSION 2
+#define RNB_ABI_VERSION 3
 #define RNB_MAX_LIN 16 /* linear layers per MLP */
 
 enum {
@@ -311,13 +311,15 @@ int rnb_loss_rnb(const float* color_fine, const float* true_rgb, const float* ma
                  float mask_weight, float* loss, float* parts, float* d_color_fine, float* d_weight_sum,
                  float* d_gradient_error, rnb_stream_t stream);
 /* The same loss for one shard of a data-parallel batch, normalised by the GLOBAL batch (exp_runner.py:194
- * mask_sum and :251 BCE mean): mask_sum_global [1] device = all-reduced sum of (mask > 0.5) (without the 1e-5),
- * B_global = rays of the whole batch, eik_share = this shard's share of the (global) gradient_error in the returned
- * loss value (1/world).  loss/parts are this shard's ADDITIVE share: their sum over the shards is the loss of the
- * whole batch, and the sum over the shards of the gradients is its gradient. */
+ * mask_sum and :251 BCE mean): batch_global [2] device floats = the all-reduced { sum of (mask > 0.5) (without the
+ * 1e-5), number of rays } of the whole batch — the ray count is taken from the collective, not assumed to be
+ * B * world, so unequal shards stay exact; gradient_error [1] = the GLOBAL eikonal ratio; eik_share = this shard's
+ * share of it in the returned loss value (1/world).  loss/parts are this shard's ADDITIVE share: their sum over the
+ * shards is the loss of the whole batch, and the sum over the shards of the gradients is its gradient.  (ABI 3: the
+ * ray count moved from a host integer into batch_global[1].) */
 int rnb_loss_rnb_shard(const float* color_fine, const float* true_rgb, const float* mask, const float* weight_sum,
                        const float* gradient_error, int32_t n_lights, int64_t B, int32_t color_depth, float igr_weight,
-                       float mask_weight, const float* mask_sum_global, int64_t B_global, float eik_share,
+                       float mask_weight, const float* batch_global, float eik_share,
                        float* loss, float* parts, float* d_color_fine, float* d_weight_sum, float* d_gradient_error,
                        rnb_stream_t stream);
 

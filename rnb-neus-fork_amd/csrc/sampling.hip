@@ -20,6 +20,10 @@ constexpr int kMaxNew = 64;
 
 __device__ inline float sigmoidf_ref(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// The order torch.sort uses: NaN compares greater than every number (and equal to NaN).  A strict weak order on ALL
+// floats, so the rank-count merge below writes every output slot exactly once whatever the depths are.
+__device__ inline bool lt_total(float a, float b) { return a < b || (a == a && b != b); }
+
 // z[b,j] = near + (far-near)*linspace(0,1,n)[j]  (+ (t_rand-0.5)*2/n) ; pts = o + d*z
 __global__ void z_init_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                               const float* __restrict__ near, const float* __restrict__ far,
@@ -75,8 +79,7 @@ __global__ __launch_bounds__(64) void up_sample_kernel(UpArgs a) {
     z[j] = zz;
     float s;
     if (a.gather_index != nullptr) {
-      // clamped: with NaN depths the merge below leaves slots of sort_index unwritten (every comparison false), and a
-      // stray index must not become a stray address — the reference yields NaNs there, not a fault
+      // clamped: the index comes from caller memory through the per-step C entry points
       const int idx = min(max(a.gather_index[b * n + j], 0), n - 1);
       s = idx < a.n_old ? a.sdf_old[b * a.n_old + idx] : a.sdf_new[b * (n - a.n_old) + (idx - a.n_old)];
     } else {
@@ -136,10 +139,10 @@ __global__ __launch_bounds__(64) void up_sample_kernel(UpArgs a) {
   // inverse-CDF sampling at u = linspace(0.5/n_new, 1-0.5/n_new, n_new); searchsorted(right=True)
   if (lane < n_new) {
     const float u = linspace_at((float)(0.5 / (double)n_new), (float)(1.0 - 0.5 / (double)n_new), n_new, lane);
-    int lo = 0, hi = n;                 // first index with cdf[idx] > u
-    while (lo < hi) {
+    int lo = 0, hi = n;                 // first index with cdf[idx] > u; `!(c > u)` as ATen's upper bound writes it,
+    while (lo < hi) {                   // so a NaN CDF (diverged model) sends the search right: ind = n, new_z = NaN
       const int mid = (lo + hi) >> 1;
-      if (cdf[mid] <= u) lo = mid + 1; else hi = mid;
+      if (!(cdf[mid] > u)) lo = mid + 1; else hi = mid;
     }
     const int ind = lo;
     const int below = max(ind - 1, 0);
@@ -159,25 +162,34 @@ __global__ __launch_bounds__(64) void up_sample_kernel(UpArgs a) {
     }
   }
   __syncthreads();
-  // stable merge of the sorted old depths with the new ones (== torch.sort over cat[z, new_z])
+  // stable merge of the sorted old depths with the new ones (== torch.sort over cat[z, new_z]) by rank counting under
+  // lt_total: old depth j lands at j + #{new < it}, new depth k at #{old <= it} + #{new before it} — a permutation of
+  // 0..nt-1 for ANY depths sorted under that order, NaNs included (they go last, as torch.sort puts them).  The row is
+  // pre-filled first, so that even depths that violate the sortedness precondition (caller memory through the per-step
+  // entry point) leave no slot of z_out / sort_index unwritten.
   const int nt = n + n_new;
+  for (int j = lane; j < nt; j += 64) {
+    a.z_out[b * nt + j] = __builtin_nanf("");
+    if (a.sort_index) a.sort_index[b * nt + j] = 0;
+  }
+  __syncthreads();
   for (int j = lane; j < n; j += 64) {
     const float zz = z[j];
     int cnt = 0;
-    for (int k = 0; k < n_new; ++k) cnt += nz[k] < zz ? 1 : 0;
+    for (int k = 0; k < n_new; ++k) cnt += lt_total(nz[k], zz) ? 1 : 0;
     const int pos = j + cnt;
     a.z_out[b * nt + pos] = zz;
     if (a.sort_index) a.sort_index[b * nt + pos] = j;
   }
   if (lane < n_new) {
     const float v = nz[lane];
-    int lo = 0, hi = n;                 // number of old depths <= v
+    int lo = 0, hi = n;                 // number of old depths <= v (total order)
     while (lo < hi) {
       const int mid = (lo + hi) >> 1;
-      if (z[mid] <= v) lo = mid + 1; else hi = mid;
+      if (!lt_total(v, z[mid])) lo = mid + 1; else hi = mid;
     }
     int cnt = lo;
-    for (int k = 0; k < n_new; ++k) cnt += (nz[k] < v || (nz[k] == v && k < lane)) ? 1 : 0;
+    for (int k = 0; k < n_new; ++k) cnt += (lt_total(nz[k], v) || (!lt_total(v, nz[k]) && k < lane)) ? 1 : 0;
     a.z_out[b * nt + cnt] = v;
     if (a.sort_index) a.sort_index[b * nt + cnt] = n + lane;
   }
@@ -190,7 +202,7 @@ __global__ void gather_sdf_kernel(const float* __restrict__ sdf_old, const float
   const int nt = n + n_new;
   if (i >= B * nt) return;
   const int64_t b = i / nt;
-  const int idx = min(max(index[i], 0), nt - 1);   // (see up_sample_kernel: NaN depths can leave index slots unwritten)
+  const int idx = min(max(index[i], 0), nt - 1);   // clamped: the index comes from caller memory
   out[i] = idx < n ? sdf_old[b * n + idx] : sdf_new[b * n_new + (idx - n)];
 }
 

@@ -22,18 +22,19 @@ __device__ inline double block_sum(double v, double* red) {
 // loss = L1(color_fine - true_rgb | mask) / (mask_sum * n_lights) + igr_w * gradient_error
 //        + mask_w * BCE(clip(weight_sum, 1e-3, 1 - 1e-3), mask)                      (exp_runner.py:241-258)
 // loss[0]; parts[0..2] = color_loss, eikonal_loss, mask_loss; d* = d loss / d input.
-// Shard form (msum_global != nullptr): normalisers of the WHOLE data-parallel batch, see rnb_loss_rnb_shard.
+// Shard form (batch_global != nullptr): normalisers of the WHOLE data-parallel batch, see rnb_loss_rnb_shard.
 __global__ __launch_bounds__(1024) void rnb_loss_kernel(const float* __restrict__ color, const float* __restrict__ rgb,
                                                         const float* __restrict__ mask, const float* __restrict__ wsum,
                                                         const float* __restrict__ gerr, int L, int64_t B, int Cd,
                                                         float igr_w, float mask_w,
-                                                        const float* __restrict__ msum_global, int64_t B_global,
-                                                        float eik_share, float* __restrict__ loss,
+                                                        const float* __restrict__ batch_global, float eik_share, float* __restrict__ loss,
                                                         float* __restrict__ parts,
                                                         float* __restrict__ dcolor, float* __restrict__ dwsum,
                                                         float* __restrict__ dgerr) {
   __shared__ double red[16];
   const int tid = threadIdx.x, nt = blockDim.x;
+  // rays of the whole batch: from the collective in the shard form (batch_global = {mask count, ray count})
+  const float B_global = batch_global ? batch_global[1] : (float)B;
   // ---- mask sum and the BCE term -------------------------------------------------------------------
   double msum = 0.0, bce = 0.0;
   for (int64_t b = tid; b < B; b += nt) {
@@ -46,11 +47,11 @@ __global__ __launch_bounds__(1024) void rnb_loss_kernel(const float* __restrict_
     bce -= (double)(m * lx + (1.f - m) * l1x);
     const bool pass = w >= 1e-3f && w <= 1.f - 1e-3f;   // clip's sub-gradient (inclusive, like torch.clamp)
     const float d = (x - m) / fmaxf((1.f - x) * x, 1e-12f);
-    dwsum[b] = pass ? mask_w * d / (float)B_global : 0.f;
+    dwsum[b] = pass ? mask_w * d / B_global : 0.f;
   }
   msum = block_sum(msum, red);
   bce = block_sum(bce, red);
-  const float mask_sum = (msum_global ? msum_global[0] : (float)msum) + 1e-5f;   // fp32 `mask.sum() + 1e-5`
+  const float mask_sum = (batch_global ? batch_global[0] : (float)msum) + 1e-5f;   // fp32 `mask.sum() + 1e-5`
   const float inv = 1.f / (mask_sum * (float)L);
   // ---- masked L1 colour term -----------------------------------------------------------------------
   double l1 = 0.0;
@@ -110,24 +111,24 @@ RNB_API int rnb_loss_rnb(const float* color_fine, const float* true_rgb, const f
   if (n_lights < 1 || B < 1 || color_depth < 1) RNB_FAIL(RNB_E_INVALID, "rnb_loss_rnb: empty shape");
   hipLaunchKernelGGL(rnb_loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, color_fine, true_rgb, mask,
                      weight_sum, gradient_error, n_lights, B, color_depth, igr_weight, mask_weight,
-                     (const float*)nullptr, B, 1.f, loss, parts, d_color_fine, d_weight_sum, d_gradient_error);
+                     (const float*)nullptr, 1.f, loss, parts, d_color_fine, d_weight_sum, d_gradient_error);
   RNB_CHECK_LAUNCH();
   return RNB_OK;
 }
 
 RNB_API int rnb_loss_rnb_shard(const float* color_fine, const float* true_rgb, const float* mask,
                                const float* weight_sum, const float* gradient_error, int32_t n_lights, int64_t B,
-                               int32_t color_depth, float igr_weight, float mask_weight, const float* mask_sum_global,
-                               int64_t B_global, float eik_share, float* loss, float* parts, float* d_color_fine,
+                               int32_t color_depth, float igr_weight, float mask_weight, const float* batch_global,
+                               float eik_share, float* loss, float* parts, float* d_color_fine,
                                float* d_weight_sum, float* d_gradient_error, rnb_stream_t stream) {
   using namespace rnb;
   if (!color_fine || !true_rgb || !mask || !weight_sum || !gradient_error || !loss || !parts || !d_color_fine ||
-      !d_weight_sum || !d_gradient_error || !mask_sum_global)
+      !d_weight_sum || !d_gradient_error || !batch_global)
     RNB_FAIL(RNB_E_NULL, "rnb_loss_rnb_shard: NULL pointer");
-  if (n_lights < 1 || B < 1 || color_depth < 1 || B_global < B) RNB_FAIL(RNB_E_INVALID, "rnb_loss_rnb_shard: bad shape");
+  if (n_lights < 1 || B < 1 || color_depth < 1) RNB_FAIL(RNB_E_INVALID, "rnb_loss_rnb_shard: bad shape");
   hipLaunchKernelGGL(rnb_loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, color_fine, true_rgb, mask,
-                     weight_sum, gradient_error, n_lights, B, color_depth, igr_weight, mask_weight, mask_sum_global,
-                     B_global, eik_share, loss, parts, d_color_fine, d_weight_sum, d_gradient_error);
+                     weight_sum, gradient_error, n_lights, B, color_depth, igr_weight, mask_weight, batch_global,
+                     eik_share, loss, parts, d_color_fine, d_weight_sum, d_gradient_error);
   RNB_CHECK_LAUNCH();
   return RNB_OK;
 }

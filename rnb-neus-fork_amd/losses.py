@@ -9,26 +9,29 @@ forward launch also produces the three input gradients, so the backward is a sin
 chain of PyTorch ops on the same tensors gives the same numbers (tests/test_gpu_parity.py) — using this
 function instead is optional.  Device tensors only: there is no CPU path.
 
-Data parallel (`group=`): rays are sharded over the ranks, and the loss couples them through three batch-global
-scalars only: `mask_sum` (exp_runner.py:194), the BCE mean over B (exp_runner.py:251) and the eikonal
-normaliser (models/renderer.py:540; the renderer handles that one, `NeuSRenderer.set_data_parallel`).  With a
-group the mask count is all-reduced before the launch and every rank normalises its own numerators by the GLOBAL
-denominators, so the SUM over ranks of the per-rank gradients (what the renderer's backward all-reduces in its
-exact mode) is the gradient of the single-process loss on the whole batch; the returned loss value and parts are
-all-reduced too, i.e. every rank reports the loss of the whole batch."""
+Data parallel (`group=`): rays are sharded over the ranks, and the loss couples them through batch-global scalars
+only: `mask_sum` (exp_runner.py:194), the BCE mean over B (exp_runner.py:251) and the eikonal ratio's
+numerator and count (models/renderer.py:538-540).  With a group ONE 4-float all-reduce ahead of the launch carries
+all of them — the eikonal partial sums arrive on the `ExactDPToken` the renderer attached to `gradient_error`
+(`NeuSRenderer.set_data_parallel(exact=True)`) — and every rank normalises its own numerators by the GLOBAL
+denominators (the ray count is the all-reduced one, so unequal shards stay exact), so the SUM over ranks of the
+per-rank gradients (what the renderer's backward all-reduces in its exact mode) is the gradient of the
+single-process loss on the whole batch; the returned loss value and parts are all-reduced too (second, optional
+collective), i.e. every rank reports the loss of the whole batch.  The pairing is checked: `group=` on a render that
+was not made in exact mode raises, and so does a missing `group=` on one that was."""
 from __future__ import annotations
 
 import torch
 import torch.distributed as dist
 
 from . import native
-from .parallel import global_mask_count
+from .parallel import local_mask_count
 
 
 class _RnbLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, color_fine, weight_sum, gradient_error, true_rgb, mask, igr_weight, mask_weight, group,
-                report_global=True):
+                report_global=True, token=None):
         for name, t in (("color_fine", color_fine), ("weight_sum", weight_sum), ("true_rgb", true_rgb),
                         ("mask", mask)):
             if not t.is_cuda:
@@ -52,15 +55,30 @@ class _RnbLoss(torch.autograd.Function):
         d_color = torch.empty_like(color)
         d_ws = torch.empty_like(ws)
         d_ge = torch.empty_like(ge)
-        world = dist.get_world_size(group) if group is not None else 1
-        if world > 1:
-            # [sum(mask > 0.5), B] of the whole batch: one 2-float all-reduce ahead of the launch
-            cnt = global_mask_count(mk, mask_weight > 0.0, group)
-            B_global = B * world      # shards are equal by construction (parallel.shard_range)
+        if group is None and token is not None:
+            raise RuntimeError("rnb_loss: this render was made in exact data-parallel mode "
+                               "(NeuSRenderer.set_data_parallel(exact=True)): pass group=<the data-parallel group>, or "
+                               "switch the renderer to exact=False for per-rank normalisers")
+        if group is not None and token is None:
+            raise RuntimeError("rnb_loss(group=...) normalises by the whole data-parallel batch and needs a render made "
+                               "under grad by a renderer in exact data-parallel mode "
+                               "(NeuSRenderer.set_data_parallel(group, exact=True)); without it the gradient all-reduce "
+                               "would be a mean and every term scaled by 1/world")
+        if group is not None:
+            if token.group is not group and token.group != group:
+                raise RuntimeError("rnb_loss: `group` differs from the renderer's data-parallel group")
+            world = dist.get_world_size(group)
+            # ONE collective for every batch-global normaliser: [eikonal numerator, eikonal count, sum(mask > 0.5), rays]
+            glob = torch.cat([token.gerr_partial, local_mask_count(mk, mask_weight > 0.0)])
+            dist.all_reduce(glob, op=dist.ReduceOp.SUM, group=group)
+            token.gerr_den_global.copy_(glob[1:2] + 1e-5)       # what the renderer's backward divides by
+            ge_global = (glob[0:1] / token.gerr_den_global).contiguous()
+            batch_global = glob[2:4].contiguous()
+            token.paired = True
             with native.on_device(color) as stream:
                 native.check(lib.rnb_loss_rnb_shard(
-                    native.ptr(color), native.ptr(rgb), native.ptr(mk), native.ptr(ws), native.ptr(ge), L, B, Cd,
-                    float(igr_weight), float(mask_weight), native.ptr(cnt), B_global, 1.0 / world, native.ptr(loss),
+                    native.ptr(color), native.ptr(rgb), native.ptr(mk), native.ptr(ws), native.ptr(ge_global), L, B, Cd,
+                    float(igr_weight), float(mask_weight), native.ptr(batch_global), 1.0 / world, native.ptr(loss),
                     native.ptr(parts), native.ptr(d_color), native.ptr(d_ws), native.ptr(d_ge), stream))
             # the loss VALUE of the whole batch on every rank (reporting only; gradients are already global-normalised).
             # report_global=False keeps this rank's additive share instead and saves the collective.
@@ -86,14 +104,17 @@ class _RnbLoss(torch.autograd.Function):
                                "backward; re-run the forward)")
         ctx.grads = None
         out = torch._foreach_mul(list(grads), g_loss)      # one multi-tensor launch
-        return out[0], out[1], out[2], None, None, None, None, None, None
+        return out[0], out[1], out[2], None, None, None, None, None, None, None
 
 
 def rnb_loss(render_out, true_rgb, mask, igr_weight=0.1, mask_weight=0.1, group=None, report_global=True):
     """exp_runner.py:229-258 (`train_rnb`).  Returns `(loss, {"color_loss", "eikonal_loss", "mask_loss"})`.
     `group`: the data-parallel process group whose ranks share one global batch (see the module docstring).
     `report_global` (with a group): True returns the loss VALUE of the whole batch on every rank (one more 4-float
-    all-reduce per step); False returns this rank's additive share of it — the gradients are identical either way."""
+    all-reduce per step); False returns this rank's additive share of it — the gradients are identical either way.
+    `render_out["gradient_error"]` stays the shard-local value; `parts["eikonal_loss"]` is (this rank's share of) the
+    global one."""
     loss, parts = _RnbLoss.apply(render_out["color_fine"], render_out["weight_sum"], render_out["gradient_error"],
-                                 true_rgb, mask, igr_weight, mask_weight, group, report_global)
+                                 true_rgb, mask, igr_weight, mask_weight, group, report_global,
+                                 getattr(render_out["gradient_error"], "rnb_dp_token", None))
     return loss, {"color_loss": parts[0], "eikonal_loss": parts[1], "mask_loss": parts[2]}

@@ -7,7 +7,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librnbneus_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_LIN = 16
 
 MODE_CORE = 0
@@ -116,7 +116,7 @@ _SIGNATURES = {
                                C.c_int32, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                C.c_void_p, C.c_void_p]),
     "rnb_loss_rnb_shard": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64,
-                                     C.c_int32, C.c_float, C.c_float, C.c_void_p, C.c_int64, C.c_float, C.c_void_p,
+                                     C.c_int32, C.c_float, C.c_float, C.c_void_p, C.c_float, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rnb_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double,
                                 C.c_double, C.c_double, C.c_double, C.c_int64, C.c_void_p]),

@@ -45,13 +45,19 @@ def allreduce_sum_(flat: torch.Tensor, group=None):
     return flat
 
 
+def local_mask_count(mask: torch.Tensor, use_mask: bool) -> torch.Tensor:
+    """This shard's [sum(mask > 0.5), rays] as a 2-float device tensor (the summands of `global_mask_count`;
+    `rnb_loss(group=)` all-reduces them together with the eikonal partial sums in one collective)."""
+    mk = mask.reshape(-1)
+    n = torch.tensor(float(mk.numel()), device=mk.device)
+    return torch.stack([(mk > 0.5).sum().to(torch.float32) if use_mask else n, n])
+
+
 def global_mask_count(mask: torch.Tensor, use_mask: bool, group=None) -> torch.Tensor:
     """[sum(mask > 0.5), rays] of the WHOLE data-parallel batch as a 2-float tensor on the mask's device: the
     normalisers of the colour term (exp_runner.py:194, mask_sum) and of the BCE mean (exp_runner.py:251).  With
     `use_mask` False (mask_weight == 0, exp_runner.py:233-236) every ray counts.  One tiny all-reduce."""
-    mk = mask.reshape(-1)
-    n = torch.tensor(float(mk.numel()), device=mk.device)
-    cnt = torch.stack([(mk > 0.5).sum().to(torch.float32) if use_mask else n, n])
+    cnt = local_mask_count(mask, use_mask)
     dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=group)
     return cnt
 

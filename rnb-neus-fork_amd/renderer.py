@@ -12,10 +12,13 @@ Differences that are deliberate and documented in DESIGN.md:
     may be supplied explicitly (`t_rand=`) so that tests can feed the oracle the same randomness.
   * with data parallelism enabled (`set_data_parallel`) the backward all-reduces the flat gradient
     buffer over RCCL before returning.  Default `exact=True`: the ranks hold contiguous shards of ONE global
-    batch; the eikonal term's two batch-global sums (models/renderer.py:538-540) are all-reduced in the
-    forward, `rnb_loss(..., group=)` does the same for `mask_sum` / the BCE mean, and the gradient
-    all-reduce is a SUM, so a G-rank step equals the single-process step on the whole batch.  `exact=False`
-    is the DDP convention (per-rank normalisers, mean of the per-rank gradients).
+    batch; the render returns its shard's eikonal sums (models/renderer.py:538-540) on a token attached to
+    `gradient_error`, `rnb_loss(..., group=)` all-reduces them TOGETHER with `mask_sum` / the ray count in one
+    4-float collective, and the gradient all-reduce is a SUM, so a G-rank step equals the single-process step
+    on the whole batch.  Forwards are never collective (a rank-0-only validation render cannot desynchronise
+    the ranks); the collectives of a step are the loss's and the backward's, and the backward raises if the
+    loss it is driven by was not `rnb_loss(..., group=)`.  `exact=False` is the DDP convention (per-rank
+    normalisers, mean of the per-rank gradients, any loss).
   * kernel / arithmetic variants (`set_variant`): explicit bits of the model descriptor, no environment
     variables (bf16 sweeps for BASELINE config 5, deterministic reductions, A/B tuning knobs).
 """
@@ -30,6 +33,16 @@ import torch.distributed as dist
 from . import native, runtime
 from .fields import _mlp_struct, model_desc
 from .parallel import allreduce_mean_, allreduce_sum_
+
+
+class ExactDPToken:
+    """Travels on `out["gradient_error"]` of a render made under grad in exact data-parallel mode.  Carries this
+    shard's eikonal (numerator, count) to `rnb_loss(..., group=)`, which all-reduces them with the mask counts, writes
+    the global denominator into `gerr_den_global` (read by the native backward) and marks the token paired."""
+
+    def __init__(self, group, gerr_partial, gerr_den_global):
+        self.group, self.gerr_partial, self.gerr_den_global = group, gerr_partial, gerr_den_global
+        self.paired = False
 
 _OUT_KEYS = ("color_fine", "s_val", "cdf_fine", "weight_sum", "weight_max", "gradients", "weights",
              "gradient_error", "inside_sphere")
@@ -84,37 +97,47 @@ class _FinePass(torch.autograd.Function):
             setattr(args, k, out[k].data_ptr())
         args.sdf = extras["sdf"].data_ptr() if "sdf" in extras else None
         args.sampled_albedo = extras["sampled_albedo"].data_ptr() if "sampled_albedo" in extras else None
-        exact_dp = renderer.dp_group is not None and renderer.dp_exact
+        # exact data parallel, training render: keep this shard's eikonal (numerator, count); the loss all-reduces them
+        # (no collective here: forwards stay local, forward-only renders return the shard-local gradient_error)
+        exact_dp = renderer.dp_group is not None and renderer.dp_exact and not (flags & native.FLAG_FORWARD_ONLY)
+        ctx.dp_token = None
         if exact_dp:
             keep["gerr_partial"] = torch.empty(2, **f32)
+            keep["gerr_den_global"] = torch.empty(1, **f32)
             args.gerr_partial = keep["gerr_partial"].data_ptr()
+            args.gerr_den_global = keep["gerr_den_global"].data_ptr()
+            ctx.dp_token = ExactDPToken(renderer.dp_group, keep["gerr_partial"], keep["gerr_den_global"])
         with native.on_device(dev) as stream:
             native.check(lib.rnb_render_fwd(C.byref(desc), native.ptr(call["packed"]), C.byref(args), native.ptr(ws),
                                             ws.numel(), stream))
-        if exact_dp:
-            # eikonal term of the WHOLE batch (renderer.py:538-540): all-reduce this shard's (numerator, count)
-            part = keep["gerr_partial"]
-            dist.all_reduce(part, op=dist.ReduceOp.SUM, group=renderer.dp_group)
-            keep["gerr_den_global"] = (part[1:2] + 1e-5).contiguous()
-            out["gradient_error"].copy_((part[0:1] / keep["gerr_den_global"]).reshape(()))
-            args.gerr_den_global = keep["gerr_den_global"].data_ptr()
         ctx.renderer, ctx.call, ctx.args, ctx.keep, ctx.ws, ctx.out = renderer, call, args, keep, ws, out
+        # the descriptor AS OF this forward: the backward must carve the workspace with the layout the forward wrote,
+        # whatever set_variant() did in between
+        ctx.desc = native.ModelDesc.from_buffer_copy(desc)
+        ctx.dp = (renderer.dp_group, renderer.dp_exact)
         ctx.n_leaves = len(leaves)
         ctx.mark_non_differentiable(out["inside_sphere"])
         # outputs the loss does not touch arrive as None in backward (no zero tensors are materialised;
         # the native backward treats a NULL cotangent as zero)
         ctx.set_materialize_grads(False)
         renderer.last_extras = extras
+        renderer._last_dp_token = ctx.dp_token
         return tuple(out[k] for k in _OUT_KEYS)
 
     @staticmethod
     def backward(ctx, *gouts):
         lib = native.load()
-        renderer, call, desc = ctx.renderer, ctx.call, ctx.renderer.desc
+        renderer, call, desc = ctx.renderer, ctx.call, ctx.desc
+        dp_group, dp_exact = ctx.dp
         if ctx.ws is None:
             raise RuntimeError("NeuSRenderer: backward called a second time on the same render (the saved per-point "
                                "state is released after the first backward, retain_graph is not supported); re-run "
                                "the forward")
+        if ctx.dp_token is not None and not ctx.dp_token.paired:
+            raise RuntimeError("NeuSRenderer: exact data-parallel mode (set_data_parallel(exact=True)) needs the loss to "
+                               "be rnb_loss(..., group=<the data-parallel group>): it all-reduces the batch-global "
+                               "normalisers this backward divides by.  Use set_data_parallel(exact=False) with any "
+                               "other loss (DDP mean of per-rank gradients)")
         dev = ctx.ws.device
         g = dict(zip(_OUT_KEYS, gouts))
         keepalive = []
@@ -148,13 +171,13 @@ class _FinePass(torch.autograd.Function):
             native.check(lib.rnb_weightnorm_bwd(C.byref(desc), C.byref(sp), C.byref(cp) if cp is not None else None,
                                                 native.ptr(packed_grad), C.byref(sg),
                                                 C.byref(cg) if cg is not None else None, stream))
-        if renderer.dp_group is not None:
+        if dp_group is not None:
             # the one exchange step of the path: the flat gradient buffer over xGMI (RCCL).  exact: the per-rank
             # losses are additive shares of the whole batch's loss -> SUM; otherwise the DDP mean.
-            if renderer.dp_exact:
-                allreduce_sum_(flat, renderer.dp_group)
+            if dp_exact:
+                allreduce_sum_(flat, dp_group)
             else:
-                allreduce_mean_(flat, renderer.dp_group)
+                allreduce_mean_(flat, dp_group)
         ctx.ws = None
         grads = []
         for leaf in call["leaves"]:
@@ -191,8 +214,12 @@ class NeuSRenderer:
     # ------------------------------------------------------------------ data parallel
     def set_data_parallel(self, group=None, enabled=True, exact=True):
         """One process per GPU, each rendering its contiguous shard of a global ray batch; the backward
-        all-reduces the flat gradient buffer over `group`.  exact=True (default): large-batch semantics, see the
-        module docstring (pair it with `rnb_loss(..., group=group)`); exact=False: DDP mean of per-rank losses."""
+        all-reduces the flat gradient buffer over `group` — BACKWARDS are collective, forwards never are (a
+        forward-only / no_grad render on one rank alone is fine and returns the shard-local `gradient_error`).
+        exact=True (default): large-batch semantics, see the module docstring; the loss MUST then be
+        `rnb_loss(..., group=group)` — the pairing is checked both ways (the backward raises otherwise, and so does
+        `rnb_loss(group=)` on a render that was not made in exact mode).  exact=False: DDP mean of per-rank
+        gradients, per-rank normalisers, any loss (`rnb_loss` without a group, or the reference's torch ops)."""
         self.dp_group = (group if group is not None else dist.group.WORLD) if enabled else None
         self.dp_exact = bool(exact)
 
@@ -292,7 +319,12 @@ class NeuSRenderer:
                     cos_anneal_ratio=cos_anneal_ratio, flags=flags, packed=packed, leaves=leaves,
                     train_color=train_color, want_extras=self.want_extras)
         outs = _FinePass.apply(self, call, *leaves)
-        return dict(zip(_OUT_KEYS, outs))
+        out = dict(zip(_OUT_KEYS, outs))
+        token = getattr(self, "_last_dp_token", None)
+        self._last_dp_token = None
+        if token is not None:
+            out["gradient_error"].rnb_dp_token = token
+        return out
 
     # ------------------------------------------------------------------ reference API
     def render(self, rays_o, rays_d, near, far, perturb_overwrite=-1, background_rgb=None, cos_anneal_ratio=0.0,

@@ -9,6 +9,14 @@ from oracle import rnb_oracle as O
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
+# Calibrated gradient bounds are `min(GRAD_CAP, max(1e-4, 3 * rel32s))` (tests/test_gpu_parity.py).  A tensor whose
+# fp32 REFERENCE gradient is further than GRAD_CAP / 3 from the reference's fp64 gradient is something fp32 cannot
+# resolve: it is not a parity target and must be listed here explicitly (fixture -> tensor names), otherwise the
+# fixture refuses to load.  No committed fixture needs an entry (largest rel32s: 2.6e-3, tiny_warmup_sharp
+# dev.variance).
+GRAD_CAP = 1e-2
+UNRESOLVED_BY_FP32 = {}
+
 
 def case_names():
     """Renderer fixtures (tiny_* / full_*); raygen_* fixtures have their own loader below."""
@@ -74,6 +82,14 @@ class Golden:
         self.grad64_stride = {k[14:]: int(z[k]) for k in z.files if k.startswith("grad64_stride.")}
         self.rel32 = {k[6:]: float(z[k]) for k in z.files if k.startswith("rel32.")}
         self.rel32s = {k[7:]: float(z[k]) for k in z.files if k.startswith("rel32s.")}
+        dropped = set(UNRESOLVED_BY_FP32.get(name, ()))
+        for k, r in self.rel32s.items():
+            if r > GRAD_CAP / 3.0 and k not in dropped:
+                raise ValueError(f"fixture {name}: the fp32 reference's own gradient of {k} is {r:.2e} (rel-L2) from "
+                                 f"its fp64 run — beyond GRAD_CAP / 3 = {GRAD_CAP / 3.0:.1e}; list it in "
+                                 "UNRESOLVED_BY_FP32 to drop it explicitly")
+        for k in dropped:
+            self.grad64.pop(k, None)
         self.weights_from = str(z["meta.weights_from"]) if "meta.weights_from" in z.files else None
         self.has_weights = any(k.startswith("w.") for k in z.files) or self.weights_from is not None
         self.wsum = {k[5:]: z[k] for k in z.files if k.startswith("wsum.")}

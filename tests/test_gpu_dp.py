@@ -1,9 +1,10 @@
-"""Data-parallel path on the device: two ranks (sharing the one GPU of the test box, gloo transport) render
-their shards of one ray batch with `set_data_parallel()`.  exact=True (default): every rank ends up with the
-gradient — and the loss value — of the SINGLE-PROCESS step on the whole batch (the three batch-global normalisers of
-SURVEY 8e are all-reduced: mask_sum, the BCE mean's B, the eikonal ratio's two sums).  exact=False: the DDP
-convention, mean of the ranks' local gradients.  On the 8-GPU node the same code runs one rank per GPU over RCCL
-(bench.py)."""
+"""Data-parallel path on the device: two ranks render their shards of one ray batch with `set_data_parallel()`.
+exact=True (default): every rank ends up with the gradient — and the loss value — of the SINGLE-PROCESS step on the
+whole batch (the batch-global normalisers of SURVEY 8e travel in ONE 4-float all-reduce inside `rnb_loss(group=)`:
+the eikonal ratio's two sums, mask_sum, the ray count).  exact=False: the DDP convention, mean of the ranks' local
+gradients.  Transport: on the one-GPU test box the two ranks share device 0 over gloo; with >= 2 GPUs visible (the
+driver's 8-GPU node) the same workers run one rank per GPU over the `nccl` backend = RCCL
+(`test_exact_data_parallel_over_rccl`, skipped on one-GPU boxes)."""
 import os
 import socket
 
@@ -21,14 +22,26 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, q):
+def _init(rank, world, port, backend="gloo"):
+    """gloo: both ranks on device 0 (one-GPU box).  nccl: one rank per GPU over RCCL / xGMI."""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if backend == "nccl":
+        dev = torch.device("cuda", rank)
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dev = torch.device("cuda:0")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    return dev
+
+
+def _worker(rank, world, port, q):
+    dev = _init(rank, world, port)
     import rnb_neus_fork_amd as R
     from rnb_neus_fork_amd import parallel as P
     from oracle import rnb_oracle as O
-    dev = torch.device("cuda:0")
     mc = O.ModelConf(sdf=O.SDFConf(d_out=65, d_hidden=64), color=O.ColorConf(d_feature=64, d_hidden=64),
                      render=O.RenderConf(n_samples=16, n_importance=16))
     torch.manual_seed(0)
@@ -76,14 +89,11 @@ def test_two_rank_gradients_are_the_mean_of_local_gradients():
         assert differs > 1e-3, "the two shards should produce different local gradients"
 
 
-def _exact_worker(rank, world, port, q):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+def _exact_worker(rank, world, port, q, backend="gloo"):
+    dev = _init(rank, world, port, backend)
     import rnb_neus_fork_amd as R
     from rnb_neus_fork_amd import parallel as P
     from oracle import rnb_oracle as O
-    dev = torch.device("cuda:0")
     mc = O.ModelConf(sdf=O.SDFConf(d_out=65, d_hidden=64), color=O.ColorConf(d_feature=64, d_hidden=64),
                      render=O.RenderConf(n_samples=16, n_importance=16))
     torch.manual_seed(0)
@@ -108,11 +118,41 @@ def _exact_worker(rank, world, port, q):
         loss, parts = R.rnb_loss(out, b["true_rgb"], b["mask"], group=loss_group)
         loss.backward()
         torch.cuda.synchronize()
-        return (torch.cat([x.grad.reshape(-1) for x in leaves]).clone(), float(loss), float(out["gradient_error"]),
+        return (torch.cat([x.grad.reshape(-1) for x in leaves]).clone(), float(loss), float(parts["eikonal_loss"]),
                 ren.last_z_vals.clone())
 
     g_single, l_single, ge_single, z_single = run(full, False, None)         # the whole batch in one process
+    # between the two steps ONLY RANK 0 renders (forward-only, as a rank-0 validation would): forwards are not
+    # collective, so this must neither hang nor pair with the other rank's next all-reduce
+    ren.set_data_parallel(enabled=True, exact=True)
+    if rank == 0:
+        with torch.no_grad():
+            ev = ren.render_rnb(mine["rays_o"], mine["rays_d"], mine["near"], mine["far"], mine["lights_dir"],
+                                cos_anneal_ratio=1.0, t_rand=mine["t_rand"])
+        assert not hasattr(ev["gradient_error"], "rnb_dp_token") and bool(torch.isfinite(ev["gradient_error"]))
     g_dp, l_dp, ge_dp, z_dp = run(mine, True, dist.group.WORLD)            # my shard, exact data parallel
+    # the pairing is checked both ways: exact render + loss without group, and group= on a non-exact render
+    pairing_ok = True
+    out = ren.render_rnb(mine["rays_o"], mine["rays_d"], mine["near"], mine["far"], mine["lights_dir"],
+                         cos_anneal_ratio=1.0, t_rand=mine["t_rand"])
+    try:
+        R.rnb_loss(out, mine["true_rgb"], mine["mask"])
+        pairing_ok = False
+    except RuntimeError:
+        pass
+    try:
+        O.rnb_loss(out, mine["true_rgb"], mine["mask"])[0].backward()      # the reference's torch ops: unpaired
+        pairing_ok = False
+    except RuntimeError:
+        pass
+    ren.set_data_parallel(enabled=True, exact=False)
+    out = ren.render_rnb(mine["rays_o"], mine["rays_d"], mine["near"], mine["far"], mine["lights_dir"],
+                         cos_anneal_ratio=1.0, t_rand=mine["t_rand"])
+    try:
+        R.rnb_loss(out, mine["true_rgb"], mine["mask"], group=dist.group.WORLD)
+        pairing_ok = False
+    except RuntimeError:
+        pass
     lo = rank * (24 // world)
     same_samples = bool(torch.equal(z_dp, z_single[lo:lo + 24 // world]))
     rel = float((g_dp - g_single).norm() / g_single.norm())
@@ -125,7 +165,7 @@ def _exact_worker(rank, world, port, q):
     R.rnb_loss(out, mine["true_rgb"], mine["mask"])[0].backward()
     g_ddp = torch.cat([x.grad.reshape(-1) for x in leaves])
     rel_ddp = float((g_ddp - g_single).norm() / g_single.norm())
-    q.put((rank, rel, abs(l_dp - l_single), abs(ge_dp - ge_single), same_samples, rel_ddp))
+    q.put((rank, rel, abs(l_dp - l_single), abs(ge_dp - ge_single), same_samples and pairing_ok, rel_ddp))
     dist.destroy_process_group()
 
 
@@ -141,20 +181,44 @@ def test_exact_data_parallel_step_equals_the_single_process_step():
     for p in procs:
         p.join(timeout=60)
     for rank, rel, dl, dge, same_samples, rel_ddp in res:
-        assert same_samples, "a shard must sample exactly the depths the whole batch samples for those rays"
+        assert same_samples, ("a shard must sample exactly the depths the whole batch samples for those rays, and the "
+                              "loss / renderer pairing checks must raise")
         assert rel <= 1e-5, f"rank {rank}: exact-DP gradient differs from the whole-batch gradient by {rel:.2e}"
         assert dl <= 2e-6 and dge <= 1e-7, f"rank {rank}: loss / gradient_error differ ({dl:.2e}, {dge:.2e})"
         assert rel_ddp > 1e-3, "with unequal mask counts the DDP mean must differ from the whole-batch gradient"
     print(f"exact DP vs single process: gradient rel-L2 {max(r[1] for r in res):.2e}; DDP-mean convention: {res[0][5]:.2e}")
 
 
+def _run_exact(backend):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_exact_worker, args=(r, 2, port, q, backend)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    return res
+
+
+def test_exact_data_parallel_over_rccl():
+    """The same exact-DP check with one rank per GPU over the `nccl` backend (RCCL over xGMI): the first RCCL call this
+    code makes is here, in a test, not in the scaling bench.  Needs two GPUs: skipped on the one-GPU boxes, runs on the
+    driver's 8-GPU node.  `device_count()` does not initialise the GPU in this (parent) process."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (one rank per GPU over RCCL)")
+    for rank, rel, dl, dge, ok, rel_ddp in _run_exact("nccl"):
+        assert ok
+        assert rel <= 1e-5, f"rank {rank}: exact-DP gradient over RCCL differs from the whole-batch gradient by {rel:.2e}"
+        assert dl <= 2e-6 and dge <= 1e-7
+        assert rel_ddp > 1e-3
+
+
 def _grid_worker(rank, world, port, q):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = _init(rank, world, port)
     import rnb_neus_fork_amd as R
     from oracle import rnb_oracle as O
-    dev = torch.device("cuda:0")
     mc = O.ModelConf(sdf=O.SDFConf(d_out=65, d_hidden=64), color=O.ColorConf(d_feature=64, d_hidden=64),
                      render=O.RenderConf(n_samples=16, n_importance=16))
     torch.manual_seed(0)

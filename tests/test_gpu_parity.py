@@ -24,6 +24,21 @@ pytestmark = pytest.mark.gpu
 
 K_OUT, FLOOR_OUT = 3.0, 2e-6     # outputs: factor over the fp32 reference's own max error + a few fp32 ulps
 K_GRAD = 3.0                     # gradients: factor over the fp32 reference's own relative L2 error
+GRAD_CAP = 1e-2                  # ... capped: a gradient the fp32 reference resolves to worse than GRAD_CAP / K_GRAD
+                                 # is not a parity target (tests/golden_util.py refuses such a fixture at load time)
+
+
+def _grad_bound(rel32s):
+    return min(GRAD_CAP, max(1e-4, K_GRAD * rel32s))
+
+
+def _assert_has_surface(out, dvariance=None):
+    """Non-degeneracy guard: the rendered scene has a surface (otherwise weights, CDFs and colours are ~0 and every
+    absolute bound passes for zeros) and the variance gradient is resolved."""
+    assert float(out["weight_sum"].mean()) > 0.3, "degenerate scene: rays do not hit a surface"
+    assert float(out["weights"].max()) > 1e-2, "degenerate scene: no sample carries weight"
+    if dvariance is not None:
+        assert float(dvariance.abs().max()) > 1e-6, "degenerate scene: d loss / d variance vanishes"
 
 CASES = case_names()
 TINY = [c for c in CASES if c.startswith("tiny")]
@@ -122,21 +137,43 @@ def _up_sample_step(R, g, st):
     return new_z.cpu(), inds.cpu(), z_out.cpu(), sidx.cpu()
 
 
+def _assert_sort_index_equal_up_to_ties(sidx, new_z, z_out, st, what):
+    """The merged order must equal the reference's traced `torch.sort` index — except inside a run of BIT-EQUAL depths.
+    The reference calls torch.sort without stable=True (models/renderer.py:183); when a new depth equals an old one
+    exactly (3 of 2,048 rows of the B = 512 fixture: the inverse-CDF lerp lands on a bin edge), the order of the two
+    equal keys is whatever ATen's unstable CPU sort (a vectorised quicksort whose code path depends on the host ISA)
+    happens to produce — there the traced index is an artefact of the build container's CPU, not a property of the
+    reference.  The device merge is the stable order (old before new).  The two tied samples are the same point of
+    the ray, so either order carries the same SDF value.  Returns the number of rows that hold such a tie."""
+    ref = st["sort_index"]
+    diff = sidx != ref
+    tie = torch.zeros_like(diff)
+    for zz in (st["z_out"], z_out):          # a tie in the reference's depths or in the device's own
+        eq = zz[:, 1:] == zz[:, :-1]
+        tie[:, 1:] |= eq
+        tie[:, :-1] |= eq
+    assert not bool((diff & ~tie).any()), f"{what}: sort index differs outside runs of equal depths"
+    cat = torch.cat([st["z_in"], new_z], -1)  # what the device merged: the reference's old depths + its own new ones
+    assert torch.equal(torch.gather(cat, 1, sidx), z_out), f"{what}: z_out must be the depths permuted by sort_index"
+    assert torch.equal(sidx, torch.sort(cat, dim=1, stable=True).indices), f"{what}: the device merge is the stable order"
+    return int(diff.any(dim=1).sum())
+
+
 @pytest.mark.parametrize("name", CASES)
 def test_up_sample_step_indices_bit_exact(R, name):
     g = Golden(name)
-    worst = 0.0
+    worst, ties = 0.0, 0
     for i, st in enumerate(g.steps):
         new_z, inds, z_out, sidx = _up_sample_step(R, g, st)
         assert torch.equal(inds.long(), st["inds"]), f"step {i}: searchsorted indices differ"
-        assert torch.equal(sidx.long(), st["sort_index"]), f"step {i}: sort index differs"
+        ties += _assert_sort_index_equal_up_to_ties(sidx.long(), new_z, z_out, st, f"step {i}")
         # depths: same arithmetic except torch.sum's vectorised summation order and the device expf
         dz = (new_z - st["new_z"]).abs().max().item()
         worst = max(worst, dz)
         torch.testing.assert_close(new_z, st["new_z"], rtol=0, atol=2e-5)
         torch.testing.assert_close(z_out, st["z_out"], rtol=0, atol=2e-5)
         assert bool((z_out[:, 1:] >= z_out[:, :-1]).all()), "merged depths must be sorted"
-    print(f"{name}: max |new_z - ref| over steps = {worst:.3e}")
+    print(f"{name}: max |new_z - ref| over steps = {worst:.3e}; rows with an exact old/new depth tie: {ties}")
 
 
 def test_gather_sdf(R):
@@ -198,6 +235,7 @@ E2E_MIN = {    # name -> (min frac of z within 1e-4, min frac of rays with ident
     "full_main_sharp": (0.995, 0.95),       # 0.9967, 63/64
     "full_render_sharp": (0.996, 0.93),     # 0.9983, 31/32
     "full_warmup_geo": (0.995, 0.95),       # 0.9965, 63/64
+    "full_main_b512": (0.99, 0.85),         # round 3: measured below
 }
 E2E_DEFAULT = (1.0, 1.0)                    # tiny_*: every z within 1e-4 (max 9e-6), every index identical
 
@@ -280,6 +318,8 @@ def test_fine_pass_golden(R, name):
     loss = _loss(g, out, b)
     got_all = {k: out[k].detach().cpu().double() for k in g.out if k != "loss"}
     got_all["loss"] = loss.detach().cpu().double()
+    _assert_has_surface(g.out)       # the reference's own outputs: every fixture renders a surface
+    _assert_has_surface(out)
     worst_out = ("", 0.0)
     for k, ref32 in g.out.items():
         got = got_all[k]
@@ -309,7 +349,7 @@ def test_fine_pass_golden(R, name):
             assert float(mine.abs().max()) < 1e-8, k
             continue
         rel = float((mine - g64).norm()) / n64
-        bound = max(1e-4, K_GRAD * g.rel32s[k])
+        bound = _grad_bound(g.rel32s[k])
         if rel / bound > worst[1]:
             worst = (k, rel / bound, rel)
         assert rel <= bound, f"{k}: rel-L2 vs fp64 {rel:.3e} > {bound:.3e} (fp32 reference: {g.rel32s[k]:.3e})"
@@ -321,31 +361,31 @@ def test_fine_pass_golden(R, name):
             continue
         rel = float((mine - ref).double().norm() / ref.double().norm())
         # triangle inequality through the fp64 result: (K_GRAD + 1) x the fp32 reference's own error
-        assert rel <= max(2e-4, (1.0 + K_GRAD) * max(g.rel32.get(k, 0.0), g.rel32s.get(k, 0.0))), \
+        assert rel <= min(2.0 * GRAD_CAP, max(2e-4, (1.0 + K_GRAD) * max(g.rel32.get(k, 0.0), g.rel32s.get(k, 0.0)))), \
             f"{k}: rel-L2 vs the fp32 reference {rel:.3e}"
     print(f"FINE {name}: worst output error ratio hip/ref32 = {worst_out[1]:.2f} ({worst_out[0]}); worst gradient: "
           f"{worst[0]} rel-L2 vs fp64 {worst[2]:.2e} = {worst[1]:.2f} of its bound")
 
 
 def test_full_batch_512_matches_oracle(R):
-    """BASELINE config 2 shape (512 rays x (64+64), full-size nets): HIP vs the CPU oracle on the z_vals
-    the device sampled, outputs + a subset of parameter gradients."""
-    mc = O.ModelConf()
-    torch.manual_seed(0)
-    p = O.init_params(mc)
-    with torch.no_grad():   # leave the structured zero blocks of the geometric init
-        for k, v in p.items():
-            if k.endswith("weight_v") or k.endswith("bias"):
-                v.add_(0.02 * torch.randn(v.shape, generator=torch.Generator().manual_seed(zlib.crc32(k.encode()) % 1000)))
-        p["dev.variance"].fill_(0.45)
+    """BASELINE config 2 at its real shape END TO END (device sampling + fine pass + loss + backward): 512 rays x
+    (64+64), full-size nets in the sharpened state of the reference-generated fixtures (a model that HAS a surface),
+    against the CPU oracle in fp64 on the z_vals the device sampled.  (The reference's own run of this shape on its own
+    z_vals is the fixture `full_main_b512`, covered by test_fine_pass_golden / test_up_sample_step_indices_bit_exact /
+    test_sample_rays_end_to_end.)  Non-degeneracy is asserted first: a scene without a surface would pass any
+    absolute bound."""
+    g = Golden("full_main_b512")
+    mc = g.mc
+    p = g.params()
     sdf, dev, col, ren = R.build_from_named_params(mc, p, _dev())
-    batch = O.synthetic_batch(512, seed=21, step=3, warmup=False)
+    batch = O.synthetic_batch(512, seed=22, step=7, warmup=False)
     b = {k: v.to(_dev()) for k, v in batch.items()}
     out = ren.render_rnb(b["rays_o"], b["rays_d"], b["near"], b["far"], b["lights_dir"], cos_anneal_ratio=1.0,
                          t_rand=b["t_rand"])
     loss = O.rnb_loss(out, b["true_rgb"], b["mask"])[0]
     loss.backward()
     torch.cuda.synchronize()
+    _assert_has_surface(out, dev.variance.grad)
     z = ren.last_z_vals.cpu()
     torch.set_num_threads(16)
     # ground truth in float64 (bias gradients are sums of 65,536 signed terms: an fp32 CPU sum is itself
@@ -356,30 +396,33 @@ def test_full_batch_512_matches_oracle(R):
                        cos_anneal_ratio=1.0, z_vals=z.double())
     ref_loss = O.rnb_loss(ref, b64["true_rgb"], b64["mask"])[0]
     ref_loss.backward()
-    for k in ("color_fine", "weights", "weight_sum", "gradients", "cdf_fine", "gradient_error"):
-        # normals are 8-layer products of 256-wide fp32 dot products: a few 1e-5 absolute on O(1) values
-        torch.testing.assert_close(out[k].detach().cpu().double(), ref[k].detach().double(), rtol=2e-4,
-                                   atol=5e-5 if k == "gradients" else 2e-5, msg=lambda m: f"{k}: {m}")
-    torch.testing.assert_close(loss.detach().cpu().double(), ref_loss.detach(), rtol=1e-4, atol=1e-5)
-    named = {("sdf." + k): v for k, v in sdf.named_parameters()}
-    named["dev.variance"] = dev.variance
-    named.update({("color." + k): v for k, v in col.named_parameters()})
-    # the same step with the oracle in fp32 (the reference's own arithmetic) calibrates how well each
-    # gradient is conditioned: e.g. d loss / d (sdf bias) is a sum of 65,536 cancelling terms
+    # the same step with the oracle in fp32 (the reference's own arithmetic) calibrates outputs and gradients
     p32 = {k: v.clone().requires_grad_(True) for k, v in p.items()}
     ref32 = O.render_rnb(p32, mc, batch["rays_o"], batch["rays_d"], batch["near"], batch["far"],
                          batch["lights_dir"], cos_anneal_ratio=1.0, z_vals=z)
     O.rnb_loss(ref32, batch["true_rgb"], batch["mask"])[0].backward()
+    for k in ("color_fine", "weights", "weight_sum", "gradients", "cdf_fine", "gradient_error"):
+        r64 = ref[k].detach().double()
+        e_hip = float((out[k].detach().cpu().double() - r64).abs().max())
+        e_ref = float((ref32[k].detach().double() - r64).abs().max())
+        bound = K_OUT * e_ref + FLOOR_OUT * max(1.0, float(r64.abs().max()))
+        assert e_hip <= bound, f"{k}: |hip - fp64| {e_hip:.3e} > {bound:.3e} (fp32 CPU oracle: {e_ref:.3e})"
+    torch.testing.assert_close(loss.detach().cpu().double(), ref_loss.detach(), rtol=1e-5, atol=1e-6)
+    named = _named(sdf, dev, col)
     worst = ("", 0.0, 0.0)
     for k, v in named.items():
         rg = pr[k].grad
-        den = rg.norm().clamp_min(1e-20)
-        rel = float((v.grad.cpu().double() - rg).norm() / den)
-        rel32 = float((p32[k].grad.double() - rg).norm() / den)
-        if rel > worst[1]:
-            worst = (k, rel, rel32)
-        assert rel < max(1e-3, 3.0 * rel32), f"{k}: rel-L2 {rel:.3e} (fp32 CPU oracle: {rel32:.3e})"
-    print(f"B=512 vs fp64 oracle: worst gradient rel-L2 = {worst[1]:.2e} ({worst[0]}; fp32 CPU oracle {worst[2]:.2e})")
+        den = float(rg.norm())
+        assert den > 1e-9, f"{k}: the fp64 gradient vanishes: not a parity target"
+        rel = float((v.grad.cpu().double() - rg).norm()) / den
+        rel32 = float((p32[k].grad.double() - rg).norm()) / den
+        assert rel32 <= GRAD_CAP / K_GRAD, f"{k}: the fp32 oracle itself is {rel32:.2e} from fp64: not a parity target"
+        bound = _grad_bound(rel32)
+        if rel / bound > worst[1]:
+            worst = (k, rel / bound, rel)
+        assert rel <= bound, f"{k}: rel-L2 {rel:.3e} > {bound:.3e} (fp32 CPU oracle: {rel32:.3e})"
+    print(f"B=512 vs fp64 oracle: weight_sum mean {float(out['weight_sum'].mean()):.3f}; worst gradient {worst[0]}: "
+          f"rel-L2 {worst[2]:.2e} = {worst[1]:.2f} of its bound")
 
 
 def test_size_independent_properties(R):
@@ -551,23 +594,122 @@ def test_wrong_device_is_rejected(R):
 
 
 def test_nan_parameters_give_nan_outputs_not_a_fault(R):
-    """A diverged model (NaN weights) must come back as NaNs, as it does in the reference: with NaN depths every
-    comparison of the importance-sampling merge is false, slots of its index buffer stay unwritten, and a stray index must
-    not become a stray address (sampling.hip clamps what it gathers by)."""
+    """A diverged model (NaN weights) must come back as NaNs exactly where the reference's come back as NaNs — not as
+    a GPU fault, and not as whatever the output buffers held before.  With a NaN SDF every CDF of the up-sampling loop
+    is NaN: ATen's upper bound then returns n (new depths NaN) and torch.sort puts NaNs last, so the reference's
+    z_vals are [64 finite coarse depths, 64 NaNs]; the importance-sampling merge here is total under the same order
+    (sampling.hip::lt_total), so every slot is written.  The output buffers are pre-filled with a finite sentinel
+    through torch.empty to prove nothing stale survives."""
     mc = O.ModelConf()
     torch.manual_seed(4)
     p = O.init_params(mc)
     sdf, devn, col, ren = R.build_from_named_params(mc, p, _dev())
     with torch.no_grad():
         sdf.lin3.bias[7] = float("nan")
-    b = {k: v.to(_dev()) for k, v in O.synthetic_batch(64, seed=8, step=3).items()}
-    out = ren.render_rnb(b["rays_o"], b["rays_d"], b["near"], b["far"], b["lights_dir"], cos_anneal_ratio=1.0,
-                         t_rand=b["t_rand"])
+        p["sdf.lin3.bias"][7] = float("nan")
+    batch = O.synthetic_batch(64, seed=8, step=3)
+    b = {k: v.to(_dev()) for k, v in batch.items()}
+    ref = O.render_rnb(p, mc, batch["rays_o"], batch["rays_d"], batch["near"], batch["far"], batch["lights_dir"],
+                       cos_anneal_ratio=1.0, t_rand=batch["t_rand"])
+    orig_empty = torch.empty
+
+    def sentinel_empty(*a, **k):           # stale-looking finite content in every buffer the shim allocates
+        t = orig_empty(*a, **k)
+        if t.is_cuda and t.dtype == torch.float32:
+            t.fill_(0.25)
+        return t
+
+    torch.empty = sentinel_empty
+    try:
+        out = ren.render_rnb(b["rays_o"], b["rays_d"], b["near"], b["far"], b["lights_dir"], cos_anneal_ratio=1.0,
+                             t_rand=b["t_rand"])
+    finally:
+        torch.empty = orig_empty
     loss = O.rnb_loss(out, b["true_rgb"], b["mask"])[0]
     loss.backward()
     torch.cuda.synchronize()
-    assert not torch.isfinite(out["color_fine"]).all()
-    assert not torch.isfinite(loss)
+    z, zr = ren.last_z_vals.cpu(), ref["z_vals"]
+    assert torch.equal(torch.isnan(z), torch.isnan(zr)), "NaN depths exactly where the reference has them (sorted last)"
+    assert torch.equal(z[~torch.isnan(z)], zr[~torch.isnan(zr)]), "the finite (coarse) depths stay bit-exact"
+    for k in ("color_fine", "weights", "weight_sum", "weight_max", "cdf_fine", "gradients", "gradient_error"):
+        assert bool(torch.isnan(ref[k]).all()), k                       # what the reference does
+        assert bool(torch.isnan(out[k]).all()), f"{k}: every element must be NaN, as in the reference"
+    assert torch.equal(out["inside_sphere"].cpu(), ref["inside_sphere"])
+    assert bool(torch.isnan(loss))
+    assert bool(torch.isnan(sdf.lin0.weight_v.grad).all())
+
+
+def test_nan_rays_poison_only_themselves(R):
+    """Rays are independent: NaN origins in two rays of a batch give NaN outputs for exactly those rays (as the
+    reference does) and leave every other ray's outputs bit-identical to the clean batch."""
+    g = Golden("full_main_sharp")
+    p, sdf, devn, col, ren = _build(R, g)
+    batch = O.synthetic_batch(64, seed=9, step=2)
+    bad = torch.tensor([3, 40])
+    poisoned = {k: v.clone() for k, v in batch.items()}
+    poisoned["rays_o"][bad, 1] = float("nan")
+    outs = []
+    with torch.no_grad():
+        for bt in (batch, poisoned):
+            b = {k: v.to(_dev()) for k, v in bt.items()}
+            outs.append(ren.render_rnb(b["rays_o"], b["rays_d"], b["near"], b["far"], b["lights_dir"],
+                                       cos_anneal_ratio=1.0, t_rand=b["t_rand"]))
+    clean, pois = outs
+    ref = O.render_rnb(p, g.mc, poisoned["rays_o"], poisoned["rays_d"], poisoned["near"], poisoned["far"],
+                       poisoned["lights_dir"], cos_anneal_ratio=1.0, t_rand=poisoned["t_rand"])
+    good = torch.ones(64, dtype=torch.bool)
+    good[bad] = False
+    for k in ("weights", "weight_sum", "cdf_fine", "gradients"):
+        assert torch.equal(torch.isnan(pois[k]).cpu(), torch.isnan(ref[k])), k
+        assert bool(torch.isnan(pois[k][bad.to(_dev())]).all()), k
+        assert torch.equal(pois[k][good.to(_dev())], clean[k][good.to(_dev())]), k
+    assert torch.equal(torch.isnan(pois["color_fine"]).cpu(), torch.isnan(ref["color_fine"]))
+    assert torch.equal(pois["color_fine"][:, good.to(_dev())], clean["color_fine"][:, good.to(_dev())])
+
+
+@pytest.mark.parametrize("variant", [dict(deterministic=True), dict(deterministic=True, bf16=True),
+                                     dict(deterministic=True, f32_mfma=True)])
+def test_uninitialised_workspace_is_never_read(R, variant):
+    """Every buffer the shim hands to the library comes from torch.empty: whatever it held before must not reach a
+    result.  The same train step (deterministic variant: bit-reproducible) is run on buffers pre-filled with NaN bit
+    patterns (fp32 NaN / 0xFF bytes: per-point state, split-K slabs, packed weights and gradients, outputs) and must
+    reproduce the clean run bit for bit.  (Round 2 saw four GPU faults traced to NaN depths whose origin was never
+    pinned down: a kernel reading a slab or a padded row it had not written is the class of bug this catches.)"""
+    g = Golden("full_main_sharp")
+    batch = O.synthetic_batch(200, seed=5, step=1)        # ragged: 25,600 points, padded rows in every tile family
+    runs = []
+    orig_empty, orig_empty_like = torch.empty, torch.empty_like
+
+    def poison(t):
+        if t.is_cuda and t.dtype == torch.float32:
+            t.fill_(float("nan"))
+        elif t.is_cuda and t.dtype == torch.uint8:
+            t.fill_(255)
+        return t
+
+    for poisoned in (False, True):
+        p, sdf, devn, col, ren = _build(R, g)
+        ren.set_variant(**variant)
+        b = {k: v.to(_dev()) for k, v in batch.items()}
+        if poisoned:
+            torch.empty = lambda *a, **k: poison(orig_empty(*a, **k))
+            torch.empty_like = lambda *a, **k: poison(orig_empty_like(*a, **k))
+        try:
+            out = ren.render_rnb(b["rays_o"], b["rays_d"], b["near"], b["far"], b["lights_dir"], cos_anneal_ratio=1.0,
+                                 t_rand=b["t_rand"])
+            loss = O.rnb_loss(out, b["true_rgb"], b["mask"])[0]
+            loss.backward()
+            torch.cuda.synchronize()
+        finally:
+            torch.empty, torch.empty_like = orig_empty, orig_empty_like
+        grads = {k: v.grad.clone() for k, v in _named(sdf, devn, col).items()}
+        runs.append((ren.last_z_vals.clone(), {k: v.detach().clone() for k, v in out.items()}, grads))
+    (z0, o0, g0), (z1, o1, g1) = runs
+    assert torch.equal(z0, z1)
+    for k in o0:
+        assert torch.equal(o0[k], o1[k]), f"output {k} depends on what its buffers held before the call"
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), f"gradient of {k} depends on what the workspace held before the call"
 
 
 def test_x3_weight_mirror_is_an_exact_three_way_split(R):

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/rnbneus.h but not exported"
     assert set(declared) == set(R.native.EXPORTED_SYMBOLS)
-    assert lib.rnb_abi_version() == 2
+    assert lib.rnb_abi_version() == 3
 
 
 def _desc(**over):
