@@ -84,6 +84,7 @@ def parse():
                     help="arithmetic of the SDF-network sweeps (bf16: bf16 operands, fp32 accumulate; config 5)")
     ap.add_argument("--mode", choices=("train", "mesh"), default="train")
     ap.add_argument("--resolution", type=int, default=512, help="--mode mesh: grid points per axis")
+    ap.add_argument("--no-marching-cubes", action="store_true", help="--mode mesh: time the SDF grid only")
     ap.add_argument("--warmup-mode", action="store_true", help="render_rnb_warmup instead of render_rnb")
     ap.add_argument("--no-albedo", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -510,6 +511,23 @@ def run_mesh(args):
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+    # the step after the grid in validate_mesh (models/renderer.py:31): marching cubes on the volume still in HBM
+    # (csrc/mcubes.hip; every rank holds the whole volume after the all-gather, rank 0 meshes it)
+    mc = None
+    if rank == 0 and not args.no_marching_cubes:
+        v, tri = R.marching_cubes(u, 0.0)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            v, tri = R.marching_cubes(u, 0.0)
+        torch.cuda.synchronize()
+        mc_ms = 1e3 * (time.perf_counter() - t1) / args.steps
+        alg = 4.0 * res ** 3 + 24.0 * v.shape[0] + 12.0 * tri.shape[0]     # volume once + the two output arrays
+        mc = {"ms": round(mc_ms, 3), "vertices": int(v.shape[0]), "triangles": int(tri.shape[0]),
+              "bound": "hbm", "algorithmic_bytes": alg, "achieved_GBps": round(alg / (mc_ms * 1e-3) / 1e9, 1),
+              "frac": round(alg / (mc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+              "note": "4 passes over the volume (count, scan, vertices, triangles) + one 4-byte id word per grid point; "
+                      "includes the host read of the two output sizes; parity with PyMCubes unpinned"}
     if rank == 0:
         n = res ** 3
         ms = 1e3 * elapsed / args.steps
@@ -541,7 +559,9 @@ def run_mesh(args):
                 "config": {"workload": f"extract_fields: {res}^3 SDF evaluations of the wmask_rnb.conf SDF network "
                                        "(geometric init), x-slabs sharded over the ranks, volume resident in HBM",
                            "resolution": res, "parallelism": f"dp{world}", "grid_mean": float(u.mean())},
-                "roofline": roof, "cpu_baseline": cpu}
+                "roofline": roof, "cpu_baseline": cpu, "marching_cubes": mc}
+        if mc:
+            line["config"]["mesh_ms_total"] = round(ms + mc["ms"], 3)     # grid + marching cubes = extract_geometry
         if rehearsal:
             line["rehearsal"] = True
         if cpu:

@@ -285,6 +285,28 @@ int rnb_algorithmic_flops(const rnb_model_desc* desc, int64_t B, int32_t flags, 
  * RNB_VARIANT_BF16, else 4) + the albedo network's fp32 activations. */
 int rnb_algorithmic_bytes(const rnb_model_desc* desc, int64_t B, int32_t flags, double* train_bytes);
 
+/* ---- Marching cubes of validate_mesh --------------------------------------------------------------
+ * Replaces `mcubes.marching_cubes(u, threshold)` (models/renderer.py:31 inside extract_geometry :27-36; called by
+ * validate_mesh, exp_runner.py:561-581) on a volume resident in device memory: volume [nx, ny, nz] fp32, C order (the
+ * array extract_fields returns).  PyMCubes (third party, un-vendored, not importable here) is the arithmetic being
+ * replaced: PARITY UNPINNED; kept from its published behaviour are the classic corner / edge numbering, "inside" :=
+ * value <= threshold, ONE vertex per crossed grid edge shared by the cells around it, linear interpolation in double
+ * precision and vertices in grid-index coordinates (the caller rescales them, models/renderer.py:34).  Triangles are
+ * oriented so that their right-hand normal points towards smaller values.  NaN samples count as outside; an edge
+ * between a NaN and an inside sample yields a NaN vertex.
+ * Two calls, because the output sizes are data dependent:
+ *   rnb_marching_cubes_count  fills counts[0..1] (device int64: vertices, triangles) and the workspace;
+ *   -- the caller reads counts, allocates vertices [n_vertices, 3] double and triangles [n_triangles, 3] int32 --
+ *   rnb_marching_cubes_emit   same volume / threshold / workspace; writes both arrays.  Deterministic order: vertices
+ *                             by owning grid point (x slowest) then edge axis; triangles by cell, then table order.
+ * Fails with RNB_E_INVALID beyond 2^30 vertices (vertex ids are 30-bit) or 2^32 grid points. */
+int rnb_marching_cubes_workspace_bytes(int32_t nx, int32_t ny, int32_t nz, int64_t* bytes);
+int rnb_marching_cubes_count(const float* volume, int32_t nx, int32_t ny, int32_t nz, float threshold,
+                             void* workspace, size_t workspace_bytes, int64_t* counts, rnb_stream_t stream);
+int rnb_marching_cubes_emit(const float* volume, int32_t nx, int32_t ny, int32_t nz, float threshold,
+                            void* workspace, size_t workspace_bytes, int64_t n_vertices, int64_t n_triangles,
+                            double* vertices, int32_t* triangles, rnb_stream_t stream);
+
 /* Ray / target generation of one train_rnb step on the device: what Dataset.ps_gen_random_rays_at_view_on_all_lights
  * (models/dataset.py:351-376), the per-pixel light gather (exp_runner.py:214-220) and near_far_from_sphere
  * (models/dataset.py:448-458) compute on the host, for one view whose tensors are resident in device memory.

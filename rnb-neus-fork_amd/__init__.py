@@ -19,9 +19,10 @@ from .renderer import NeuSRenderer  # noqa: F401
 from .losses import rnb_loss  # noqa: F401
 from .optim import FlatAdam  # noqa: F401
 from .raygen import DeviceRays  # noqa: F401
+from .mcubes import marching_cubes  # noqa: F401
 
 __all__ = ["NeuSRenderer", "SDFNetwork", "RenderingNetwork", "SingleVarianceNetwork", "NeRF", "get_embedder",
-           "native", "build_from_named_params", "rnb_loss", "FlatAdam", "DeviceRays"]
+           "native", "build_from_named_params", "rnb_loss", "FlatAdam", "DeviceRays", "marching_cubes"]
 
 
 def build_from_named_params(mc, params, device):

@@ -843,7 +843,7 @@ __global__ __launch_bounds__(256, 2) void bf_color_fwd_kernel(BfColArgs g) {
           float a[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            a[j] = fmaxf(acc[ti][tj][4 * q + j] + bc, 0.f);
+            a[j] = relu_nan(acc[ti][tj][4 * q + j] + bc);
             X[(ti * 32 + 8 * q + 4 * h + j) * CP + col] = to_bf(a[j]);
           }
           k8_store_quad(g.ac8[l], row0, ti, q, col, h, a[0], a[1], a[2], a[3]);

@@ -17,7 +17,7 @@ __device__ inline float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
 __device__ inline float inv_s_from_variance(const float* variance, bool* inside_clip) {
   const float raw = expf(variance[0] * 10.0f);
   if (inside_clip) *inside_clip = (raw >= 1e-6f) && (raw <= 1e6f);
-  return fminf(fmaxf(raw, 1e-6f), 1e6f);
+  return clamp_nan(raw, 1e-6f, 1e6f);
 }
 
 // pts[b,j] = o + d * (z + dists/2),  dists[b,j] = z[j+1]-z[j] (last: sample_dist)
@@ -44,7 +44,7 @@ __device__ inline float wave_sum(float v) {
 }
 __device__ inline float wave_max(float v) {
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  for (int o = 32; o > 0; o >>= 1) v = max_nan(v, __shfl_xor(v, o, 64));
   return v;
 }
 // inclusive product scan across the wave
@@ -65,13 +65,13 @@ __device__ inline SampleState eval_sample(float s, float n0, float n1, float n2,
                                           float delta, float inv_s, float c) {
   SampleState st;
   st.tc = d0 * n0 + d1 * n1 + d2 * n2;
-  const float ic = -(fmaxf(-st.tc * 0.5f + 0.5f, 0.f) * (1.0f - c) + fmaxf(-st.tc, 0.f) * c);
+  const float ic = -(relu_nan(-st.tc * 0.5f + 0.5f) * (1.0f - c) + relu_nan(-st.tc) * c);
   st.e_next = s + ic * delta * 0.5f;
   st.e_prev = s - ic * delta * 0.5f;
   st.pc = sigm(st.e_prev * inv_s);
   st.nc = sigm(st.e_next * inv_s);
   st.raw = (st.pc - st.nc + 1e-5f) / (st.pc + 1e-5f);
-  st.alpha = fminf(fmaxf(st.raw, 0.f), 1.f);
+  st.alpha = clamp_nan(st.raw, 0.f, 1.f);
   return st;
 }
 
@@ -127,15 +127,19 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(CompArgs a) {
       if (a.albedo_out)
         for (int c = 0; c < a.C; ++c) a.albedo_out[p * a.C + c] = a.alb[p * 4 + c];
       wsum += w;
-      wmax = fmaxf(wmax, w);
-      if (pn < 1.2f) { gnum += (nn - 1.0f) * (nn - 1.0f); gden += 1.0f; }
+      wmax = max_nan(wmax, w);
+      {   // relax_inside_sphere as a FACTOR (models/renderer.py:538-540): 0 * NaN stays NaN, as in the reference
+        const float relax = pn < 1.2f ? 1.f : 0.f;
+        gnum += relax * ((nn - 1.0f) * (nn - 1.0f));
+        gden += relax;
+      }
       float al[4];
 #pragma unroll
       for (int c = 0; c < 4; ++c) al[c] = no_alb ? 1.0f : a.alb[p * 4 + c];
       if (mvps) {
         for (int l = 0; l < a.L; ++l) {
           float sh = n0 * Lv[l][0] + n1 * Lv[l][1] + n2 * Lv[l][2];
-          if (relu_sh) sh = fmaxf(sh, 0.f);
+          if (relu_sh) sh = relu_nan(sh);
           const float ws = w * sh;
 #pragma unroll
           for (int c = 0; c < 4; ++c) col[l][c] = fmaf(al[c], ws, col[l][c]);

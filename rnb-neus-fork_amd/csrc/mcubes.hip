@@ -1,0 +1,309 @@
+// Marching cubes of validate_mesh on a volume resident in HBM.
+//
+// Replaces `mcubes.marching_cubes(u, threshold)` (models/renderer.py:31, called from extract_geometry :27-36 and
+// exp_runner.py:561-581).  PyMCubes is a third-party C++ extension that the reference does not vendor and that is not
+// importable in this image: PARITY UNPINNED.  What is kept from its published behaviour: the classic
+// corner / edge numbering, "corner is inside when value <= isovalue", one vertex per crossed grid edge shared by the
+// cells around it (no duplicates), linear interpolation in double precision, vertices in grid-index coordinates.
+// The case tables are derived, not typed in (tools/gen_mc_tables.py -> mc_tables.inc): watertight by construction.
+//
+// Byte / integer work bound by HBM: the volume is read once per pass (8 corner loads per point, 7 of them served by
+// L1 / L2), one 4-byte word per grid point of workspace carries the vertex numbering between the two emit kernels.
+//
+//   pass 1  mc_count_kernel     per block of 1024 grid points: (# vertices, # triangles)          -> block sums
+//   pass 2  mc_scan_kernel      exclusive scan of the block sums (one workgroup), totals to `counts`
+//           -- the caller reads the two totals and allocates the outputs --
+//   pass 3  mc_vertex_kernel    recompute, block-local scan + block offset: vertex ids; writes the vertices and, per
+//                               grid point, id of its first vertex | active-x << 30 | active-y << 31
+//   pass 4  mc_triangle_kernel  recompute the case index, scan, look the three vertex ids of every triangle up
+//
+// Order of the outputs (deterministic, independent of the launch geometry): vertices by owning grid point
+// (x slowest, z fastest), then by edge axis x, y, z; triangles by cell in the same order, then in table order.
+#include "rnb_internal.h"
+
+namespace rnb {
+
+#define RNB_MC_TABLE static __constant__ const
+#include "mc_tables.inc"
+#undef RNB_MC_TABLE
+
+constexpr int kMcThreads = 256;
+constexpr int kMcItems = 4;
+constexpr int kMcTile = kMcThreads * kMcItems;     // grid points per workgroup
+
+struct McGrid {
+  const float* v;
+  int nx, ny, nz;
+  int64_t n;       // nx * ny * nz
+  float iso;
+};
+
+struct McPoint {
+  int x, y, z;
+  unsigned edges;      // bit 0/1/2: the grid edge leaving this point in +x / +y / +z crosses the isovalue
+  unsigned cube;       // case index (valid when `cell`)
+  bool cell;           // this point is corner 0 of a cell
+  float f000, f100, f010, f001;
+};
+
+__device__ inline bool mc_set(float f, float iso) { return f <= iso; }
+
+// everything the four passes need to know about grid point p (corner 0 of its cell, owner of three grid edges)
+__device__ inline McPoint mc_point(const McGrid& g, int64_t p) {
+  McPoint r;
+  const int64_t yz = (int64_t)g.ny * g.nz;
+  r.x = (int)(p / yz);
+  const int64_t rem = p - (int64_t)r.x * yz;
+  r.y = (int)(rem / g.nz);
+  r.z = (int)(rem - (int64_t)r.y * g.nz);
+  const bool hx = r.x + 1 < g.nx, hy = r.y + 1 < g.ny, hz = r.z + 1 < g.nz;
+  const float* v = g.v + p;
+  r.f000 = v[0];
+  r.f100 = hx ? v[yz] : r.f000;
+  r.f010 = hy ? v[g.nz] : r.f000;
+  r.f001 = hz ? v[1] : r.f000;
+  const bool s0 = mc_set(r.f000, g.iso);
+  r.edges = (unsigned)(hx && (s0 != mc_set(r.f100, g.iso))) | ((unsigned)(hy && (s0 != mc_set(r.f010, g.iso))) << 1) |
+            ((unsigned)(hz && (s0 != mc_set(r.f001, g.iso))) << 2);
+  r.cell = hx && hy && hz;
+  r.cube = 0;
+  if (r.cell) {
+    const float f110 = v[yz + g.nz], f101 = v[yz + 1], f011 = v[g.nz + 1], f111 = v[yz + g.nz + 1];
+    // corner m of the classic numbering: 0 (0,0,0) 1 (1,0,0) 2 (1,1,0) 3 (0,1,0) 4 (0,0,1) 5 (1,0,1) 6 (1,1,1) 7 (0,1,1)
+    r.cube = (unsigned)s0 | ((unsigned)mc_set(r.f100, g.iso) << 1) | ((unsigned)mc_set(f110, g.iso) << 2) |
+             ((unsigned)mc_set(r.f010, g.iso) << 3) | ((unsigned)mc_set(r.f001, g.iso) << 4) |
+             ((unsigned)mc_set(f101, g.iso) << 5) | ((unsigned)mc_set(f111, g.iso) << 6) |
+             ((unsigned)mc_set(f011, g.iso) << 7);
+  }
+  return r;
+}
+
+// exclusive prefix of `v` over the 256 threads of the workgroup (thread order); *total = sum over the workgroup
+__device__ inline unsigned block_exclusive_scan(unsigned v, unsigned* total, unsigned* red /* [4] */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += t;
+  }
+  __syncthreads();                 // `red` may still be read by the previous call
+  if (lane == 63) red[wave] = inc;
+  __syncthreads();
+  unsigned base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < kMcThreads / 64; ++w) {
+    if (w < wave) base += red[w];
+    tot += red[w];
+  }
+  *total = tot;
+  return base + inc - v;
+}
+
+__global__ __launch_bounds__(kMcThreads) void mc_count_kernel(McGrid g, unsigned* __restrict__ block_verts,
+                                                              unsigned* __restrict__ block_tris) {
+  __shared__ unsigned red[4];
+  const int64_t p0 = (int64_t)blockIdx.x * kMcTile + (int64_t)threadIdx.x * kMcItems;
+  unsigned nv = 0, nt = 0;
+#pragma unroll
+  for (int k = 0; k < kMcItems; ++k) {
+    const int64_t p = p0 + k;
+    if (p < g.n) {
+      const McPoint pt = mc_point(g, p);
+      nv += __popc(pt.edges);
+      nt += pt.cell ? kMcNumTris[pt.cube] : 0;
+    }
+  }
+  unsigned tv, tt;
+  block_exclusive_scan(nv, &tv, red);
+  block_exclusive_scan(nt, &tt, red);
+  if (threadIdx.x == 0) {
+    block_verts[blockIdx.x] = tv;
+    block_tris[blockIdx.x] = tt;
+  }
+}
+
+// exclusive scan of the two block-sum arrays in place (64-bit running totals; the offsets themselves fit 32 bits
+// whenever the totals pass the caller's range check); counts[0..1] = total vertices, total triangles
+__global__ __launch_bounds__(1024) void mc_scan_kernel(unsigned* __restrict__ block_verts,
+                                                       unsigned* __restrict__ block_tris, int64_t nblocks,
+                                                       int64_t* __restrict__ counts) {
+  __shared__ unsigned long long wsum[16];
+  __shared__ unsigned long long carry_s;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int which = 0; which < 2; ++which) {
+    unsigned* a = which == 0 ? block_verts : block_tris;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < nblocks; base += 1024) {
+      const int64_t i = base + threadIdx.x;
+      const unsigned long long v = i < nblocks ? a[i] : 0;
+      unsigned long long inc = v;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const unsigned long long t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+      }
+      if (lane == 63) wsum[wave] = inc;
+      __syncthreads();
+      unsigned long long before = carry_s;
+      for (int w = 0; w < wave; ++w) before += wsum[w];
+      if (i < nblocks) a[i] = (unsigned)(before + inc - v);
+      __syncthreads();
+      if (threadIdx.x == 1023) carry_s = before + inc;
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) counts[which] = (int64_t)carry_s;
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(kMcThreads) void mc_vertex_kernel(McGrid g, const unsigned* __restrict__ block_verts,
+                                                               unsigned* __restrict__ voff,
+                                                               double* __restrict__ vertices, int64_t n_vertices) {
+  __shared__ unsigned red[4];
+  const int64_t p0 = (int64_t)blockIdx.x * kMcTile + (int64_t)threadIdx.x * kMcItems;
+  McPoint pt[kMcItems];
+  unsigned nv = 0;
+#pragma unroll
+  for (int k = 0; k < kMcItems; ++k) {
+    pt[k].edges = 0;
+    if (p0 + k < g.n) pt[k] = mc_point(g, p0 + k);
+    nv += __popc(pt[k].edges);
+  }
+  unsigned tot;
+  unsigned id = block_verts[blockIdx.x] + block_exclusive_scan(nv, &tot, red);
+  const double iso = (double)g.iso;
+#pragma unroll
+  for (int k = 0; k < kMcItems; ++k) {
+    if (p0 + k >= g.n) break;
+    const unsigned e = pt[k].edges;
+    voff[p0 + k] = id | ((e & 1u) << 30) | (((e >> 1) & 1u) << 31);
+    const double f0 = (double)pt[k].f000;
+    const float fn[3] = {pt[k].f100, pt[k].f010, pt[k].f001};
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      if (!((e >> d) & 1u)) continue;
+      if ((int64_t)id < n_vertices) {           // (always, when the caller passed the counts of pass 2)
+        const double t = (iso - f0) / ((double)fn[d] - f0);
+        double* o = vertices + (int64_t)id * 3;
+        o[0] = (double)pt[k].x + (d == 0 ? t : 0.0);
+        o[1] = (double)pt[k].y + (d == 1 ? t : 0.0);
+        o[2] = (double)pt[k].z + (d == 2 ? t : 0.0);
+      }
+      ++id;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kMcThreads) void mc_triangle_kernel(McGrid g, const unsigned* __restrict__ block_tris,
+                                                                 const unsigned* __restrict__ voff,
+                                                                 int32_t* __restrict__ triangles, int64_t n_triangles) {
+  __shared__ unsigned red[4];
+  const int64_t p0 = (int64_t)blockIdx.x * kMcTile + (int64_t)threadIdx.x * kMcItems;
+  unsigned cube[kMcItems];
+  unsigned nt = 0;
+#pragma unroll
+  for (int k = 0; k < kMcItems; ++k) {
+    cube[k] = 0;
+    if (p0 + k < g.n) {
+      const McPoint pt = mc_point(g, p0 + k);
+      cube[k] = pt.cell ? pt.cube : 0;          // case 0 has no triangles
+    }
+    nt += kMcNumTris[cube[k]];
+  }
+  unsigned tot;
+  unsigned tid = block_tris[blockIdx.x] + block_exclusive_scan(nt, &tot, red);
+  const int64_t yz = (int64_t)g.ny * g.nz;
+#pragma unroll
+  for (int k = 0; k < kMcItems; ++k) {
+    const int n = kMcNumTris[cube[k]];
+    for (int t = 0; t < n; ++t) {
+      int32_t ids[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const int e = kMcTriEdges[cube[k]][3 * t + c];
+        const int64_t q = p0 + k + kMcEdgeOwner[e][0] * yz + kMcEdgeOwner[e][1] * (int64_t)g.nz + kMcEdgeOwner[e][2];
+        const unsigned w = voff[q];
+        const unsigned ax = (w >> 30) & 1u, ay = w >> 31;
+        const int axis = kMcEdgeAxis[e];
+        ids[c] = (int32_t)((w & 0x3FFFFFFFu) + (axis == 0 ? 0u : (axis == 1 ? ax : ax + ay)));
+      }
+      if ((int64_t)tid < n_triangles) {
+        int32_t* o = triangles + (int64_t)tid * 3;
+        o[0] = ids[0]; o[1] = ids[1]; o[2] = ids[2];
+      }
+      ++tid;
+    }
+  }
+}
+
+static int mc_check(const char* who, const void* volume, int nx, int ny, int nz) {
+  if (!volume) RNB_FAIL(RNB_E_NULL, "%s: NULL volume", who);
+  if (nx < 2 || ny < 2 || nz < 2) RNB_FAIL(RNB_E_INVALID, "%s: the grid needs >= 2 points per axis (%d %d %d)", who, nx, ny, nz);
+  if ((int64_t)nx * ny * nz > ((int64_t)1 << 32)) RNB_FAIL(RNB_E_INVALID, "%s: more than 2^32 grid points", who);
+  return RNB_OK;
+}
+
+static int64_t mc_blocks(int64_t n) { return (n + kMcTile - 1) / kMcTile; }
+
+}  // namespace rnb
+
+#define RNB_API extern "C" __attribute__((visibility("default")))
+
+RNB_API int rnb_marching_cubes_workspace_bytes(int32_t nx, int32_t ny, int32_t nz, int64_t* bytes) {
+  using namespace rnb;
+  if (!bytes) RNB_FAIL(RNB_E_NULL, "rnb_marching_cubes_workspace_bytes: NULL");
+  if (nx < 2 || ny < 2 || nz < 2) RNB_FAIL(RNB_E_INVALID, "rnb_marching_cubes_workspace_bytes: bad grid");
+  const int64_t n = (int64_t)nx * ny * nz;
+  const int64_t nb = (mc_blocks(n) + 63) / 64 * 64;
+  *bytes = (2 * nb + n) * (int64_t)sizeof(unsigned);
+  return RNB_OK;
+}
+
+RNB_API int rnb_marching_cubes_count(const float* volume, int32_t nx, int32_t ny, int32_t nz, float threshold,
+                                     void* workspace, size_t workspace_bytes, int64_t* counts, rnb_stream_t stream) {
+  using namespace rnb;
+  RNB_TRY(mc_check("rnb_marching_cubes_count", volume, nx, ny, nz));
+  if (!workspace || !counts) RNB_FAIL(RNB_E_NULL, "rnb_marching_cubes_count: NULL workspace / counts");
+  int64_t need;
+  RNB_TRY(rnb_marching_cubes_workspace_bytes(nx, ny, nz, &need));
+  if ((int64_t)workspace_bytes < need) RNB_FAIL(RNB_E_INVALID, "rnb_marching_cubes_count: workspace %zu < %lld bytes", workspace_bytes, (long long)need);
+  const int64_t n = (int64_t)nx * ny * nz, nb = mc_blocks(n), nbp = (nb + 63) / 64 * 64;
+  unsigned* bv = (unsigned*)workspace;
+  unsigned* bt = bv + nbp;
+  McGrid g{volume, nx, ny, nz, n, threshold};
+  hipLaunchKernelGGL(mc_count_kernel, dim3((unsigned)nb), dim3(kMcThreads), 0, (hipStream_t)stream, g, bv, bt);
+  RNB_CHECK_LAUNCH();
+  hipLaunchKernelGGL(mc_scan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, bv, bt, nb, counts);
+  RNB_CHECK_LAUNCH();
+  return RNB_OK;
+}
+
+RNB_API int rnb_marching_cubes_emit(const float* volume, int32_t nx, int32_t ny, int32_t nz, float threshold,
+                                    void* workspace, size_t workspace_bytes, int64_t n_vertices, int64_t n_triangles,
+                                    double* vertices, int32_t* triangles, rnb_stream_t stream) {
+  using namespace rnb;
+  RNB_TRY(mc_check("rnb_marching_cubes_emit", volume, nx, ny, nz));
+  if (!workspace) RNB_FAIL(RNB_E_NULL, "rnb_marching_cubes_emit: NULL workspace");
+  if (n_vertices < 0 || n_triangles < 0 || n_vertices >= ((int64_t)1 << 30) || n_triangles >= ((int64_t)1 << 31) / 3)
+    RNB_FAIL(RNB_E_INVALID, "rnb_marching_cubes_emit: %lld vertices / %lld triangles exceed the 30-bit vertex ids",
+             (long long)n_vertices, (long long)n_triangles);
+  if ((n_vertices > 0 && !vertices) || (n_triangles > 0 && !triangles))
+    RNB_FAIL(RNB_E_NULL, "rnb_marching_cubes_emit: NULL output");
+  int64_t need;
+  RNB_TRY(rnb_marching_cubes_workspace_bytes(nx, ny, nz, &need));
+  if ((int64_t)workspace_bytes < need) RNB_FAIL(RNB_E_INVALID, "rnb_marching_cubes_emit: workspace too small");
+  const int64_t n = (int64_t)nx * ny * nz, nb = mc_blocks(n), nbp = (nb + 63) / 64 * 64;
+  unsigned* bv = (unsigned*)workspace;
+  unsigned* bt = bv + nbp;
+  unsigned* voff = bt + nbp;
+  McGrid g{volume, nx, ny, nz, n, threshold};
+  hipLaunchKernelGGL(mc_vertex_kernel, dim3((unsigned)nb), dim3(kMcThreads), 0, (hipStream_t)stream, g, bv, voff,
+                     vertices, n_vertices);
+  RNB_CHECK_LAUNCH();
+  hipLaunchKernelGGL(mc_triangle_kernel, dim3((unsigned)nb), dim3(kMcThreads), 0, (hipStream_t)stream, g, bt, voff,
+                     triangles, n_triangles);
+  RNB_CHECK_LAUNCH();
+  return RNB_OK;
+}

@@ -473,7 +473,7 @@ struct EpiRelu {
     const vf4 bb = ld4(b + col);
     vf4 o;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) o[c] = col + c < n_real ? fmaxf(v[c] + bb[c], 0.f) : 0.f;
+    for (int c = 0; c < 4; ++c) o[c] = col + c < n_real ? relu_nan(v[c] + bb[c]) : 0.f;
     st4(out + (size_t)row * ld + col, o);
   }
 };

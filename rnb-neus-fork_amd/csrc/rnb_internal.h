@@ -76,6 +76,14 @@ struct Layout {
 int make_layout(const rnb_model_desc* d, Layout* L);
 
 #if defined(__HIPCC__)
+// torch.clamp / torch.minimum / torch.max / F.relu PROPAGATE NaN; fmaxf / fminf (v_max_f32 / v_min_f32) return the
+// other operand.  A diverged model must come back as NaN exactly where the reference's does, so the element-wise
+// min / max of the path go through these.  Identical to fminf / fmaxf on numbers.
+__device__ inline float max_nan(float a, float b) { return a != a ? a : (b != b ? b : fmaxf(a, b)); }
+__device__ inline float min_nan(float a, float b) { return a != a ? a : (b != b ? b : fminf(a, b)); }
+__device__ inline float clamp_nan(float x, float lo, float hi) { return x != x ? x : fminf(fmaxf(x, lo), hi); }
+__device__ inline float relu_nan(float x) { return x < 0.f ? 0.f : x; }
+
 // torch.linspace(start, end, steps)[i] as ATen's CPU kernel computes it: step = (end-start)/(steps-1); first half
 // start + step*i, second half end - step*(steps-1-i), each as one fused multiply-add (explicit fmaf: independent of
 // the translation unit's contraction mode).

@@ -97,8 +97,8 @@ __global__ __launch_bounds__(64) void up_sample_kernel(UpArgs a) {
   __syncthreads();
   for (int j = lane; j < n - 1; j += 64) {
     const float prev = j == 0 ? 0.f : cs[j - 1];
-    float c = fminf(prev, cs[j]);
-    c = fminf(fmaxf(c, -1e3f), 0.0f);
+    float c = min_nan(prev, cs[j]);
+    c = clamp_nan(c, -1e3f, 0.0f);
     c = c * ((ins[j] | ins[j + 1]) ? 1.0f : 0.0f);
     const float dist = z[j + 1] - z[j];
     const float mid = (sd[j] + sd[j + 1]) * 0.5f;

@@ -41,9 +41,9 @@ __global__ __launch_bounds__(1024) void rnb_loss_kernel(const float* __restrict_
     const float m = mask_w > 0.f ? (mask[b] > 0.5f ? 1.f : 0.f) : 1.f;
     msum += m;
     const float w = wsum[b];
-    const float x = fminf(fmaxf(w, 1e-3f), 1.f - 1e-3f);
+    const float x = clamp_nan(w, 1e-3f, 1.f - 1e-3f);
     // torch.nn.functional.binary_cross_entropy clamps both logs at -100
-    const float lx = fmaxf(logf(x), -100.f), l1x = fmaxf(logf(1.f - x), -100.f);
+    const float lx = max_nan(logf(x), -100.f), l1x = max_nan(logf(1.f - x), -100.f);
     bce -= (double)(m * lx + (1.f - m) * l1x);
     const bool pass = w >= 1e-3f && w <= 1.f - 1e-3f;   // clip's sub-gradient (inclusive, like torch.clamp)
     const float d = (x - m) / fmaxf((1.f - x) * x, 1e-12f);

@@ -94,6 +94,11 @@ _SIGNATURES = {
     "rnb_sdf_grid_workspace_bytes": (C.c_int, [_P(ModelDesc), _P(GridDesc), _P(C.c_int64)]),
     "rnb_sdf_grid": (C.c_int, [_P(ModelDesc), C.c_void_p, _P(GridDesc), C.c_void_p, C.c_void_p, C.c_size_t,
                                C.c_void_p]),
+    "rnb_marching_cubes_workspace_bytes": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P(C.c_int64)]),
+    "rnb_marching_cubes_count": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p,
+                                           C.c_size_t, C.c_void_p, C.c_void_p]),
+    "rnb_marching_cubes_emit": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p,
+                                          C.c_size_t, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rnb_up_sample_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
                                      C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p]),

@@ -393,17 +393,32 @@ class NeuSRenderer:
                 u = slab[:res]
         return u.cpu().numpy() if to_host else u
 
-    def extract_geometry(self, bound_min, bound_max, resolution, threshold=0.0):
-        """models/renderer.py:1219-1224 / :27-36.  Marching cubes itself is PyMCubes (third party, not
-        vendored by the reference); it is imported lazily exactly as the reference depends on it."""
-        u = self.extract_fields(bound_min, bound_max, resolution)
-        try:
-            import mcubes
-        except ImportError as e:  # pragma: no cover - PyMCubes is not installed in the build image
-            raise ImportError("extract_geometry needs PyMCubes (as the reference does); the SDF grid itself is "
-                              "available from NeuSRenderer.extract_fields") from e
-        vertices, triangles = mcubes.marching_cubes(u, threshold)
+    def extract_geometry(self, bound_min, bound_max, resolution, threshold=0.0, backend=None):
+        """models/renderer.py:1219-1224 / :27-36: SDF grid + marching cubes + rescaling to the bounding box; returns
+        numpy `(vertices [V,3] float64, triangles [T,3])` as the reference does.
+        `backend`: "native" — the library's own marching cubes on the volume still resident in HBM
+        (csrc/mcubes.hip); "mcubes" — PyMCubes on the host copy, exactly the reference's call (raises ImportError when
+        PyMCubes is not installed); None (default) — "mcubes" when it is importable (the reference-faithful default),
+        else "native".  The native mesh has the same vertices (one per crossed grid edge, same interpolation); its
+        triangulation of ambiguous cells / quad diagonals may differ from PyMCubes' table (parity unpinned: DESIGN)."""
+        if backend is None:
+            try:
+                import mcubes  # noqa: F401
+                backend = "mcubes"
+            except ImportError:
+                backend = "native"
+        if backend not in ("native", "mcubes"):
+            raise ValueError(f"extract_geometry: unknown backend {backend!r}")
         b_max = bound_max.detach().cpu().numpy()
         b_min = bound_min.detach().cpu().numpy()
+        if backend == "mcubes":
+            import mcubes
+            u = self.extract_fields(bound_min, bound_max, resolution)
+            vertices, triangles = mcubes.marching_cubes(u, threshold)
+        else:
+            from .mcubes import marching_cubes
+            u = self.extract_fields(bound_min, bound_max, resolution, to_host=False)
+            v, t = marching_cubes(u, threshold)
+            vertices, triangles = v.cpu().numpy(), t.cpu().numpy()
         vertices = vertices / (resolution - 1.0) * (b_max - b_min)[None, :] + b_min[None, :]
         return vertices, triangles
