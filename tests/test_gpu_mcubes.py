@@ -89,7 +89,7 @@ def test_extract_geometry_native_on_the_geometric_init(R):
     V, E, F, euler, closed = M.mesh_report(verts, tris)
     assert closed and euler == 2
     r = np.linalg.norm(verts, axis=1)
-    assert 0.4 < r.min() and r.max() < 0.6
+    assert 0.3 < r.min() and r.max() < 0.7          # the geometric init is a rough sphere of radius ~0.5
     # orientation: outward (u = -sdf decreases outwards)
     pts = verts[tris.astype(np.int64)]
     nrm = np.cross(pts[:, 1] - pts[:, 0], pts[:, 2] - pts[:, 0])

@@ -235,7 +235,7 @@ E2E_MIN = {    # name -> (min frac of z within 1e-4, min frac of rays with ident
     "full_main_sharp": (0.995, 0.95),       # 0.9967, 63/64
     "full_render_sharp": (0.996, 0.93),     # 0.9983, 31/32
     "full_warmup_geo": (0.995, 0.95),       # 0.9965, 63/64
-    "full_main_b512": (0.99, 0.85),         # round 3: measured below
+    "full_main_b512": (0.997, 0.97),        # 0.9987, 503/512 (round 3)
 }
 E2E_DEFAULT = (1.0, 1.0)                    # tiny_*: every z within 1e-4 (max 9e-6), every index identical
 
@@ -625,7 +625,9 @@ def test_nan_parameters_give_nan_outputs_not_a_fault(R):
                              t_rand=b["t_rand"])
     finally:
         torch.empty = orig_empty
-    loss = O.rnb_loss(out, b["true_rgb"], b["mask"])[0]
+    # the library's loss kernel: NaN in, NaN out.  (torch's own binary_cross_entropy device-asserts 0 <= input <= 1 and
+    # would take the whole process down on a NaN weight_sum — as it raises on the CPU in the reference.)
+    loss = R.rnb_loss(out, b["true_rgb"], b["mask"])[0]
     loss.backward()
     torch.cuda.synchronize()
     z, zr = ren.last_z_vals.cpu(), ref["z_vals"]
