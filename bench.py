@@ -52,9 +52,18 @@ def measured_traffic(name, n_gpus, rays, samples):
     return None
 
 
-def kernel_classes(lib, steps, peak_tflops):
+# kernel class tag (rnb_profile_report) -> substring of the kernel names whose PMC traffic belongs to it
+CLASS_KERNELS = {"RA_sweep": "fused_ra_kernel", "FB_sweep": "fused_fb_kernel", "R_sweep": "fused_reverse_kernel",
+                 "F_sweep(save)": "fused_forward_kernel<2, true", "dW(256x256)": "gemm_dw_x3_kernel",
+                 "dW(all)": "bf_dw_kernel", "dW(other)": "gemm_dw_direct_kernel", "layer_gemm": "gemm_rows_x3_kernel"}
+HBM_BOUND_TBS = 4.0    # a class that moves more than this (PMC bytes / event time) is labelled hbm-bound: half of the 8 TB/s
+                       # spec, ~2/3 of what a plain copy reaches (6.3 TB/s)
+
+
+def kernel_classes(lib, steps, peak_tflops, traffic=None):
     """Per kernel class of the last rnb_profile_collect (HIP events on the launch stream): ms per step, launches per step,
-    algorithmic TFLOP/s and its fraction of `peak_tflops`; sorted by time."""
+    algorithmic TFLOP/s and its fraction of `peak_tflops`; with the stored PMC traffic of the same workload also the
+    HBM rate of the class and the roof that bounds it (`bound`: "hbm" above HBM_BOUND_TBS, else "mfma"); sorted by time."""
     need = lib.rnb_profile_report(None, 0)
     buf = C.create_string_buffer(int(need) + 16)
     lib.rnb_profile_report(buf, len(buf))
@@ -65,8 +74,17 @@ def kernel_classes(lib, steps, peak_tflops):
         if ms <= 0:
             continue
         tf = fl / (ms * 1e-3) / 1e12
-        out.append({"kernel_class": tag, "ms_per_step": round(ms / steps, 4), "launches_per_step": n / steps,
-                    "tflops": round(tf, 2), "frac": round(tf / peak_tflops, 4)})
+        d = {"kernel_class": tag, "ms_per_step": round(ms / steps, 4), "launches_per_step": n / steps,
+             "tflops": round(tf, 2), "frac": round(tf / peak_tflops, 4)}
+        key = CLASS_KERNELS.get(tag)
+        if traffic and key:
+            b = sum((2.0 * v["fetch_size_raw_kb_per_launch"] + v["write_size_kb_per_launch"]) * 1024.0 * v["launches_per_step"]
+                    for k, v in traffic.get("per_kernel", {}).items() if key in k)
+            if b > 0:
+                tbs = b / (ms / steps * 1e-3) / 1e12
+                d.update(hbm_gb_per_step=round(b / 1e9, 3), hbm_tb_per_s=round(tbs, 2),
+                         hbm_frac=round(tbs * 1e3 / HBM_PEAK_GBS, 3), bound="hbm" if tbs > HBM_BOUND_TBS else "mfma")
+        out.append(d)
     out.sort(key=lambda d: -d["ms_per_step"])
     return out
 
@@ -82,7 +100,15 @@ def parse():
     ap.add_argument("--samples", type=int, default=128, help="samples per ray (half coarse, half importance)")
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
                     help="arithmetic of the SDF-network sweeps (bf16: bf16 operands, fp32 accumulate; config 5)")
-    ap.add_argument("--mode", choices=("train", "mesh"), default="train")
+    ap.add_argument("--mode", choices=("train", "render", "mesh"), default="train",
+                    help="train: full train_rnb step (the metric); render: forward-only NeuSRenderer.render under no_grad "
+                         "(SURVEY 8d 'also'); mesh: validate_mesh's SDF grid + marching cubes")
+    ap.add_argument("--device-rays", action="store_true",
+                    help="--mode train: draw pixels and gather rays / targets / lights INSIDE the timed step with "
+                         "DeviceRays.sample() on HBM-resident synthetic image stacks (SURVEY 8f-2) instead of pre-staged "
+                         "batches; the line also carries the pre-staged time of the same run")
+    ap.add_argument("--stack", default="20x512x612", help="--device-rays: views x H x W of the synthetic capture "
+                                                          "(config 5: 200x1024x1024, ~22 GB of HBM)")
     ap.add_argument("--resolution", type=int, default=512, help="--mode mesh: grid points per axis")
     ap.add_argument("--no-marching-cubes", action="store_true", help="--mode mesh: time the SDF grid only")
     ap.add_argument("--warmup-mode", action="store_true", help="render_rnb_warmup instead of render_rnb")
@@ -103,9 +129,9 @@ def parse():
                          "the library's one-launch loss and flat Adam")
     a = ap.parse_args()
     if a.steps is None:
-        a.steps = 50 if a.mode == "train" else 3
+        a.steps = 3 if a.mode == "mesh" else 50
     if a.warmup is None:
-        a.warmup = 10 if a.mode == "train" else 1
+        a.warmup = 1 if a.mode == "mesh" else 10
     return a
 
 
@@ -193,6 +219,32 @@ def cpu_baseline(rays, samples, steps, warmup_mode, no_albedo):
                       f"{torch.__version__} CPU fp32, {threads} threads; median {med:.3f} s/step"}
 
 
+def cpu_baseline_render(rays, samples, steps):
+    """CPU leg of --mode render: the oracle's `render` (sampling + fine pass with the autograd normal, as the reference
+    computes it even for a forward-only image, exp_runner.py:389-472)."""
+    import torch
+    from oracle import rnb_oracle as O
+    mc = O.ModelConf(render=O.RenderConf(n_samples=samples // 2, n_importance=samples // 2))
+    threads = cpu_threads()
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    p = O.init_params(mc)
+    times = []
+    for it in range(steps + 1):
+        b = O.synthetic_batch(rays, seed=0, step=it)
+        t0 = time.perf_counter()
+        O.render(p, mc, b["rays_o"], b["rays_d"], b["near"], b["far"], t_rand=b["t_rand"], cos_anneal_ratio=1.0)
+        dt = time.perf_counter() - t0
+        print(f"[bench] cpu baseline render {it}: {dt:.2f} s", file=sys.stderr, flush=True)
+        if it > 0:
+            times.append(dt)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": rays / med, "unit": "rays/s", "cores": threads, "kind": "port",
+            "sample": f"{steps} timed calls (+1 warm-up) of oracle/rnb_oracle.py::render on {rays} rays x ({samples // 2}+"
+                      f"{samples // 2}) samples, torch {torch.__version__} CPU fp32, {threads} threads; median {med:.3f} s"}
+
+
 def cpu_baseline_mesh(n_points):
     """CPU leg of --mode mesh: the oracle's SDF forward (models/fields.py:82-108) on a bounded sample of grid points."""
     import torch
@@ -244,6 +296,51 @@ def init_distributed(args):
     if args.gpus != world and rank == 0:
         print(f"[bench] --gpus {args.gpus} but WORLD_SIZE {world}: using {world}", file=sys.stderr)
     return world, rank, dev, backend, rehearsal
+
+
+def synthetic_capture(R, dev, n_views, H, W, n_lights=3):
+    """HBM-resident stacks shaped like the reference's Dataset tensors (models/dataset.py:219-239): images and
+    per-pixel light directions [V, L, H, W, 3], masks [V, H, W, 1], inverse intrinsics and poses [V, 4, 4].  Cameras
+    sit on the radius-3 sphere looking at the origin with a field of view that just holds the unit sphere; the mask
+    is the silhouette of the radius-0.5 ball (the geometric init).  Generated on the device, view by view."""
+    import math
+    import torch
+    g = torch.Generator(device=dev).manual_seed(0)
+    gv = torch.Generator("cpu").manual_seed(0)
+    c = torch.randn(n_views, 3, generator=gv)
+    c = 3.0 * c / c.norm(dim=-1, keepdim=True)
+    fwd = -c / c.norm(dim=-1, keepdim=True)
+    up0 = torch.tensor([0.0, 0.0, 1.0]).expand_as(fwd).clone()
+    up0[fwd[:, 2].abs() > 0.9] = torch.tensor([1.0, 0.0, 0.0])
+    right = torch.linalg.cross(up0, fwd)
+    right = right / right.norm(dim=-1, keepdim=True)
+    up = torch.linalg.cross(fwd, right)
+    pose = torch.eye(4).repeat(n_views, 1, 1)
+    pose[:, :3, 0], pose[:, :3, 1], pose[:, :3, 2], pose[:, :3, 3] = right, up, fwd, c
+    focal = 0.5 * min(H, W) / math.tan(math.asin(1.0 / 3.0))
+    K = torch.eye(4)
+    K[0, 0] = K[1, 1] = focal
+    K[0, 2], K[1, 2] = W / 2.0, H / 2.0
+    Kinv = torch.inverse(K).repeat(n_views, 1, 1)
+    images = torch.empty(n_views, n_lights, H, W, 3, device=dev)
+    lights = torch.empty(n_views, n_lights, H, W, 3, device=dev)
+    masks = torch.empty(n_views, H, W, 1, device=dev)
+    ys, xs = torch.meshgrid(torch.arange(H, device=dev, dtype=torch.float32),
+                            torch.arange(W, device=dev, dtype=torch.float32), indexing="ij")
+    pix = torch.stack([xs, ys, torch.ones_like(xs)], -1)                          # [H, W, 3]
+    for v in range(n_views):
+        images[v].uniform_(0.0, 1.0, generator=g)
+        lights[v].normal_(generator=g)
+        lights[v] /= lights[v].norm(dim=-1, keepdim=True)
+        d = pix @ Kinv[v, :3, :3].T.to(dev)
+        d = d / d.norm(dim=-1, keepdim=True)
+        d = d @ pose[v, :3, :3].T.to(dev)
+        o = c[v].to(dev)
+        closest = o + d * (-(o * d).sum(-1, keepdim=True))
+        masks[v] = (closest.norm(dim=-1, keepdim=True) < 0.5).float()
+    lw = torch.randn(n_views, n_lights, 3, generator=gv)
+    lw = lw / lw.norm(dim=-1, keepdim=True)
+    return R.DeviceRays(images, None, masks, lights, lw, Kinv, pose, dev)
 
 
 def build_model(R, dev, samples, dtype, deterministic, fwd_ti=0, bwd_ti=0, dw_staged=False, x3=False, fwd_nw=0, bwd_nw=0, f32_mfma=False):
@@ -307,9 +404,34 @@ def run_train(args):
         batches.append({k: v.to(dev) for k, v in mine.items()})
 
     group = dist.group.WORLD if (world > 1 and exact_dp) else None
+    forward_only = args.mode == "render"
+    capture = None
+    if args.device_rays:
+        if forward_only or args.warmup_mode:
+            raise SystemExit("--device-rays measures the train_rnb step in main mode")
+        V, Hh, Ww = (int(x) for x in args.stack.lower().split("x"))
+        capture = synthetic_capture(R, dev, V, Hh, Ww)
+        torch.cuda.synchronize()
+        if rank == 0:
+            gb = sum(t.numel() * 4 for t in (capture.images, capture.light_directions, capture.masks)) / 1e9
+            print(f"[bench] synthetic capture {V} x {Hh} x {Ww} resident in HBM: {gb:.2f} GB", file=sys.stderr, flush=True)
+    use_capture = [capture is not None]
 
     def step(i):
-        b = batches[i % n_batches]
+        if forward_only:
+            # NeuSRenderer.render under no_grad (models/renderer.py:556-648; validate_image's call): sampling + fine
+            # forward + composite, nothing saved for a backward (FLAG_FORWARD_ONLY)
+            b = batches[i % n_batches]
+            with torch.no_grad():
+                out = ren.render(b["rays_o"], b["rays_d"], b["near"], b["far"], cos_anneal_ratio=1.0, t_rand=b["t_rand"])
+            return out["color_fine"].sum()
+        if use_capture[0]:
+            # exp_runner.py:174-220 on the device: pixel draw, ray / target / per-pixel light gather, near / far — one
+            # launch (+ two torch.randint) inside the step; the perturbation draw is the renderer's own torch.rand
+            b = capture.sample(i % capture.n_images, B)
+            b["t_rand"] = None
+        else:
+            b = batches[i % n_batches]
         fn = ren.render_rnb_warmup if args.warmup_mode else ren.render_rnb
         out = fn(b["rays_o"], b["rays_d"], b["near"], b["far"], b["lights_dir"], cos_anneal_ratio=1.0,
                  no_albedo=args.no_albedo, t_rand=b["t_rand"])
@@ -357,18 +479,33 @@ def run_train(args):
     final_loss = float(loss.detach())
     if rank == 0:
         print(f"[bench] timed region done: {elapsed:.3f} s for {args.steps} steps", file=sys.stderr, flush=True)
+    prestaged_ms = None
+    if capture is not None:
+        # the same steps on pre-staged batches, in the same process: what the in-step ray generation costs
+        use_capture[0] = False
+        for i in range(3):
+            step(i)
+        barrier()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            step(args.warmup + i)
+        barrier()
+        prestaged_ms = 1e3 * (time.perf_counter() - t1) / args.steps
 
     if rank == 0:
-        flags = R.native.MODE_MVPS | (R.native.FLAG_NO_ALBEDO if args.no_albedo else 0)
+        flags = (R.native.MODE_CORE if forward_only else
+                 R.native.MODE_MVPS | (R.native.FLAG_NO_ALBEDO if args.no_albedo else 0))
         tf, ff = C.c_double(), C.c_double()
         R.native.check(lib.rnb_algorithmic_flops(C.byref(ren.desc), B, flags, C.byref(tf), C.byref(ff)))
+        if forward_only:
+            tf = ff           # forward-only: (112 + 2 x 128) SDF sweeps + 128 albedo evaluations per ray
         ms_per_step = 1e3 * elapsed / args.steps
         value = B * world * args.steps / elapsed
         bf16 = args.dtype == "bf16"
         roof = None
         traffic_file = ("hbm_traffic_bf16.json" if bf16 else
                         ("r02_hbm_traffic_f32_mfma.json" if args.f32_mfma else "hbm_traffic.json"))
-        tr = measured_traffic(traffic_file, world, B, S)
+        tr = None if (forward_only or capture is not None) else measured_traffic(traffic_file, world, B, S)
         if use_events and gemm_n.value > 0:
             ach = gemm_fl.value / (gemm_ms.value * 1e-3) / 1e12
             step_tf = tf.value / (ms_per_step * 1e-3) / 1e12
@@ -401,10 +538,13 @@ def run_train(args):
                         "step_frac": round(step_tf / peak, 4),
                         "step_frac_of_fp32_mfma_peak": round(step_tf / FP32_MFMA_PEAK_TFLOPS, 4)}
                 roof.update(common)
-                by = kernel_classes(lib, args.steps, peak)
+                by = kernel_classes(lib, args.steps, peak, tr)
                 if by:
                     roof["dominant_kernel"] = by[0]     # the class with the largest share of the step
                     roof["by_kernel_class"] = by
+                    if any(k.get("bound") == "hbm" for k in by):
+                        roof["bound_note"] = ("family label `bound` = the roof of the dominant class; classes marked "
+                                              "bound: hbm in by_kernel_class move > 4 TB/s and are co-bound by HBM")
             else:
                 # bf16 sweeps: 1/16 of the fp32 matrix time, so the per-point saved state decides: the bound is HBM.
                 # achieved = algorithmic bytes of the MFMA-family launches (each saved-state matrix written once and
@@ -426,14 +566,16 @@ def run_train(args):
                         "mfma_tflops": round(ach, 2), "mfma_frac_of_bf16_peak": round(ach / BF16_MFMA_PEAK_TFLOPS, 4),
                         "step_frac_of_bf16_peak": round(step_tf / BF16_MFMA_PEAK_TFLOPS, 4)}
                 roof.update(common)
-                by = kernel_classes(lib, args.steps, BF16_MFMA_PEAK_TFLOPS)
+                by = kernel_classes(lib, args.steps, BF16_MFMA_PEAK_TFLOPS, tr)
                 if by:
                     roof["by_kernel_class"] = by
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(B, S, args.cpu_steps, args.warmup_mode, args.no_albedo)
+            cpu = (cpu_baseline_render(B, S, args.cpu_steps) if forward_only else
+                   cpu_baseline(B, S, args.cpu_steps, args.warmup_mode, args.no_albedo))
         line = {
-            "metric": f"training rays/sec at {B} rays x {S} samples/ray",
+            "metric": (f"forward-only rays/sec (NeuSRenderer.render, no_grad) at {B} rays x {S} samples/ray" if forward_only
+                       else f"training rays/sec at {B} rays x {S} samples/ray"),
             "value": round(value, 1), "unit": "rays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "ms_per_step_median": round(median_ms, 3), "higher_is_better": True,
@@ -454,6 +596,20 @@ def run_train(args):
             "roofline": roof,
             "cpu_baseline": cpu,
         }
+        if forward_only:
+            line["config"]["workload"] = ("DiLiGenT-MV-shaped synthetic rays, wmask_rnb.conf networks, NeuSRenderer.render "
+                                          f"under no_grad (sampling + fine forward + composite), {B} rays x "
+                                          f"({S // 2}+{S // 2}) samples per GPU, geometric init")
+            line["config"]["train_ops"] = None
+        if capture is not None:
+            line["config"]["device_rays"] = {
+                "stack": args.stack, "hbm_gb": round(sum(t.numel() * 4 for t in (capture.images, capture.light_directions,
+                                                                                  capture.masks)) / 1e9, 2),
+                "ms_per_step_with_in_step_ray_generation": round(ms_per_step, 3),
+                "ms_per_step_prestaged_batches": round(prestaged_ms, 3),
+                "delta_ms": round(ms_per_step - prestaged_ms, 3),
+                "note": "DeviceRays.sample() (2 x torch.randint + rnb_gen_rays_at_view) and the renderer's own torch.rand "
+                        "inside the timed step; `value` is this configuration"}
         if rehearsal:
             line["rehearsal"] = True
             line["config"]["note"] = ("ranks share ONE GPU over gloo: functional rehearsal of the N > 1 path, not a "

@@ -250,7 +250,7 @@ RNB_API int rnb_gather_sdf(const float* sdf_old, const float* sdf_new, const int
 struct SampleBufs {
   float* z[2];
   float* sdf[2];
-  int32_t* index;
+  int32_t* index[2];   // sort index of a step (read by the next step's kernel while that one writes its own: ping-pong)
   float* pts;      // [B*n_samples,3] coarse points, later [B*n_new,3]
   PointBufs pb;    // sized for B*n_samples points
   size_t pb_off;   // carve offset of the point buffers
@@ -260,7 +260,7 @@ static void carve_sample(const Layout& L, const rnb_model_desc* d, Carver& c, in
   const int S = d->n_samples + d->n_importance;
   for (int i = 0; i < 2; ++i) sb->z[i] = c.take<float>(B * S);
   for (int i = 0; i < 2; ++i) sb->sdf[i] = c.take<float>(B * S);
-  sb->index = c.take<int32_t>(B * S);
+  for (int i = 0; i < 2; ++i) sb->index[i] = c.take<int32_t>(B * S);
   sb->pts = c.take<float>(B * d->n_samples * 3);
   sb->pb_off = c.off;
   carve_points(L, c, B * d->n_samples, PM_SDF_ONLY, &sb->pb);
@@ -318,22 +318,32 @@ RNB_API int rnb_sample_rays(const rnb_model_desc* desc, const float* packed, con
 
   RNB_TRY(launch_z_init(rays_o, rays_d, near, far, t_rand, B, n0, sb.z[0], sb.pts, s));
   RNB_TRY(forward_points(L, packed, sb.pts, B * n0, sb.pb, false, false, false, nullptr, s));
-  RNB_CHECK_HIP(hipMemcpyAsync(sb.sdf[0], sb.pb.sdf, (size_t)B * n0 * sizeof(float), hipMemcpyDeviceToDevice, s));
+  // The SDF row travels through the loop inside the up-sampling kernel itself (renderer.py:185-190: sdf = cat[sdf,
+  // new_sdf] gathered by the sort index): step i reads the row step i - 1 left sorted, the SDF of the points step i - 1
+  // proposed and its sort index, and leaves the merged row for step i + 1 — no separate gather launches, no copy of the
+  // coarse row out of the point buffers (which the next forward re-carves).
+  const float* sdf_old = sb.pb.sdf;    // step 0: the coarse row, as the forward wrote it
+  const float* sdf_new = nullptr;
+  const int32_t* gidx = nullptr;
+  int n_old = n0;
   int cur = 0;
   int n = n0;
   for (int i = 0; i < steps; ++i) {
     const bool last = (i + 1 == steps);
     float* z_next = last ? z_vals_out : sb.z[cur ^ 1];
-    RNB_TRY(launch_up_sample_step(rays_o, rays_d, sb.z[cur], sb.sdf[cur], nullptr, nullptr, n, B, n, n_new,
-                                  (float)(64 << i), nullptr, nullptr, z_next, last ? nullptr : sb.index,
-                                  last ? nullptr : sb.pts, nullptr, s));
+    RNB_TRY(launch_up_sample_step(rays_o, rays_d, sb.z[cur], sdf_old, sdf_new, gidx, n_old, B, n, n_new,
+                                  (float)(64 << i), nullptr, nullptr, z_next, last ? nullptr : sb.index[i & 1],
+                                  last ? nullptr : sb.pts, last ? nullptr : sb.sdf[cur ^ 1], s));
     if (!last) {
-      // SDF of the new points (renderer.py:185), then carry the SDF row through the sort (:186-190)
+      // SDF of the new points (renderer.py:185)
       Carver c2((char*)ws + sb.pb_off, ws_bytes - sb.pb_off);
       PointBufs pbn;
       carve_points(L, c2, B * n_new, PM_SDF_ONLY, &pbn);
       RNB_TRY(forward_points(L, packed, sb.pts, B * n_new, pbn, false, false, false, nullptr, s));
-      RNB_TRY(launch_gather_sdf(sb.sdf[cur], pbn.sdf, sb.index, B, n, n_new, sb.sdf[cur ^ 1], s));
+      sdf_old = sb.sdf[cur ^ 1];       // this step's input row in sorted order (n entries)
+      sdf_new = pbn.sdf;
+      gidx = sb.index[i & 1];
+      n_old = n;
     }
     cur ^= 1;
     n += n_new;

@@ -605,7 +605,9 @@ __global__ __launch_bounds__(256, OCC) void gemm_dw_direct_kernel(const DwGroup 
 template <int DUMMY>
 __global__ __launch_bounds__(256) void dw_reduce_kernel(const DwGroup g) {
   const DwJob& J = g.job[blockIdx.y];
-  const size_t n = (size_t)J.N * J.lddw;
+  // slabs [split][N][K] (K == lddw for whole-matrix jobs; a column range of a wider matrix has K < lddw)
+  const size_t n = (size_t)J.N * J.K;
+  const bool dense = J.K == J.lddw;
   for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (size_t)gridDim.x * 256) {
     // four interleaved running sums (splits 0, 4, 8 .. / 1, 5, .. / ..) combined in a fixed order: as reproducible as one
     // chain, but four loads in flight instead of one
@@ -616,7 +618,8 @@ __global__ __launch_bounds__(256) void dw_reduce_kernel(const DwGroup g) {
       for (int u = 0; u < 4; ++u) s[u] += (double)J.part[(size_t)(sp + u) * n + idx];
     }
     for (int u = 0; sp < J.splits; ++sp, ++u) s[u] += (double)J.part[(size_t)sp * n + idx];
-    J.dW[idx] = (float)((s[0] + s[1]) + (s[2] + s[3]));
+    const size_t dst = dense ? idx : (idx / (size_t)J.K) * (size_t)J.lddw + idx % (size_t)J.K;
+    J.dW[dst] = (float)((s[0] + s[1]) + (s[2] + s[3]));
   }
   if (J.db != nullptr && J.partb != nullptr) {
     for (int r = blockIdx.x * 256 + threadIdx.x; r < J.N; r += gridDim.x * 256) {
@@ -972,6 +975,37 @@ __device__ inline void dw_x3_chunk(const char* fx, const char* fy, v16f (&acc)[2
   }
   __builtin_amdgcn_sched_barrier(0);
 }
+// The same for a NARROW job (Y operand of 64 columns: the PE-input layer, the tail of the albedo net's 320-wide first
+// layer): wave (wm, wn) owns rows 64 wm .. + 64, columns 32 wn .. + 32 — 12 MFMAs per chunk; the staging split of the
+// thread's whole 4 x 4 raw block rides between them (st_on: lanes that stage nothing skip the stores).
+__device__ inline void dw_x3_chunk_narrow(const char* fx, const char* fy, v16f (&acc)[2][1], const vf4 (&x)[4], char* w,
+                                          bool st_on) {
+  vu4x a[2][3], b[3];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) a[t][pl] = *reinterpret_cast<const vu4x*>(fx + pl * kX3Plane + t * 128);
+#pragma unroll
+  for (int pl = 0; pl < 3; ++pl) b[pl] = *reinterpret_cast<const vu4x*>(fy + pl * kX3Plane);
+  constexpr int PA[6] = {2, 0, 1, 1, 0, 0};   // small terms first (x3_mfma)
+  constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+  for (int t = 0; t < 6; ++t)
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+      acc[ti][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(x3bf8, a[ti][PA[t]]),
+                                                           __builtin_bit_cast(x3bf8, b[PB[t]]), acc[ti][0], 0, 0, 0);
+  vu2x hi[4], mid[4], lo[4];
+  dw_x3_split(x, hi, mid, lo);
+  __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);
+#pragma unroll
+  for (int m = 0; m < 12; ++m) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  if (st_on) dw_x3_store(w, hi, mid, lo);
+}
 __device__ inline void dw_x3_colsum(const vf4 (&x)[4], bool on, double (&bs)[4]) {
   if (!on) return;
 #pragma unroll
@@ -980,35 +1014,32 @@ __device__ inline void dw_x3_colsum(const vf4 (&x)[4], bool on, double (&bs)[4])
 
 // DUMMY == 1 (tools/dwx3_bench only): wave 0 sums the clocks it spends waiting at the barrier / issuing a chunk's
 // reads, MFMAs, split and stores / issuing the next loads, and leaves them in J.db (as uint64[8] per workgroup)
-template <int DUMMY>
-__global__ __launch_bounds__(512, 1) void gemm_dw_x3_kernel(const DwGroup g) {
-  __shared__ __attribute__((aligned(16))) char lds[2 * kX3BufBytes];   // 102 KB
+template <int DUMMY, bool NARROW>
+__device__ inline void dw_x3_body(const DwGroup& g, const DwJob& J, int split, char* lds) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = wave_id();
   const int wm = wave >> 1, wn = wave & 1;
-  int ji = 0, begin = 0;
-  for (int q = 0; q + 1 < g.njobs; ++q)
-    if ((int)blockIdx.x >= g.job[q].block_end) { ji = q + 1; begin = g.job[q].block_end; }
-  const DwJob& J = g.job[ji];
-  const int split = (int)blockIdx.x - begin;
-  if (split >= J.splits) return;
   const int m_begin = split * J.rows_per_split;
   const int m_end = min(g.M, m_begin + J.rows_per_split);
-  if (m_begin >= m_end) return;
+  if (m_begin >= m_end) return;   // (workgroup-uniform)
   const int nchunks = (m_end - m_begin) / kX3Chunk;   // even: ranges are multiples of 32 points (host)
+  // narrow job: the Y operand has 64 columns (J.K == 64); everything about X and the row split stays
+  constexpr bool narrow = NARROW;
   // staging role of this thread: columns 4 cg .. + 4, points 4 pq .. + 4 of operand sop
   const int cg = lane, pq = wave & 3, sop = wave >> 2;
+  const bool st_on = !(narrow && sop == 1 && cg >= 16);   // a narrow Y row is 16 column groups
   char* const swr = lds + sop * kX3OpBytes + (pq >> 1) * kX3Half + cg * 16 + (pq & 1) * 8;   // + buffer, column, plane
   // fragment addresses of this lane: column 64 wm (128 wn) + 32 t + i of the operand, point half h
   const int i = lane & 31, h = lane >> 5;
   const int ui = (i & 3) * 68 + (i >> 2);
   const char* const fx = lds + h * kX3Half + (ui + 16 * wm) * 16;
-  const char* const fy = lds + kX3OpBytes + h * kX3Half + (ui + 32 * wn) * 16;
-  v16f acc[2][4];
+  const char* const fy = lds + kX3OpBytes + h * kX3Half + (ui + (narrow ? 8 : 32) * wn) * 16;
+  constexpr int NTJ = NARROW ? 1 : 4;
+  v16f acc[2][NTJ];
 #pragma unroll
   for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
-    for (int tj = 0; tj < 4; ++tj)
+    for (int tj = 0; tj < NTJ; ++tj)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[ti][tj][r] = 0.f;
   double bs[4] = {0.0, 0.0, 0.0, 0.0};
@@ -1021,7 +1052,7 @@ __global__ __launch_bounds__(512, 1) void gemm_dw_x3_kernel(const DwGroup g) {
     // resource based at this split's first row: 32-bit offsets stay inside the split whatever the total point count
     const BufRsrc src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>((sop == 0 ? p.X : p.Y) + (size_t)m_begin * ld), 0,
                                                           0xfffffffc, 0x00020000);
-    const unsigned voff = 16u * (unsigned)cg;
+    const unsigned voff = st_on ? 16u * (unsigned)cg : 0u;   // (lanes that stage nothing re-read column group 0)
     const bool do_bias = DUMMY == 0 && J.db != nullptr && pi == J.bias_pair && sop == 0;
     const int last = nchunks - 1;
     const int r0 = 4 * pq;   // (rows relative to the split)
@@ -1032,7 +1063,7 @@ __global__ __launch_bounds__(512, 1) void gemm_dw_x3_kernel(const DwGroup g) {
     {
       vu2x hi[4], mid[4], lo[4];
       dw_x3_split(x0, hi, mid, lo);
-      dw_x3_store(swr, hi, mid, lo);
+      if (st_on) dw_x3_store(swr, hi, mid, lo);
       dw_x3_colsum(x0, do_bias, bs);
     }
     dw_x3_load(src, voff, ld, r0 + min(2, last) * kX3Chunk, x0);
@@ -1042,7 +1073,8 @@ __global__ __launch_bounds__(512, 1) void gemm_dw_x3_kernel(const DwGroup g) {
       [[maybe_unused]] const unsigned long long s0 = DUMMY == 1 ? __builtin_amdgcn_s_memtime() : 0;
       __builtin_amdgcn_s_barrier();
       [[maybe_unused]] const unsigned long long s1 = DUMMY == 1 ? __builtin_amdgcn_s_memtime() : 0;
-      dw_x3_chunk(fx, fy, acc, x1, swr + kX3BufBytes);
+      if constexpr (narrow) dw_x3_chunk_narrow(fx, fy, acc, x1, swr + kX3BufBytes, st_on);
+      else dw_x3_chunk(fx, fy, acc, x1, swr + kX3BufBytes);
       dw_x3_colsum(x1, do_bias, bs);   // (nchunks even: chunk c + 1 always exists)
       [[maybe_unused]] const unsigned long long s2 = DUMMY == 1 ? __builtin_amdgcn_s_memtime() : 0;
       dw_x3_load(src, voff, ld, r0 + min(c + 3, last) * kX3Chunk, x1);
@@ -1054,23 +1086,25 @@ __global__ __launch_bounds__(512, 1) void gemm_dw_x3_kernel(const DwGroup g) {
       // nobody reads); x0 <- chunk c + 4
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      dw_x3_chunk(fx + kX3BufBytes, fy + kX3BufBytes, acc, x0, swr);
+      if constexpr (narrow) dw_x3_chunk_narrow(fx + kX3BufBytes, fy + kX3BufBytes, acc, x0, swr, st_on);
+      else dw_x3_chunk(fx + kX3BufBytes, fy + kX3BufBytes, acc, x0, swr);
       dw_x3_colsum(x0, do_bias && c + 2 < nchunks, bs);
       dw_x3_load(src, voff, ld, r0 + min(c + 4, last) * kX3Chunk, x0);
     }
   }
   // accumulator (ti, tj, r) of lane (i, h) is dW[64 wm + 32 ti + rho][128 wn + 32 tj + i], rho = (r & 3) + 8 (r >> 2) + 4 h
-  const int lddw = J.lddw;
-  float* __restrict__ pdst = J.part ? J.part + (size_t)split * J.N * lddw : nullptr;
+  // slabs are compact [split][N][K] (K = the job's Y columns; dw_reduce_kernel scatters them into dW with lddw)
+  const int lddw = J.lddw, Kj = J.K;
+  float* __restrict__ pdst = J.part ? J.part + (size_t)split * J.N * Kj : nullptr;
 #pragma unroll
-  for (int tj = 0; tj < 4; ++tj) {
-    const int col = wn * 128 + tj * 32 + i;
+  for (int tj = 0; tj < NTJ; ++tj) {
+    const int col = narrow ? wn * 32 + i : wn * 128 + tj * 32 + i;
 #pragma unroll
     for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = wm * 64 + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (pdst) pdst[(size_t)row * lddw + col] = acc[ti][tj][r];
+        if (pdst) pdst[(size_t)row * Kj + col] = acc[ti][tj][r];
         else atomicAdd(J.dW + (size_t)row * lddw + col, acc[ti][tj][r]);
       }
   }
@@ -1096,6 +1130,21 @@ __global__ __launch_bounds__(512, 1) void gemm_dw_x3_kernel(const DwGroup g) {
       else atomicAdd(J.db + tid, v);
     }
   }
+}
+
+
+template <int DUMMY>
+__global__ __launch_bounds__(512, 1) void gemm_dw_x3_kernel(const DwGroup g) {
+  __shared__ __attribute__((aligned(16))) char lds[2 * kX3BufBytes];   // 102 KB
+  int ji = 0, begin = 0;
+  for (int q = 0; q + 1 < g.njobs; ++q)
+    if ((int)blockIdx.x >= g.job[q].block_end) { ji = q + 1; begin = g.job[q].block_end; }
+  const DwJob& J = g.job[ji];
+  const int split = (int)blockIdx.x - begin;
+  if (split >= J.splits) return;
+  // two bodies, one per job width (workgroup-uniform): separate accumulator sets, separate register allocation
+  if (J.K < 256) dw_x3_body<DUMMY, true>(g, J, split, lds);
+  else dw_x3_body<DUMMY, false>(g, J, split, lds);
 }
 
 // ---- activation helpers ----------------------------------------------------------------------------

@@ -670,6 +670,20 @@ static void dw_staged_plan(int64_t M, int npairs, int total_pairs, int* splits_o
   *rows_out = (int)rows;
 }
 
+// Jobs of the one-workgroup-per-gradient kernels.  The LDS-DMA staged kernel takes 256 x 256 matrices only; the x3
+// kernel also takes 256 x K with K a multiple of 64 as COLUMN RANGES of the Y operand: 256-column ranges run as whole
+// jobs, what is left as narrow (64-column) jobs — the PE-input layer (K = 64) and the albedo net's first layer
+// (K = 320 = 256 + 64) then ride in the same launch instead of a separate fp32-MFMA one.  Work units for the split
+// plan: a 256-column pair costs about twice a narrow pair (a quarter of the MFMAs, the same staging of X).
+static bool x3_job_shape(bool x3, int N, int K) { return N == 256 && (K == 256 || (x3 && K % 64 == 0 && K >= 64 && K <= 1024)); }
+static int x3_job_units(int npairs, int width) { return npairs * (width >= 256 ? 2 : 1); }
+template <class F>
+static void x3_for_each_range(int K, F f) {   // f(first column, width): 256-wide ranges, then 64-wide ones
+  int c = 0;
+  for (; c + 256 <= K; c += 256) f(c, 256);
+  for (; c + 64 <= K; c += 64) f(c, 64);
+}
+
 struct DwBatch {
   DwGroup grp[4];     // [0] K % 128 == 0, [1] K % 64 == 0, [2] anything (guarded), [3] 256 x 256 (LDS-DMA staged)
   double flops[4];
@@ -690,8 +704,8 @@ struct DwBatch {
   int flush_staged() {
     DwGroup& g = grp[3];
     if (g.njobs == 0) return RNB_OK;
-    int total_pairs = 0;
-    for (int q = 0; q < g.njobs; ++q) total_pairs += g.job[q].npairs;
+    int total_pairs = 0;   // (work units: x3_job_units)
+    for (int q = 0; q < g.njobs; ++q) total_pairs += x3_job_units(g.job[q].npairs, g.job[q].K);
     for (int a = 0, b = g.njobs - 1; a < b; ++a, --b) {   // most recently produced operands first (see flush)
       const DwJob t = g.job[a];
       g.job[a] = g.job[b];
@@ -701,9 +715,9 @@ struct DwBatch {
     for (int q = 0; q < g.njobs; ++q) {
       DwJob& j = g.job[q];
       int splits, rows;
-      dw_staged_plan(M, j.npairs, total_pairs, &splits, &rows);
+      dw_staged_plan(M, x3_job_units(j.npairs, j.K), total_pairs, &splits, &rows);
       {   // never more slabs than the workspace holds (a group smaller than the one the workspace was sized for)
-        const int64_t per_split = (int64_t)j.N * j.lddw + j.N;
+        const int64_t per_split = (int64_t)j.N * j.K + j.N;
         const int64_t room = slab != nullptr ? slab_left / per_split / (g.njobs - q) : 0;
         if (room < 1) RNB_FAIL(RNB_E_WORKSPACE, "weight-gradient slab workspace exhausted");
         if (splits > room) {
@@ -718,10 +732,10 @@ struct DwBatch {
       j.rows_per_split = rows;
       end += splits;
       j.block_end = end;
-      const int64_t need = (int64_t)splits * j.N * j.lddw + (int64_t)splits * j.N;
+      const int64_t need = (int64_t)splits * j.N * j.K + (int64_t)splits * j.N;
       if (slab == nullptr || need > slab_left) RNB_FAIL(RNB_E_WORKSPACE, "weight-gradient slab workspace exhausted");
       j.part = slab;
-      j.partb = slab + (int64_t)splits * j.N * j.lddw;
+      j.partb = slab + (int64_t)splits * j.N * j.K;
       slab += need;
       slab_left -= need;
     }
@@ -779,13 +793,22 @@ struct DwBatch {
   int add(DwPair p1, DwPair p2, int npairs, int N, int K, float* dW, int lddw, float* db, int bias_pair, double fl) {
     int v, splits, rows;
     dw_plan(M, N, K, &v, &splits, &rows);
-    if (v == 0 && N == 256 && K == 256 && M % kStChunk == 0 && !lds_path && !no_staged) {   // -> the staged kernel
-      if (grp[3].njobs == kMaxDwJobs) RNB_TRY(flush_staged());
-      DwJob& j = grp[3].job[grp[3].njobs++];
-      j.p1 = p1; j.p2 = p2; j.dW = dW; j.db = db;
-      j.part = nullptr; j.partb = nullptr;
-      j.npairs = npairs; j.N = N; j.K = K; j.lddw = lddw; j.bias_pair = bias_pair;
-      j.splits = 0; j.rows_per_split = 0; j.block_end = 0;
+    if (x3_job_shape(x3, N, K) && M % kStChunk == 0 && !lds_path && !no_staged) {   // -> the one-workgroup-per-gradient kernel
+      int rc = RNB_OK;
+      x3_for_each_range(K, [&](int c0, int width) {
+        if (rc != RNB_OK) return;
+        if (grp[3].njobs == kMaxDwJobs) rc = flush_staged();
+        if (rc != RNB_OK) return;
+        DwJob& j = grp[3].job[grp[3].njobs++];
+        j.p1 = p1; j.p2 = p2;
+        j.p1.Y += c0; j.p2.Y += c0;              // column range of the Y operands (their leading dimension stays)
+        j.dW = dW + c0;
+        j.db = c0 == 0 ? db : nullptr;            // the bias sums (columns of X) belong to the first range
+        j.part = nullptr; j.partb = nullptr;
+        j.npairs = npairs; j.N = N; j.K = width; j.lddw = lddw; j.bias_pair = bias_pair;
+        j.splits = 0; j.rows_per_split = 0; j.block_end = 0;
+      });
+      RNB_TRY(rc);
       flops[3] += fl;
       return RNB_OK;
     }
@@ -826,18 +849,25 @@ struct DwBatch {
 // as sweep_backward
 // floats of slab workspace of the staged kernel for one backward over M points (the 256 x 256 jobs of sweep_backward)
 int64_t dw_staged_floats(const Layout& L, int64_t M, bool with_color) {
-  int total_pairs = 0;
-  for (int l = 0; l < L.nh; ++l) total_pairs += 2 * (L.hid[l].Np == 256 && L.hid[l].Kp == 256);
+  const bool x3 = is_x3(L);
+  int total_units = 0;
+  auto units = [&](const Lin& ln, int npairs) {
+    if (!x3_job_shape(x3, ln.Np, ln.Kp)) return;
+    x3_for_each_range(ln.Kp, [&](int, int width) { total_units += x3_job_units(npairs, width); });
+  };
+  for (int l = 0; l < L.nh; ++l) units(L.hid[l], 2);
   if (with_color) {
-    total_pairs += (L.feat.Np == 256 && L.feat.Kp == 256);
-    for (int l = 0; l < L.nc; ++l) total_pairs += (L.col[l].Np == 256 && L.col[l].Kp == 256);
+    units(L.feat, 1);
+    for (int l = 0; l < L.nc; ++l) units(L.col[l], 1);
   }
   int64_t total = 0;
   auto job = [&](const Lin& ln, int npairs) {
-    if (ln.Np != 256 || ln.Kp != 256) return;
-    int splits, rows;
-    dw_staged_plan(M, npairs, total_pairs, &splits, &rows);
-    total += (int64_t)splits * 256 * 256 + (int64_t)splits * 256;
+    if (!x3_job_shape(x3, ln.Np, ln.Kp)) return;
+    x3_for_each_range(ln.Kp, [&](int, int width) {
+      int splits, rows;
+      dw_staged_plan(M, x3_job_units(npairs, width), total_units, &splits, &rows);
+      total += (int64_t)splits * 256 * width + (int64_t)splits * 256;
+    });
   };
   for (int l = 0; l < L.nh; ++l) job(L.hid[l], 2);
   if (with_color) {

@@ -20,6 +20,13 @@ constexpr int kMaxNew = 64;
 
 __device__ inline float sigmoidf_ref(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// `f` is what the double running value `v` of a scan rounds to.  True when every double within 2e-13 relative of v rounds
+// to the same fp32 value — the distance by which a differently associated scan of <= 512 terms can differ from the
+// sequential one (each of the <= 512 double operations contributes <= 2^-53 relative).  NaN: never safe.
+__device__ inline bool scan_safe(double v, float f) {
+  return (float)(v * (1.0 - 2e-13)) == f && (float)(v * (1.0 + 2e-13)) == f;
+}
+
 // The order torch.sort uses: NaN compares greater than every number (and equal to NaN).  A strict weak order on ALL
 // floats, so the rank-count merge below writes every output slot exactly once whatever the depths are.
 __device__ inline bool lt_total(float a, float b) { return a < b || (a == a && b != b); }
@@ -108,31 +115,82 @@ __global__ __launch_bounds__(64) void up_sample_kernel(UpArgs a) {
     w[j] = (prev_cdf - next_cdf + 1e-5f) / (prev_cdf + 1e-5f);   // alpha
   }
   __syncthreads();
-  // weights = alpha * cumprod([1, 1-alpha+1e-7])[:-1]; then w + 1e-5 (sample_pdf)
-  if (lane == 0) {
-    double run = 1.0;
-    for (int j = 0; j < n - 1; ++j) {
+  // weights = alpha * cumprod([1, 1-alpha+1e-7])[:-1]; then w + 1e-5 (sample_pdf).  torch.cumprod / torch.cumsum on
+  // the CPU keep the running value in double and round every output to fp32, one element after the other.  Here every
+  // lane scans a contiguous segment and the segments are chained by a wave scan — a different association of the same
+  // double products, i.e. a running value within ~n 2^-52 of the sequential one.  That can only change an fp32 OUTPUT
+  // when the running value lies that close to an fp32 rounding boundary: every output is therefore checked
+  // (scan_safe) and a ray with a single unsafe element is redone serially, so the results are bit-identical to the
+  // sequential scan in all cases.
+  const int m = n - 1;
+  const int per = (m + 63) >> 6;
+  const int j0 = min(lane * per, m), j1 = min(j0 + per, m);
+  {
+    double loc = 1.0;
+    for (int j = j0; j < j1; ++j) loc *= (double)(1.0f - w[j] + 1e-7f);
+    double inc = loc;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const double t = __shfl_up(inc, o, 64);
+      if (lane >= o) inc *= t;
+    }
+    double run = __shfl_up(inc, 1, 64);
+    if (lane == 0) run = 1.0;
+    bool safe = true;
+    for (int j = j0; j < j1; ++j) {
       const float al = w[j];
       const float T = (float)run;
+      safe = safe && scan_safe(run, T);
       run *= (double)(1.0f - al + 1e-7f);
-      w[j] = al * T + 1e-5f;
+      cs[j] = al * T + 1e-5f;             // (cs is free: the section cosines were consumed above)
+    }
+    if (__any(!safe)) {                    // wave-uniform; practically never taken
+      if (lane == 0) {
+        double r = 1.0;
+        for (int j = 0; j < m; ++j) {
+          const float al = w[j];
+          const float T = (float)r;
+          r *= (double)(1.0f - al + 1e-7f);
+          cs[j] = al * T + 1e-5f;
+        }
+      }
     }
   }
   __syncthreads();
   // pdf = w / sum(w); cdf = [0, cumsum(pdf)]
   double part = 0.0;
-  for (int j = lane; j < n - 1; j += 64) part += (double)w[j];
+  for (int j = lane; j < m; j += 64) part += (double)cs[j];
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
   const float wsum = (float)part;
-  for (int j = lane; j < n - 1; j += 64) w[j] = w[j] / wsum;
+  for (int j = lane; j < m; j += 64) w[j] = cs[j] / wsum;
   __syncthreads();
-  if (lane == 0) {
-    double run = 0.0;
-    cdf[0] = 0.f;
-    for (int j = 0; j < n - 1; ++j) {
+  {
+    double loc = 0.0;
+    for (int j = j0; j < j1; ++j) loc += (double)w[j];
+    double inc = loc;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const double t = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += t;
+    }
+    double run = __shfl_up(inc, 1, 64);
+    if (lane == 0) { run = 0.0; cdf[0] = 0.f; }
+    bool safe = true;
+    for (int j = j0; j < j1; ++j) {
       run += (double)w[j];
-      cdf[j + 1] = (float)run;
+      const float c = (float)run;
+      safe = safe && scan_safe(run, c);
+      cdf[j + 1] = c;
+    }
+    if (__any(!safe)) {
+      if (lane == 0) {
+        double r = 0.0;
+        for (int j = 0; j < m; ++j) {
+          r += (double)w[j];
+          cdf[j + 1] = (float)r;
+        }
+      }
     }
   }
   __syncthreads();
