@@ -33,6 +33,9 @@ struct FusedBwdArgs {
   float* D[RNB_MAX_LIN];
   float* gz[RNB_MAX_LIN];
   float* u[RNB_MAX_LIN + 1];
+  long long M;          // real points (rows >= M of the last tile are padding)
+  float* ucol;          // RA: [tiles][FH] column sums of u_nh per point tile INSTEAD of the matrix u_nh (its only reader is
+                        // the sdf-head row gradient, which wants exactly these sums), or nullptr: store u_nh
   float* zR[RNB_MAX_LIN];
   float* zb[RNB_MAX_LIN];
   const float* x4;      // [Mp,4]
@@ -282,6 +285,27 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TI == 2) ? 1 : 2) void fused_r
     const int n_real = g.n_real[l];
     const bool pe_tail = (l + 1 == g.skip);
     const BufRsrc rzR = tile_rsrc(g.zR[l] + (size_t)row0 * FH, BT * FH * 4);
+    if (l + 1 == g.nh && g.ucol != nullptr) {
+      // last layer: u_nh feeds nothing but the column sums of the sdf-head row gradient.  Every wave owns its columns
+      // for all rows of the tile: sum the lane's 16 TI values per column tile, fold the two lane halves, one store per
+      // column — 64 MB less to write here and to read there.  (No tile is written to LDS: nothing follows.)
+      float cs[TJ];
+#pragma unroll
+      for (int tj = 0; tj < TJ; ++tj) cs[tj] = 0.f;
+      for_each_acc<TI, TJ>(n0, lane_e, [&](int tj, int ti, int r, int col, int rowc, int row) {
+        const float v = acc[ti][tj][r];
+        const float un = col < n_real ? v * aD.v[ti][tj][r] : 0.f;
+        const float zr = col < n_real ? ((v - un) * aG.v[ti][tj][r]) * 100.f : 0.f;
+        bstore(rzR, (unsigned)(4 * h * FH + col) * 4u, rowc * FH * 4, zr);
+        cs[tj] += (row0 + row < g.M) ? un : 0.f;     // padding rows hold whatever the workspace held
+      });
+#pragma unroll
+      for (int tj = 0; tj < TJ; ++tj) {
+        const float tot = cs[tj] + __shfl_xor(cs[tj], 32, 64);
+        if (lane_e < 32) g.ucol[(size_t)blockIdx.x * FH + n0 + tj * 32 + lane_e] = tot;
+      }
+      break;
+    }
     const BufRsrc ru = tile_rsrc(g.u[l + 1] + (size_t)row0 * FH, BT * FH * 4);
     for_each_acc_split<TI, TJ>(
         n0, lane_e, n_real,
@@ -424,6 +448,8 @@ static void fill_args(const Layout& L, const float* packed, PointBufs& pb, Fused
   for (int l = 1; l <= L.nh; ++l) g.u[l] = pb.u[l];
   g.wsdf_off = L.wsdf_off;
   g.wfT_off = L.feat.wT_off;
+  g.M = pb.M;
+  g.ucol = nullptr;
   g.x4 = pb.x;
   g.nrm = pb.nrm;
   g.geb = pb.geb;
@@ -478,11 +504,17 @@ int fused_reverse(const Layout& L, const float* packed, PointBufs& pb, hipStream
   return RNB_OK;
 }
 
-int fused_ra(const Layout& L, const float* packed, PointBufs& pb, hipStream_t s) {
+// u_tiles != nullptr: the last layer leaves per-tile column sums of u_nh in pb.u[nh] ([tiles][256], *u_tiles tiles)
+// instead of the matrix (see FusedBwdArgs::ucol)
+int fused_ra(const Layout& L, const float* packed, PointBufs& pb, hipStream_t s, int* u_tiles) {
   FusedBwdArgs g;
   fill_args(L, packed, pb, g);
   ProfScope prof(hidden_flops(L, pb.M, 0), s, "RA_sweep");
   const int ti = bwd_ti(L, is_x3(L) ? 2 : 1), nw = bwd_nw(L, is_x3(L) ? 4 : 8);
+  if (u_tiles != nullptr) {
+    g.ucol = pb.u[L.nh];
+    *u_tiles = (int)(pb.Mp / (32 * ti));
+  }
   const dim3 grid((unsigned)(pb.Mp / (32 * ti))), block(64 * nw);
   if (is_x3(L)) {
     if (ti == 2 && nw == 8) hipLaunchKernelGGL((fused_ra_kernel<2, 8, true>), grid, block, 0, s, g);

@@ -340,7 +340,9 @@ __global__ __launch_bounds__(64) void nbar_geb_kernel(const float* __restrict__ 
 // phases), i.e. every row contributes one 128-byte line per matrix, and an output address only receives one
 // atomic per row slab (same-address atomics serialise in the L2: with whole-row workgroups every address took
 // one atomic from every workgroup).  fp64 partial sums (long signed sums).
+// ulast == nullptr: u_nh arrives as per-tile column sums `ucol` [ntiles][Hp] (fused RA sweep), added by the first row slab.
 __global__ __launch_bounds__(512) void sdf_head_bwd_kernel(const float* __restrict__ a, const float* __restrict__ ulast,
+                                                           const float* __restrict__ ucol, int ntiles,
                                                            int Hp, int H, const float* __restrict__ sbar,
                                                            float inv_scale, int64_t M, int rows_per_blk,
                                                            float* __restrict__ dwsdf, float* __restrict__ dbsdf) {
@@ -356,9 +358,21 @@ __global__ __launch_bounds__(512) void sdf_head_bwd_kernel(const float* __restri
     const float t = sbar[row] * inv_scale;
     if (cg == 0) sb += (double)t;
     const vf4 av = *reinterpret_cast<const vf4*>(a + row * Hp + k0);
-    const vf4 uv = *reinterpret_cast<const vf4*>(ulast + row * Hp + k0);
+    if (ulast != nullptr) {
+      const vf4 uv = *reinterpret_cast<const vf4*>(ulast + row * Hp + k0);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) s[j] += (double)(t * av[j] + uv[j]);
+      for (int j = 0; j < 4; ++j) s[j] += (double)(t * av[j] + uv[j]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s[j] += (double)(t * av[j]);
+    }
+  }
+  if (ulast == nullptr && blockIdx.x == 0) {
+    for (int tile = ph; tile < ntiles; tile += 64) {
+      const vf4 uv = *reinterpret_cast<const vf4*>(ucol + (size_t)tile * Hp + k0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s[j] += (double)uv[j];
+    }
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) red[ph][kl + j] = s[j];
@@ -1047,8 +1061,9 @@ int sweep_backward(const Layout& L, const float* packed, PointBufs& pb, bool wit
     return bf16_backward(L, packed, pb, with_color, color_bf16, packed_grad, s);
   }
   // ---- RA: adjoint of the reverse sweep, forward layer order -----------------------------------------
+  int u_tiles = 0;
   if (fused) {
-    RNB_TRY(fused_ra(L, packed, pb, s));
+    RNB_TRY(fused_ra(L, packed, pb, s, &u_tiles));
   } else {
     for (int l = 0; l < L.nh; ++l) {
       const Lin& ln = L.hid[l];
@@ -1066,7 +1081,8 @@ int sweep_backward(const Layout& L, const float* packed, PointBufs& pb, bool wit
     int rows_per_blk = (int)((M + slabs - 1) / slabs);
     rows_per_blk = (rows_per_blk + 63) / 64 * 64;
     hipLaunchKernelGGL(sdf_head_bwd_kernel, dim3(blocks_for(M, rows_per_blk), chunks), dim3(512), 0, s, pb.a[L.nh - 1],
-                       pb.u[L.nh], L.Hp, L.H, pb.sbar, 1.f / L.sdf_scale, M, rows_per_blk,
+                       fused ? (const float*)nullptr : (const float*)pb.u[L.nh], (const float*)pb.u[L.nh], u_tiles, L.Hp,
+                       L.H, pb.sbar, 1.f / L.sdf_scale, M, rows_per_blk,
                        packed_grad + L.wsdf_off, packed_grad + L.bsdf_off);
     RNB_CHECK_LAUNCH();
   }

@@ -170,7 +170,7 @@ int64_t dw_staged_floats(const Layout& L, int64_t M, bool with_color);
 int sweep_backward(const Layout& L, const float* packed, PointBufs& pb, bool with_color, float* packed_grad,
                    bool fused, hipStream_t s);
 int fused_reverse(const Layout& L, const float* packed, PointBufs& pb, hipStream_t s);
-int fused_ra(const Layout& L, const float* packed, PointBufs& pb, hipStream_t s);
+int fused_ra(const Layout& L, const float* packed, PointBufs& pb, hipStream_t s, int* u_tiles = nullptr);
 int fused_fb(const Layout& L, const float* packed, PointBufs& pb, bool with_color, hipStream_t s);
 
 // ---- fused sweeps for hidden width 256 (fused.hip) ---------------------------------------------------

@@ -176,12 +176,16 @@ __global__ __launch_bounds__(64) void up_sample_kernel(UpArgs a) {
     }
     double run = __shfl_up(inc, 1, 64);
     if (lane == 0) { run = 0.0; cdf[0] = 0.f; }
+    // The pdf values are fp32 numbers in [2^-27, 4) (each raw weight is >= 1e-5 of a sum <= ~1): every partial sum of any
+    // subset then fits 53 bits, i.e. the double additions are EXACT in any order and the chained scan equals the
+    // sequential one bit for bit (checked per element; anything else — NaN, a degenerate row — goes the serial way).
+    // (scan_safe would be wrong here: an exact sum of two floats is often exactly half-way between two fp32 values.)
     bool safe = true;
     for (int j = j0; j < j1; ++j) {
-      run += (double)w[j];
-      const float c = (float)run;
-      safe = safe && scan_safe(run, c);
-      cdf[j + 1] = c;
+      const float wj = w[j];
+      safe = safe && (wj >= 7.450580596923828e-09f) && (wj < 4.0f);
+      run += (double)wj;
+      cdf[j + 1] = (float)run;
     }
     if (__any(!safe)) {
       if (lane == 0) {
