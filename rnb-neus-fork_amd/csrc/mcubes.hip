@@ -48,14 +48,11 @@ struct McPoint {
 
 __device__ inline bool mc_set(float f, float iso) { return f <= iso; }
 
-// everything the four passes need to know about grid point p (corner 0 of its cell, owner of three grid edges)
-__device__ inline McPoint mc_point(const McGrid& g, int64_t p) {
+// everything the four passes need to know about grid point p = (x, y, z) (corner 0 of its cell, owner of three edges)
+__device__ inline McPoint mc_point_at(const McGrid& g, int64_t p, int x, int y, int z) {
   McPoint r;
   const int64_t yz = (int64_t)g.ny * g.nz;
-  r.x = (int)(p / yz);
-  const int64_t rem = p - (int64_t)r.x * yz;
-  r.y = (int)(rem / g.nz);
-  r.z = (int)(rem - (int64_t)r.y * g.nz);
+  r.x = x; r.y = y; r.z = z;
   const bool hx = r.x + 1 < g.nx, hy = r.y + 1 < g.ny, hz = r.z + 1 < g.nz;
   const float* v = g.v + p;
   r.f000 = v[0];
@@ -77,6 +74,23 @@ __device__ inline McPoint mc_point(const McGrid& g, int64_t p) {
   }
   return r;
 }
+
+// coordinates of a thread's first item (32-bit divisions: the host admits fewer than 2^32 grid points), then z + 1 with
+// carries for its next items — a 64-bit division per item was most of each pass's time
+struct McCursor {
+  int x, y, z;
+  __device__ inline McCursor(const McGrid& g, int64_t p0) {
+    const unsigned yz = (unsigned)g.ny * (unsigned)g.nz;     // < 2^32 (host check)
+    const unsigned p = (unsigned)min(p0, g.n);
+    x = (int)(p / yz);
+    const unsigned rem = p - (unsigned)x * yz;
+    y = (int)(rem / (unsigned)g.nz);
+    z = (int)(rem - (unsigned)y * (unsigned)g.nz);
+  }
+  __device__ inline void next(const McGrid& g) {
+    if (++z == g.nz) { z = 0; if (++y == g.ny) { y = 0; ++x; } }
+  }
+};
 
 // exclusive prefix of `v` over the 256 threads of the workgroup (thread order); *total = sum over the workgroup
 __device__ inline unsigned block_exclusive_scan(unsigned v, unsigned* total, unsigned* red /* [4] */) {
@@ -105,11 +119,12 @@ __global__ __launch_bounds__(kMcThreads) void mc_count_kernel(McGrid g, unsigned
   __shared__ unsigned red[4];
   const int64_t p0 = (int64_t)blockIdx.x * kMcTile + (int64_t)threadIdx.x * kMcItems;
   unsigned nv = 0, nt = 0;
+  McCursor cur(g, p0);
 #pragma unroll
-  for (int k = 0; k < kMcItems; ++k) {
+  for (int k = 0; k < kMcItems; ++k, cur.next(g)) {
     const int64_t p = p0 + k;
     if (p < g.n) {
-      const McPoint pt = mc_point(g, p);
+      const McPoint pt = mc_point_at(g, p, cur.x, cur.y, cur.z);
       nv += __popc(pt.edges);
       nt += pt.cell ? kMcNumTris[pt.cube] : 0;
     }
@@ -165,10 +180,11 @@ __global__ __launch_bounds__(kMcThreads) void mc_vertex_kernel(McGrid g, const u
   const int64_t p0 = (int64_t)blockIdx.x * kMcTile + (int64_t)threadIdx.x * kMcItems;
   McPoint pt[kMcItems];
   unsigned nv = 0;
+  McCursor cur(g, p0);
 #pragma unroll
-  for (int k = 0; k < kMcItems; ++k) {
+  for (int k = 0; k < kMcItems; ++k, cur.next(g)) {
     pt[k].edges = 0;
-    if (p0 + k < g.n) pt[k] = mc_point(g, p0 + k);
+    if (p0 + k < g.n) pt[k] = mc_point_at(g, p0 + k, cur.x, cur.y, cur.z);
     nv += __popc(pt[k].edges);
   }
   unsigned tot;
@@ -203,11 +219,12 @@ __global__ __launch_bounds__(kMcThreads) void mc_triangle_kernel(McGrid g, const
   const int64_t p0 = (int64_t)blockIdx.x * kMcTile + (int64_t)threadIdx.x * kMcItems;
   unsigned cube[kMcItems];
   unsigned nt = 0;
+  McCursor cur(g, p0);
 #pragma unroll
-  for (int k = 0; k < kMcItems; ++k) {
+  for (int k = 0; k < kMcItems; ++k, cur.next(g)) {
     cube[k] = 0;
     if (p0 + k < g.n) {
-      const McPoint pt = mc_point(g, p0 + k);
+      const McPoint pt = mc_point_at(g, p0 + k, cur.x, cur.y, cur.z);
       cube[k] = pt.cell ? pt.cube : 0;          // case 0 has no triangles
     }
     nt += kMcNumTris[cube[k]];
@@ -241,7 +258,7 @@ __global__ __launch_bounds__(kMcThreads) void mc_triangle_kernel(McGrid g, const
 static int mc_check(const char* who, const void* volume, int nx, int ny, int nz) {
   if (!volume) RNB_FAIL(RNB_E_NULL, "%s: NULL volume", who);
   if (nx < 2 || ny < 2 || nz < 2) RNB_FAIL(RNB_E_INVALID, "%s: the grid needs >= 2 points per axis (%d %d %d)", who, nx, ny, nz);
-  if ((int64_t)nx * ny * nz > ((int64_t)1 << 32)) RNB_FAIL(RNB_E_INVALID, "%s: more than 2^32 grid points", who);
+  if ((int64_t)nx * ny * nz >= ((int64_t)1 << 32)) RNB_FAIL(RNB_E_INVALID, "%s: 2^32 or more grid points", who);
   return RNB_OK;
 }
 

@@ -1,0 +1,29 @@
+"""Matrix-pipe utilisation per kernel from a rocprofv3 --pmc pass (development / evidence tool).
+usage: python tools/sq_summary.py <sq_counter_collection.csv> [<kernel_trace.csv of the same run>]
+busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs); with the kernel trace also the clock the chip
+held: (GRBM_GUI_ACTIVE / 8) / duration."""
+import collections
+import csv
+import re
+import sys
+
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for r in csv.DictReader(open(sys.argv[1])):
+    agg[re.sub(r"\(.*", "", r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+dur = collections.defaultdict(list)
+if len(sys.argv) > 2:
+    for r in csv.DictReader(open(sys.argv[2])):
+        dur[re.sub(r"\(.*", "", r["Kernel_Name"])].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+print("# matrix pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), per kernel")
+for k, v in agg.items():
+    if not v.get("SQ_VALU_MFMA_BUSY_CYCLES") or sum(v["SQ_VALU_MFMA_BUSY_CYCLES"]) == 0:
+        continue
+    busy = sum(v["SQ_VALU_MFMA_BUSY_CYCLES"]) / len(v["SQ_VALU_MFMA_BUSY_CYCLES"])
+    clk = sum(v["GRBM_GUI_ACTIVE"]) / len(v["GRBM_GUI_ACTIVE"]) / 8.0
+    wait = sum(v.get("SQ_WAIT_ANY", [0])) / max(len(v.get("SQ_WAIT_ANY", [0])), 1)
+    wave = sum(v.get("SQ_WAVE_CYCLES", [1])) / max(len(v.get("SQ_WAVE_CYCLES", [1])), 1)
+    line = f"{k[:64]:66s} matrix pipe busy {100 * busy / (clk * 1024):5.1f} %   waves parked {100 * wait / wave:5.1f} %   (GRBM_GUI_ACTIVE/8 = {clk:.0f} clk"
+    if dur.get(k):
+        d = sum(dur[k]) / len(dur[k])
+        line += f", {d / 1e3:.1f} us under the counters => {clk / d:.2f} GHz"
+    print(line + ")")
