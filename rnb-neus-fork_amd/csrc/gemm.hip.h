@@ -38,6 +38,12 @@ __device__ inline int wave_id() { return __builtin_amdgcn_readfirstlane((int)(th
 // Raw buffer access to one tile of a row-major matrix: resource = tile base + byte size, per-lane 32-bit
 // byte offset in a VGPR, wave-uniform byte offset in the scalar operand (no per-access vector address
 // arithmetic; out-of-range reads return 0, out-of-range writes are dropped).
+#ifndef RNB_AUX_ST
+#define RNB_AUX_ST 2   // nt: the saved state is written once and read much later (or once): keep it out of L2's way
+#endif
+#ifndef RNB_AUX_LD
+#define RNB_AUX_LD 2   // nt: epilogue operand tiles are read exactly once
+#endif
 typedef __amdgpu_buffer_rsrc_t BufRsrc;
 typedef float vf2 __attribute__((ext_vector_type(2)));
 typedef unsigned vu2 __attribute__((ext_vector_type(2)));
@@ -45,10 +51,10 @@ __device__ inline BufRsrc tile_rsrc(const float* p, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, p ? bytes : 0, 0x00020000);
 }
 __device__ inline void bstore(BufRsrc r, unsigned voff, unsigned soff, float v) {
-  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, RNB_AUX_ST);
 }
 __device__ inline float bload(BufRsrc r, unsigned voff, unsigned soff) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, RNB_AUX_LD));
 }
 __device__ inline vf2 bload2(BufRsrc r, unsigned voff, unsigned soff) {
   return __builtin_bit_cast(vf2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
@@ -912,7 +918,7 @@ constexpr int kX3BufBytes = 2 * kX3OpBytes;     // both operands
 __device__ inline void dw_x3_load(BufRsrc rs, unsigned voff, int ld, int row0, vf4 (&x)[4]) {
 #pragma unroll
   for (int p = 0; p < 4; ++p)
-    x[p] = __builtin_bit_cast(vf4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (unsigned)(row0 + p) * (unsigned)ld * 4u, 0));
+    x[p] = __builtin_bit_cast(vf4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (unsigned)(row0 + p) * (unsigned)ld * 4u, RNB_AUX_LD));   // read once
 }
 // 4 columns x 4 points of one thread -> 12 half units at w (+ 68 * 16 per column, + kX3Plane per plane)
 __device__ inline void dw_x3_split(const vf4 (&x)[4], vu2x (&hi)[4], vu2x (&mid)[4], vu2x (&lo)[4]) {
@@ -1104,7 +1110,7 @@ __device__ inline void dw_x3_body(const DwGroup& g, const DwJob& J, int split, c
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = wm * 64 + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (pdst) pdst[(size_t)row * Kj + col] = acc[ti][tj][r];
+        if (pdst) __builtin_nontemporal_store(acc[ti][tj][r], pdst + (size_t)row * Kj + col);
         else atomicAdd(J.dW + (size_t)row * lddw + col, acc[ti][tj][r]);
       }
   }
