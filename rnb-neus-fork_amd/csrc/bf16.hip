@@ -175,13 +175,13 @@ __device__ inline __amdgpu_buffer_rsrc_t k8_rsrc(const bfraw* base, int64_t row0
 }
 __device__ inline Quad k8_load_quad(const bfraw* __restrict__ base, int64_t row0, int ti, int g, int col, int h) {
   const vu2 u = __builtin_bit_cast(vu2, __builtin_amdgcn_raw_buffer_load_b64(k8_rsrc(base, row0, FH), (unsigned)(col * 16 + 8 * h),
-                                                                               (unsigned)((ti * 4 + g) * FH * 16), 0));
+                                                                               (unsigned)((ti * 4 + g) * FH * 16), RNB_AUX_LD));
   return Quad{{bf_lo(u.x), bf_hi(u.x), bf_lo(u.y), bf_hi(u.y)}};
 }
 __device__ inline void k8_store_quad(bfraw* __restrict__ base, int64_t row0, int ti, int g, int col, int h, float a, float b,
                                      float c, float d, int C = FH) {
   const vu2 u = {pack2(a, b), pack2(c, d)};
-  __builtin_amdgcn_raw_buffer_store_b64(u, k8_rsrc(base, row0, C), (unsigned)(col * 16 + 8 * h), (unsigned)((ti * 4 + g) * C * 16), 0);
+  __builtin_amdgcn_raw_buffer_store_b64(u, k8_rsrc(base, row0, C), (unsigned)(col * 16 + 8 * h), (unsigned)((ti * 4 + g) * C * 16), RNB_AUX_ST);
 }
 // 8 rows of one column of an LDS tile (row-major, pitch P) -> one 16-byte K8 unit
 template <int P>
@@ -212,7 +212,7 @@ __device__ inline void k8_prefetch(const bfraw* __restrict__ base, int64_t row0,
 #pragma unroll
       for (int g = 0; g < 4; ++g)
         t.q[ti][tj][g] = __builtin_bit_cast(vu2, __builtin_amdgcn_raw_buffer_load_b64(
-            rs, (unsigned)((n0 + c) * 16 + 8 * h), (unsigned)((ti * 4 + g) * FH * 16 + tj * 512), 0));
+            rs, (unsigned)((n0 + c) * 16 + 8 * h), (unsigned)((ti * 4 + g) * FH * 16 + tj * 512), RNB_AUX_LD));
 }
 template <int TI>
 __device__ inline float aux_at(const AuxBf<TI>& t, int ti, int tj, int r) {
@@ -1165,9 +1165,9 @@ __device__ inline void dw_issue_chunk(const bfraw* __restrict__ Xg, const bfraw*
     const bfraw* xs = Xg + ((size_t)(c * 4 + blk) * FH + col) * 8;
     const bfraw* ys = Yg + ((size_t)(c * 4 + blk) * CyUnits + col) * 8;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)xs,
-                                     (__attribute__((address_space(3))) void*)(lds_buf + u * 16), 16, 0, 0);
+                                     (__attribute__((address_space(3))) void*)(lds_buf + u * 16), 16, 0, RNB_AUX_LD);
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ys,
-                                     (__attribute__((address_space(3))) void*)(lds_buf + kDwOpBytes + u * 16), 16, 0, 0);
+                                     (__attribute__((address_space(3))) void*)(lds_buf + kDwOpBytes + u * 16), 16, 0, RNB_AUX_LD);
   }
 }
 
