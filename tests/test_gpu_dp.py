@@ -215,6 +215,48 @@ def test_exact_data_parallel_over_rccl():
         assert rel_ddp > 1e-3
 
 
+def _rccl_one_rank_worker(port, q):
+    """world_size 1 over the `nccl` backend: RCCL is loaded, a communicator is created on the device and the two
+    collectives of a training step (the 4-float normaliser all-reduce, the flat-gradient SUM) run through it."""
+    dev = _init(0, 1, port, "nccl")
+    import rnb_neus_fork_amd as R
+    from oracle import rnb_oracle as O
+    mc = O.ModelConf(sdf=O.SDFConf(d_out=65, d_hidden=64), color=O.ColorConf(d_feature=64, d_hidden=64),
+                     render=O.RenderConf(n_samples=16, n_importance=16))
+    torch.manual_seed(0)
+    sdf, devn, col, ren = R.build_from_named_params(mc, O.init_params(mc), dev)
+    b = {k: v.to(dev) for k, v in O.synthetic_batch(16, seed=9, step=2).items()}
+    leaves = list(sdf.parameters()) + list(devn.parameters()) + list(col.parameters())
+    res = []
+    for dp in (False, True):
+        ren.set_data_parallel(enabled=dp, exact=True)
+        ren.set_variant(deterministic=True)
+        for x in leaves:
+            x.grad = None
+        out = ren.render_rnb(b["rays_o"], b["rays_d"], b["near"], b["far"], b["lights_dir"], cos_anneal_ratio=1.0,
+                             t_rand=b["t_rand"])
+        loss, _ = R.rnb_loss(out, b["true_rgb"], b["mask"], group=dist.group.WORLD if dp else None)
+        loss.backward()
+        torch.cuda.synchronize()
+        res.append((float(loss), torch.cat([x.grad.reshape(-1) for x in leaves]).clone()))
+    same = bool(torch.equal(res[0][1], res[1][1])) and abs(res[0][0] - res[1][0]) < 1e-7
+    q.put((same, dist.get_backend()))
+    dist.destroy_process_group()
+
+
+def test_rccl_single_rank_smoke():
+    """The one-GPU boxes cannot run two RCCL ranks, but they can run ONE: the exact data-parallel step over a
+    world-size-1 `nccl` group must equal the plain single-process step bit for bit (the collectives are identities),
+    which proves RCCL loads, builds a communicator and reduces on this software stack before the scaling bench needs it."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_one_rank_worker, args=(_free_port(), q))
+    p.start()
+    same, backend = q.get(timeout=300)
+    p.join(timeout=60)
+    assert backend == "nccl" and same
+
+
 def _grid_worker(rank, world, port, q):
     dev = _init(rank, world, port)
     import rnb_neus_fork_amd as R

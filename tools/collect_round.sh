@@ -25,6 +25,9 @@ python tools/kstats.py $out/ksbf_kernel_stats.csv 25 30 > $out/kernel_table_bf16
 echo "== PMC passes"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out -o fetch -- python bench.py --no-cpu-baseline --steps 4 --warmup 2 --no-gemm-events > $out/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out -o write -- python bench.py --no-cpu-baseline --steps 4 --warmup 2 --no-gemm-events > $out/write.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out -o fetchbf -- python bench.py --no-cpu-baseline --steps 4 --warmup 2 --no-gemm-events --dtype bf16 --samples 256 > $out/fetchbf.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out -o writebf -- python bench.py --no-cpu-baseline --steps 4 --warmup 2 --no-gemm-events --dtype bf16 --samples 256 > $out/writebf.log 2>&1
+python tools/traffic_summary.py $out/fetchbf_counter_collection.csv $out/writebf_counter_collection.csv 6 512 256 _tmp_traffic_bf16.json > /dev/null && mv profiles/_tmp_traffic_bf16.json $out/hbm_traffic_bf16.json
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS --output-format csv -d $out -o sq -- python bench.py --no-cpu-baseline --steps 4 --warmup 2 --no-gemm-events > $out/sq.log 2>&1
 python tools/sq_summary.py $out/sq_counter_collection.csv $out/sq_kernel_trace.csv > $out/sq_counters_x3.txt || true
 python tools/traffic_summary.py $out/fetch_counter_collection.csv $out/write_counter_collection.csv 6 512 128 _tmp_traffic.json > /dev/null && mv profiles/_tmp_traffic.json $out/hbm_traffic.json
