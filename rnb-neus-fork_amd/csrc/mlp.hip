@@ -754,7 +754,7 @@ struct DwBatch {
       slab_left -= need;
     }
     {
-      ProfScope prof(flops[3], s, "dW(256x256)");
+      ProfScope prof(flops[3], s, "dW(x3: 256x256 + narrow jobs + reduce)");
       if (x3) hipLaunchKernelGGL(gemm_dw_x3_kernel<0>, dim3((unsigned)end), dim3(512), 0, s, g);
       else hipLaunchKernelGGL(gemm_dw_staged_kernel<0>, dim3((unsigned)end), dim3(1024), 0, s, g);
       RNB_CHECK_LAUNCH();
