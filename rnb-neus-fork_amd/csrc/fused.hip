@@ -755,6 +755,10 @@ int x3_pack_weights(const Layout& L, float* packed, hipStream_t s) {
     add(L.feat.w_off, L.feat.Np, L.feat.Kp);
     add(L.feat.wT_off, L.feat.Kp, L.feat.Np);
   }
+  for (int l = 0; l < L.nc; ++l) {   // the albedo network's hidden layers (gemm_rows_x3m_kernel reads them as fragments)
+    add(L.col[l].w_off, L.col[l].Np, L.col[l].Kp);
+    add(L.col[l].wT_off, L.col[l].Kp, L.col[l].Np);
+  }
   hipLaunchKernelGGL(x3_pack_kernel, dim3((unsigned)((t.total_units + 255) / 256)), dim3(256), 0, s, packed, t, dst);
   RNB_CHECK_LAUNCH();
   return RNB_OK;

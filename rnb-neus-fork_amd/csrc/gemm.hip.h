@@ -170,15 +170,15 @@ __device__ inline int acc_row(int ti, int r, int lane) { return ti * 32 + (r & 3
 // row-major with 16 bytes per lane: the epilogue functor sees 4 consecutive columns of one row
 // (`epi.apply4(row, col, v)`, col % 4 == 0) and issues dwordx4 loads/stores (512 contiguous bytes per
 // half-wave).  `strip` = this wave's [16][32*TN + 4] floats of the (now idle) staging LDS.
-template <int TN, class Epi>
-__device__ inline void run_epilogue(const v16f (&acc)[2][TN], float* __restrict__ strip, int row0, int col0,
+template <int TN, class Epi, int TI = 2>
+__device__ inline void run_epilogue(const v16f (&acc)[TI][TN], float* __restrict__ strip, int row0, int col0,
                                     int lane, unsigned mask, const Epi& epi) {
   constexpr int W = 32 * TN;   // columns of the wave's sub-tile
   constexpr int P = W + 4;     // strip pitch (floats)
   constexpr int C4 = W / 4;    // 16-byte groups per row
   const int h = lane >> 5, cl = lane & 31;
 #pragma unroll
-  for (int ti = 0; ti < 2; ++ti) {
+  for (int ti = 0; ti < TI; ++ti) {
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       // registers 8*half .. 8*half+7 of every column tile hold rows 16*half .. 16*half+15
@@ -894,6 +894,113 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_x3_kernel(const float* __res
   static_assert(4 * 16 * (32 * TN + 4) * 4 <= 3 * (BM + BN) * XP, "epilogue strips must fit in the staging LDS");
   run_epilogue<TN, Epi>(acc, reinterpret_cast<float*>(smem) + wave * 16 * (32 * TN + 4), m_blk + wm * 64,
                         n_blk + wn * (BN / 2), lane, mask, epi);
+}
+
+// ---- the same product with the WEIGHTS TAKEN FROM THE SPLIT MIRROR ("x3m"; the albedo network's GEMMs) -----------------
+// gemm_rows_x3_kernel splits both operands on their way into LDS — the weight tile again in every one of the M / 128
+// workgroups — behind two barriers per 16-k step.  Here only the activations are staged: one float4 per thread and step,
+// split once, into one of two plane tiles [3][128][48 B] (one barrier per step; the split of step s + 1 rides beside the
+// MFMAs of step s); the weight fragments come straight from the fragment-ordered mirror that rnb_weightnorm_fwd wrote
+// (x3_pack_weights; one contiguous 1 KB per load, as in the fused sweeps), two steps ahead in registers.  One 8-wave
+// workgroup per 128 rows; wave w owns ALL 128 rows x the column tiles w and (TJ == 2) w + 8 — every weight fragment is
+// fetched once per workgroup, every activation split once.  N <= 32 * 8 * TJ, N % 32 == 0, K % 32 == 0.
+template <int TJ, class Epi>
+__global__ __launch_bounds__(512, 1) void gemm_rows_x3m_kernel(const float* __restrict__ A, int lda,
+                                                               const x3raw* __restrict__ W3, int N, int K, Epi epi) {
+  constexpr int ROWS = 128;
+  constexpr int PLB = ROWS * XP;              // bytes of one plane
+  constexpr int BUFB = 3 * PLB;               // one staging buffer (three planes): 18,432 B
+  constexpr int STRIP = 16 * (32 + 4) * 4;    // epilogue strip of one wave (one 32-column tile at a time)
+  __shared__ __attribute__((aligned(16))) char smem[2 * BUFB > 8 * STRIP ? 2 * BUFB : 8 * STRIP];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = wave_id();
+  const int m_blk = blockIdx.x * ROWS;
+  const int nks = K >> 4;   // even
+  int nt[TJ];
+  bool on[TJ];
+#pragma unroll
+  for (int tj = 0; tj < TJ; ++tj) { nt[tj] = wave + 8 * tj; on[tj] = nt[tj] * 32 < N; }
+  // staging role: row tid >> 2, k quad tid & 3 of every 16-k step
+  const int sr = tid >> 2, sc = tid & 3;
+  const BufRsrc rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A + (size_t)m_blk * lda), 0, 0xfffffffc, 0x00020000);
+  const unsigned aoff = ((unsigned)sr * (unsigned)lda + (unsigned)sc * 4u) * 4u;
+  char* const swr = smem + sr * XP + sc * 8;
+  const int i = lane & 31, h = lane >> 5;
+  const char* const fa = smem + i * XP + h * 16;
+  const BufRsrc rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<x3raw*>(W3), 0, 0x7ffffff0, 0x00020000);
+  const unsigned boff = (unsigned)lane * 16u;
+  auto load_b = [&](int ks, vu4x (&b)[TJ][3]) {
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj) {
+      const unsigned soff = (unsigned)((on[tj] ? nt[tj] : 0) * nks + ks) * 3072u;
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+        b[tj][pl] = __builtin_bit_cast(vu4x, __builtin_amdgcn_raw_buffer_load_b128(rsW, boff, soff + pl * 1024, 0));
+    }
+  };
+  auto load_a = [&](int ks) {
+    return __builtin_bit_cast(vf4, __builtin_amdgcn_raw_buffer_load_b128(rsA, aoff, (unsigned)ks * 64u, RNB_AUX_LD));
+  };
+  auto stage = [&](const vf4& x, int buf) {
+    vu2x hi, mid, lo;
+    x3_split4(x, hi, mid, lo);
+    char* w = swr + buf * BUFB;
+    *reinterpret_cast<vu2x*>(w) = hi;
+    *reinterpret_cast<vu2x*>(w + PLB) = mid;
+    *reinterpret_cast<vu2x*>(w + 2 * PLB) = lo;
+  };
+  v16f acc[4][TJ];
+#pragma unroll
+  for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ti][tj][r] = 0.f;
+  vu4x b0[TJ][3], b1[TJ][3];
+  load_b(0, b0);
+  load_b(1, b1);
+  vf4 x = load_a(0);
+  stage(x, 0);
+  x = load_a(1);
+  auto step = [&](int ks, vu4x (&b)[TJ][3]) {
+    // buffer ks & 1 holds step ks (written before the barrier); buffer (ks + 1) & 1 was read in step ks - 1: free
+    lds_barrier();
+    stage(x, (ks + 1) & 1);                        // step ks + 1 (past the end: a harmless re-stage of the last step)
+    x = load_a(min(ks + 2, nks - 1));
+    const char* f = fa + (ks & 1) * BUFB;
+    vu4x a[4][3];
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) a[ti][pl] = *reinterpret_cast<const vu4x*>(f + pl * PLB + ti * 32 * XP);
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0};   // small terms first (x3_mfma)
+    constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj) {
+      if (TJ == 2 && tj == 1 && !on[1]) continue;   // (wave-uniform)
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti)
+          acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(x3bf8, a[ti][PA[t]]),
+                                                                __builtin_bit_cast(x3bf8, b[tj][PB[t]]), acc[ti][tj], 0, 0, 0);
+    }
+    load_b(min(ks + 2, nks - 1), b);
+  };
+  for (int ks = 0; ks < nks; ks += 2) {
+    step(ks, b0);
+    step(ks + 1, b1);
+  }
+  __syncthreads();   // the staging buffers become the epilogue strips
+  float* strip = reinterpret_cast<float*>(smem + wave * STRIP);
+#pragma unroll
+  for (int tj = 0; tj < TJ; ++tj) {
+    if (!on[tj]) continue;
+    v16f t[4][1];
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti) t[ti][0] = acc[ti][tj];
+    run_epilogue<1, Epi, 4>(t, strip, m_blk, nt[tj] * 32, lane, 1u, epi);
+  }
 }
 
 // ---- dW for 256 x 256 weight matrices as six bf16 MFMA terms (RNB_VARIANT_X3) --------------------------------------

@@ -616,9 +616,16 @@ static inline double mm_flops(int64_t M, const Lin& ln) { return 2.0 * (double)M
 // x3: the product as six bf16 MFMA terms (RNB_VARIANT_X3; k-contiguous weights, N >= 256, K % 16 == 0)
 template <bool B_KMAJOR, class Epi>
 static int launch_rows(const float* A, int lda, const float* W, int ldw, int64_t Mp, int N, int K, const Epi& epi,
-                       double flops, hipStream_t s, bool x3 = false) {
+                       double flops, hipStream_t s, bool x3 = false, const x3raw* W3 = nullptr) {
   ProfScope prof(flops, s, "layer_gemm");
   if constexpr (!B_KMAJOR) {
+    // W3: this matrix in the split mirror (x3_pack_weights): the weights are then read as ready-made fragments
+    if (x3 && W3 != nullptr && N % 32 == 0 && N <= 512 && K % 32 == 0 && Mp % 128 == 0) {
+      if (N <= 256) hipLaunchKernelGGL((gemm_rows_x3m_kernel<1, Epi>), dim3((unsigned)(Mp / 128)), dim3(512), 0, s, A, lda, W3, N, K, epi);
+      else hipLaunchKernelGGL((gemm_rows_x3m_kernel<2, Epi>), dim3((unsigned)(Mp / 128)), dim3(512), 0, s, A, lda, W3, N, K, epi);
+      RNB_CHECK_LAUNCH();
+      return RNB_OK;
+    }
     if (x3 && N >= 256 && K % XK == 0) {
       dim3 grid((unsigned)(Mp / BM), (unsigned)((N + 255) / 256));
       if (N % 256 == 0) hipLaunchKernelGGL((gemm_rows_x3_kernel<256, false, Epi>), grid, dim3(256), 0, s, A, lda, W, ldw, N, K, epi);
@@ -907,6 +914,12 @@ int64_t dw_partial_floats(const Layout& L, int64_t M, bool with_color) {
   return total;
 }
 
+// the split mirror of the matrix at float offset `off` of the packed buffer (x3_pack_weights), or nullptr
+static inline const x3raw* x3_mirror(const Layout& L, const float* packed, int64_t off) {
+  if (!is_x3(L) || off < 0) return nullptr;
+  return reinterpret_cast<const x3raw*>(packed + L.total) + 3 * off;
+}
+
 static inline unsigned blocks_for(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
 
 int launch_grid_points(const GridGen& g, int64_t first, int64_t n, float* pts, hipStream_t s) {
@@ -994,7 +1007,8 @@ int sweep_color(const Layout& L, const float* packed, PointBufs& pb, const float
     const float* in = l == 0 ? pb.cin : pb.ac[l - 1];
     const int lda = l == 0 ? L.Cinp : L.Hcp;
     EpiRelu epi{packed + ln.b_off, pb.ac[l], L.Hcp, ln.N};
-    RNB_TRY((launch_rows<false, EpiRelu>(in, lda, packed + ln.w_off, ln.Kp, pb.Mp, ln.Np, ln.Kp, epi, mm_flops(pb.M, ln), s, is_x3(L))));
+    RNB_TRY((launch_rows<false, EpiRelu>(in, lda, packed + ln.w_off, ln.Kp, pb.Mp, ln.Np, ln.Kp, epi, mm_flops(pb.M, ln), s, is_x3(L),
+                                         x3_mirror(L, packed, ln.w_off))));
   }
   hipLaunchKernelGGL(color_out_kernel, dim3(blocks_for(pb.Mp * 16, 256)), dim3(256), 0, s, pb.ac[L.nc - 1], L.Hcp,
                      L.Hc, packed + L.colo.w_off, L.colo.Kp, packed + L.colo.b_off, L.Co, L.squeeze, pb.Mp, pb.alb);
@@ -1039,10 +1053,12 @@ int sweep_backward(const Layout& L, const float* packed, PointBufs& pb, bool wit
       if (l > 0) {
         EpiReluMask epi{pb.ac[l - 1], pb.zc[l - 1], L.Hcp, L.col[l - 1].N};
         // zc_{l-1} = (zc_l W_l) * relu': k-contiguous product against the transposed copy W_l^T [Kp x Np]
-        RNB_TRY((launch_rows<false, EpiReluMask>(pb.zc[l], L.Hcp, packed + ln.wT_off, ln.Np, Mp, ln.Kp, ln.Np, epi, mm_flops(M, ln), s, is_x3(L))));
+        RNB_TRY((launch_rows<false, EpiReluMask>(pb.zc[l], L.Hcp, packed + ln.wT_off, ln.Np, Mp, ln.Kp, ln.Np, epi, mm_flops(M, ln), s, is_x3(L),
+                                                 x3_mirror(L, packed, ln.wT_off))));
       } else {
         EpiStore epi{pb.cinb, L.Cinp};
-        RNB_TRY((launch_rows<false, EpiStore>(pb.zc[0], L.Hcp, packed + ln.wT_off, ln.Np, Mp, ln.Kp, ln.Np, epi, mm_flops(M, ln), s, is_x3(L))));
+        RNB_TRY((launch_rows<false, EpiStore>(pb.zc[0], L.Hcp, packed + ln.wT_off, ln.Np, Mp, ln.Kp, ln.Np, epi, mm_flops(M, ln), s, is_x3(L),
+                                              x3_mirror(L, packed, ln.wT_off))));
       }
     }
   }
