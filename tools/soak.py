@@ -1,7 +1,7 @@
 """Stability soak (development / evidence tool; GPU box): N train_rnb steps of the default (non-deterministic x3) variant on
 the analytic sphere capture of the convergence test, 512 rays x (64+64) samples, schedule of exp_runner.py:320-332 scaled
 to N; prints the loss every N/10 steps, the final PSNR on held-out batches, and whether every loss was finite.
-usage: python tools/soak.py [steps]"""
+usage: python tools/soak.py [steps] [bf16]"""
 import sys
 import time
 
@@ -21,6 +21,9 @@ devn = R.SingleVarianceNetwork(0.3).to(dev)
 col = R.RenderingNetwork(d_feature=256, mode="no_view_dir", d_in=6, d_out=3, d_hidden=256, n_layers=2, weight_norm=True,
                          multires_view=4, squeeze_out=True).to(dev)
 ren = R.NeuSRenderer(None, sdf, devn, col, n_samples=64, n_importance=64, n_outside=0, up_sample_steps=4, perturb=1.0)
+if len(sys.argv) > 2 and sys.argv[2] == "bf16":
+    ren.set_variant(bf16=True)          # RNB_VARIANT_BF16 (BASELINE config 5's arithmetic)
+    print("variant: bf16 sweeps")
 opt = R.FlatAdam(list(sdf.parameters()) + list(devn.parameters()) + list(col.parameters()), lr=5e-4)
 B = 512
 losses = []
