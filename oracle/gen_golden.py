@@ -495,6 +495,28 @@ def b512_case():
           f"d loss / d variance {float(dev.variance.grad):.3e}")
 
 
+def grid_case():
+    """The SDF grid of validate_mesh from the REFERENCE's own `extract_fields` (models/renderer.py:10-25, called with
+    query_func = -sdf_network.sdf as at :1219-1224): tiny networks (seed 0 state of tiny_warmup_geo), asymmetric bounds,
+    resolution 70 — larger than the reference's block size N = 64, so its chunked evaluation is exercised."""
+    import_reference()
+    from models.renderer import extract_fields  # type: ignore
+    mc = tiny_conf()
+    sdf, dev, col, ren = build_reference(mc, seed=0)
+    lo = torch.tensor([-1.0, -0.9, -0.8])
+    hi = torch.tensor([1.0, 0.9, 1.1])
+    res = 70
+    u = extract_fields(lo, hi, res, lambda pts: -sdf.sdf(pts))
+    arrs = dict(conf_arrays(mc))
+    arrs["bound_min"], arrs["bound_max"], arrs["resolution"] = lo.numpy(), hi.numpy(), np.array(res)
+    arrs["u"] = u.astype(np.float32)
+    for k, v in named_params(sdf, dev, col).items():
+        arrs["w." + k] = v.detach().numpy().copy()
+    path = os.path.join(OUT, "grid_tiny.npz")
+    np.savez_compressed(path, **arrs)
+    print(f"wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB): u in [{u.min():.3f}, {u.max():.3f}]")
+
+
 CONV = dict(B=64, steps=200, warm_steps=100, lr=5e-4, warm_up_end=20, end_iter=200, alpha=0.05, eval_steps=4)
 
 
@@ -618,15 +640,16 @@ def main():
     b512_case()
 
 
-if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] in ("raygen", "checkpoint", "convergence", "b512"):
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] in ("raygen", "checkpoint", "convergence", "b512", "grid"):
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     {"raygen": raygen_case, "checkpoint": checkpoint_case, "convergence": convergence_case,
-     "b512": b512_case}[sys.argv[1]]()
+     "b512": b512_case, "grid": grid_case}[sys.argv[1]]()
     sys.exit(0)
 
 if __name__ == "__main__":
     main()
     raygen_case()
     checkpoint_case()
+    grid_case()
     convergence_case()

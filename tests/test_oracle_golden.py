@@ -137,3 +137,25 @@ def test_raygen_oracle_matches_reference_vectors():
         assert torch.equal(out["near"], c["near"]) and torch.equal(out["far"], c["far"])
         B = c["pixels_x"].numel()
         assert c["data"].shape == (B, 7) and c["images"].shape == (3, B, 3)
+
+
+def test_sdf_grid_of_validate_mesh_matches_the_reference_extract_fields():
+    """tests/golden/grid_tiny.npz holds the volume the REFERENCE's own `extract_fields` (models/renderer.py:10-25, 64-point
+    blocks, query_func = -sdf) returns at resolution 70: the oracle on the plain torch.linspace grid must reproduce it —
+    which also shows that the reference's blocking does not change a single value."""
+    import os
+    import numpy as np
+    from tests.golden_util import GOLDEN_DIR
+    z = np.load(os.path.join(GOLDEN_DIR, "grid_tiny.npz"), allow_pickle=False)
+    s_, sf = z["conf.sdf"], z["conf.sdf_f"]
+    conf = O.SDFConf(d_in=int(s_[0]), d_out=int(s_[1]), d_hidden=int(s_[2]), n_layers=int(s_[3]),
+                     skip_in=(int(s_[4]),) if s_[4] >= 0 else (), multires=int(s_[5]), bias=float(sf[0]), scale=float(sf[1]))
+    p = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w.")}
+    res = int(z["resolution"])
+    lo, hi = torch.from_numpy(z["bound_min"]), torch.from_numpy(z["bound_max"])
+    xs = [torch.linspace(float(lo[i]), float(hi[i]), res) for i in range(3)]
+    xx, yy, zz = torch.meshgrid(*xs, indexing="ij")
+    pts = torch.stack([xx.reshape(-1), yy.reshape(-1), zz.reshape(-1)], dim=-1)
+    with torch.no_grad():
+        mine = -O.sdf_only(p, conf, pts).reshape(res, res, res)
+    torch.testing.assert_close(mine, torch.from_numpy(z["u"]), rtol=0, atol=2e-6)
