@@ -93,7 +93,11 @@ typedef struct rnb_model_desc {
  *                             only makes the request explicit (an unsupported shape is then an error).
  *   RNB_VARIANT_F32_MFMA      the same kernels on v_mfma_f32_32x32x2_f32 (the round-1 arithmetic; A/B switch).
  *   RNB_VARIANT_*_TI/_NW      tile height (1: 32 points, 2: 64 points) / waves per workgroup (4 or 8) of the fused
- *                             backward sweeps (BWD) and of the fused forward (FWD); 0 = the measured default. */
+ *                             backward sweeps (BWD) and of the fused forward (FWD); 0 = the measured default.
+ *   RNB_VARIANT_REG_TILE /    which family of fused x3 sweeps runs: REG_TILE = the register-tile kernels (fused_t.hip:
+ *   RNB_VARIANT_LDS_TILE      32 points per wave, activations in registers from layer to layer, weights through an LDS
+ *                             ring), LDS_TILE = the 64-point LDS-tile kernels (fused.hip / fused_bwd.hip).  Neither bit:
+ *                             the measured default per sweep and batch size.  A/B switches. */
 enum {
   RNB_VARIANT_BF16 = 1,
   RNB_VARIANT_DETERMINISTIC = 2,
@@ -105,7 +109,9 @@ enum {
   RNB_VARIANT_BWD_TI_SHIFT = 8,   /* 2 bits: 0 default, 1, 2 */
   RNB_VARIANT_BWD_NW_SHIFT = 10,  /* 2 bits: 0 default, 1 = 4 waves, 2 = 8 waves */
   RNB_VARIANT_FWD_TI_SHIFT = 12,
-  RNB_VARIANT_FWD_NW_SHIFT = 14
+  RNB_VARIANT_FWD_NW_SHIFT = 14,
+  RNB_VARIANT_REG_TILE = 1 << 16,
+  RNB_VARIANT_LDS_TILE = 1 << 17
 };
 
 /* Trainable leaves of one MLP in the reference's state_dict naming (linN.weight_g [out,1],

@@ -11,6 +11,31 @@ constexpr int FH = 256;       // hidden width of the fused path
 constexpr int FP = FH + 4;    // LDS pitch of the activation tile
 constexpr int FEP = 40;       // LDS pitch of the positional-encoding copy kept for the skip connection
 
+// arguments of the forward sweep kernels (fused.hip, fused_t.hip)
+struct FusedFwdArgs {
+  const float* pts;     // [M,3]
+  int64_t M;
+  const float* packed;
+  const x3raw* w3;      // RNB_VARIANT_X3: split mirror of the weight matrices (matrix at 3 x its float offset)
+  int nh, skip, pe, multires, Ep;
+  float scale;
+  int n_real[RNB_MAX_LIN];
+  int Kp[RNB_MAX_LIN];
+  long long w_off[RNB_MAX_LIN], b_off[RNB_MAX_LIN];
+  long long wsdf_off, bsdf_off;
+  int with_feat, F, Cinp;
+  long long wf_off, bf_off;
+  float* cin;           // [Mp,Cinp] feature block destination (with_feat)
+  float* sdf;           // [Mp]
+  // saved state (SAVE only)
+  float* x4;            // [Mp,4]
+  float* e;             // [Mp,Ep]
+  float* a[RNB_MAX_LIN];
+  float* D[RNB_MAX_LIN];
+  float* gz_last;       // [Mp,256] seed of the reverse sweep: w_sdf * D_last (optional)
+  GridGen grid;         // on: points come from the regular grid, sdf (scaled) goes to rows < M only
+};
+
 // One (32*TI) x (32*TJ) output block per wave (TJ = 2 unless stated): C[rows][n0..] = X[rows][K] * W[n][K]^T, K a
 // multiple of 32.
 // k-permutation inside each 32-k block: lane half h takes k = 32Q + 16h + 4q + c, so every lane streams 64
@@ -168,7 +193,8 @@ __device__ inline void layer_mma_nt_ring(const float* __restrict__ X, const floa
 // MFMA co-executes with the VALU work of the epilogues (profiles/r02_overlap_probe_*).
 // Weights are split once per step into a fragment-ordered mirror (x3_pack_weights): for W [N][K], fragment (nt, ks)
 // = rows 32 nt .. +32, k = 16 ks .. +16 is three consecutive 1 KB blocks (hi, mid, lo), each 64 lanes x 16 bytes with
-// lane (c, h) = W[32 nt + c][16 ks + 8 h .. +8].  Activations stay fp32 in LDS and are split as they are read.
+// lane (c, h) = W[32 nt + c][16 ks + 4 h + {0..3, 8..11}] (SDF network; the albedo net's matrices keep 16 ks + 8 h .. + 8).
+// Activations stay fp32 in LDS and are split as they are read.
 // (buffer loads: per-lane offset lane * 16 in one VGPR, the fragment's offset in the scalar operand, the plane in the
 // immediate — plain pointer arithmetic cost five 64-bit vector adds per step in front of the loads)
 template <int TJ>
@@ -187,8 +213,8 @@ template <int TI>
 __device__ inline void x3_read_a(const float* __restrict__ xp, int ks, vf4 (&a)[TI][2]) {
 #pragma unroll
   for (int ti = 0; ti < TI; ++ti) {
-    a[ti][0] = *reinterpret_cast<const vf4*>(xp + ti * 32 * FP + ks * 16);
-    a[ti][1] = *reinterpret_cast<const vf4*>(xp + ti * 32 * FP + ks * 16 + 4);
+    a[ti][0] = *reinterpret_cast<const vf4*>(xp + ti * 32 * FP + ks * 16);       // k = 16 ks + 4 h + 0..3
+    a[ti][1] = *reinterpret_cast<const vf4*>(xp + ti * 32 * FP + ks * 16 + 8);   //     16 ks + 4 h + 8..11  (the mirror's order)
   }
 }
 template <int TI>
@@ -235,7 +261,7 @@ struct X3Mma {
   __device__ inline void run(const float* __restrict__ X, const x3raw* __restrict__ W3, int K, int n0, int lane,
                              v16f (&acc)[TI][TJ], const x3raw* __restrict__ W3n, int Kn, int n0n, Hook hook = Hook()) {
     const int i = lane & 31, h = lane >> 5;
-    const float* xp = X + i * FP + h * 8;
+    const float* xp = X + i * FP + h * 4;   // (k order of the SDF mirror: x3_pack_kernel, tperm)
     const int nks = K >> 4;   // even
     vu4x a0[TI][3], a1[TI][3];
     vf4 raw[TI][2];

@@ -44,7 +44,7 @@ int make_layout(const rnb_model_desc* d, Layout* L) {
   if (d->sdf_multires < 0 || d->sdf_multires > 16) RNB_FAIL(RNB_E_INVALID, "bad sdf_multires");
   if (!(d->sdf_scale > 0.f)) RNB_FAIL(RNB_E_INVALID, "sdf_scale must be positive");
   L->variant = d->variant;
-  if (d->variant & ~0xFF7F) RNB_FAIL(RNB_E_INVALID, "unknown bits in rnb_model_desc.variant (0x%x)", d->variant);
+  if (d->variant & ~0x3FF7F) RNB_FAIL(RNB_E_INVALID, "unknown bits in rnb_model_desc.variant (0x%x)", d->variant);
   L->nh = d->sdf_n_layers;
   L->multires = d->sdf_multires;
   L->pe = 3 * (1 + 2 * d->sdf_multires);

@@ -177,6 +177,17 @@ int fused_fb(const Layout& L, const float* packed, PointBufs& pb, bool with_colo
 bool fused_supported(const Layout& L);
 int fused_forward(const Layout& L, const float* packed, const float* pts, int64_t M, PointBufs& pb, bool save,
                   bool need_feat, bool need_gz_last, hipStream_t s, const GridGen* grid = nullptr);
+// ---- register-tile sweeps (fused_t.hip): x3 arithmetic, 32 points per wave, weights through an LDS ring ----
+bool fused_t_supported(const Layout& L);
+int fused_forward_t(const Layout& L, const float* packed, const float* pts, int64_t M, PointBufs& pb, bool save,
+                    bool need_feat, bool need_gz_last, hipStream_t s, const GridGen* grid = nullptr);
+// family of a sweep over Mp points: the register-tile kernels need >= one 128-point workgroup per CU to fill the chip
+constexpr bool kRegTileDefault = false;
+inline bool use_reg_tile(const Layout& L, int64_t Mp) {
+  if (!fused_t_supported(L) || (L.variant & RNB_VARIANT_LDS_TILE)) return false;
+  if (L.variant & RNB_VARIANT_REG_TILE) return true;
+  return kRegTileDefault && Mp >= 128 * 200;
+}
 int launch_grid_points(const GridGen& g, int64_t first, int64_t n, float* pts, hipStream_t s);
 int launch_scale_copy(const float* src, float scale, int64_t n, float* dst, hipStream_t s);
 
