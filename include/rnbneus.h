@@ -94,10 +94,10 @@ typedef struct rnb_model_desc {
  *   RNB_VARIANT_F32_MFMA      the same kernels on v_mfma_f32_32x32x2_f32 (the round-1 arithmetic; A/B switch).
  *   RNB_VARIANT_*_TI/_NW      tile height (1: 32 points, 2: 64 points) / waves per workgroup (4 or 8) of the fused
  *                             backward sweeps (BWD) and of the fused forward (FWD); 0 = the measured default.
- *   RNB_VARIANT_REG_TILE /    which family of fused x3 sweeps runs: REG_TILE = the register-tile kernels (fused_t.hip:
- *   RNB_VARIANT_LDS_TILE      32 points per wave, activations in registers from layer to layer, weights through an LDS
- *                             ring), LDS_TILE = the 64-point LDS-tile kernels (fused.hip / fused_bwd.hip).  Neither bit:
- *                             the measured default per sweep and batch size.  A/B switches. */
+ *   RNB_VARIANT_REG_TILE /    which family of fused x3 sweeps runs: REG_TILE = the M/V kernels (sweep_mv.hip: matrix waves
+ *   RNB_VARIANT_LDS_TILE      with 32 points each and the weights through an LDS-DMA ring + vector waves for the
+ *                             epilogues), LDS_TILE = the 64-point LDS-tile kernels (fused.hip / fused_bwd.hip).  Neither
+ *                             bit: the measured default per sweep and batch size.  A/B switches. */
 enum {
   RNB_VARIANT_BF16 = 1,
   RNB_VARIANT_DETERMINISTIC = 2,

@@ -208,7 +208,7 @@ struct X3Entry { long long off; int N, K, unit_begin, tperm; };
 struct X3Table { int n, total_units; X3Entry e[kMaxX3]; };
 // one thread per 16-byte unit of one plane-triple: W[32 nt + c][16 ks + 8 h .. +8] -> hi, mid, lo.
 // tperm (the SDF network's matrices): the lane's 8 k of a step are 16 ks + 4 h + {0..3, 8..11} instead — the order in
-// which the accumulator of a TRANSPOSED product (fused_t.hip: t_kfeat) hands its features to the next layer; the
+// which the accumulator of a TRANSPOSED product (sweep_mv.hip: mv_kfeat) hands its features to the next layer; the
 // LDS-tile kernels read their activation rows in the same order (x3_read_a), so one mirror serves both families.
 __global__ void x3_pack_kernel(const float* __restrict__ src, X3Table t, x3raw* __restrict__ dst) {
   const int u = blockIdx.x * blockDim.x + threadIdx.x;
@@ -270,7 +270,7 @@ bool fused_supported(const Layout& L) {
 // Fused replacement of launch_pe_points + sweep_forward (same outputs; pb.a / pb.D only when `save`).
 int fused_forward(const Layout& L, const float* packed, const float* pts, int64_t M, PointBufs& pb, bool save,
                   bool need_feat, bool need_gz_last, hipStream_t s, const GridGen* grid) {
-  if (use_reg_tile(L, pb.Mp)) return fused_forward_t(L, packed, pts, M, pb, save, need_feat, need_gz_last, s, grid);
+  if (use_reg_tile(L, pb.Mp)) return sweep_mv_forward(L, packed, pts, M, pb, save, need_feat, need_gz_last, s, grid);
   FusedFwdArgs g;
   memset(&g, 0, sizeof(g));
   if (grid) g.grid = *grid;

@@ -11,7 +11,7 @@ constexpr int FH = 256;       // hidden width of the fused path
 constexpr int FP = FH + 4;    // LDS pitch of the activation tile
 constexpr int FEP = 40;       // LDS pitch of the positional-encoding copy kept for the skip connection
 
-// arguments of the forward sweep kernels (fused.hip, fused_t.hip)
+// arguments of the forward sweep kernels (fused.hip, sweep_mv.hip)
 struct FusedFwdArgs {
   const float* pts;     // [M,3]
   int64_t M;

@@ -177,14 +177,15 @@ int fused_fb(const Layout& L, const float* packed, PointBufs& pb, bool with_colo
 bool fused_supported(const Layout& L);
 int fused_forward(const Layout& L, const float* packed, const float* pts, int64_t M, PointBufs& pb, bool save,
                   bool need_feat, bool need_gz_last, hipStream_t s, const GridGen* grid = nullptr);
-// ---- register-tile sweeps (fused_t.hip): x3 arithmetic, 32 points per wave, weights through an LDS ring ----
-bool fused_t_supported(const Layout& L);
-int fused_forward_t(const Layout& L, const float* packed, const float* pts, int64_t M, PointBufs& pb, bool save,
-                    bool need_feat, bool need_gz_last, hipStream_t s, const GridGen* grid = nullptr);
-// family of a sweep over Mp points: the register-tile kernels need >= one 128-point workgroup per CU to fill the chip
+// ---- M/V sweeps (sweep_mv.hip): x3 arithmetic, matrix waves (32 points each, transposed product, weights through an
+// LDS-DMA ring) + vector waves (epilogues, saved state, operand split) ----
+bool sweep_mv_supported(const Layout& L);
+int sweep_mv_forward(const Layout& L, const float* packed, const float* pts, int64_t M, PointBufs& pb, bool save,
+                     bool need_feat, bool need_gz_last, hipStream_t s, const GridGen* grid = nullptr);
+// family of a sweep over Mp points: the M/V kernels need >= one 128-point workgroup per CU to fill the chip
 constexpr bool kRegTileDefault = false;
 inline bool use_reg_tile(const Layout& L, int64_t Mp) {
-  if (!fused_t_supported(L) || (L.variant & RNB_VARIANT_LDS_TILE)) return false;
+  if (!sweep_mv_supported(L) || (L.variant & RNB_VARIANT_LDS_TILE)) return false;
   if (L.variant & RNB_VARIANT_REG_TILE) return true;
   return kRegTileDefault && Mp >= 128 * 200;
 }

@@ -1,0 +1,763 @@
+// "M/V" sweeps of the 256-wide SDF network (x3 arithmetic): matrix waves and vector waves.
+//
+// fused.hip / fused_bwd.hip give each of the four waves of a workgroup 64 output COLUMNS of a 64-point LDS tile: every
+// wave splits the same fp32 rows into bf16 planes (4 x redundant), every layer ends in two workgroup barriers, each tile
+// streams the 393 KB plane mirror of a layer from L2 — three co-limits of the same size (matrix pipe, vector issue,
+// L2 -> CU weight stream: DESIGN 4), and the matrix pipe ends ~50 % busy.
+//
+// Here the product is taken TRANSPOSED, acc[feature][point] = W[feature][k] * act[k][point]: the weights are the MFMA's A
+// operand, the activations its B operand, a matrix wave owns 32 POINTS and all 256 features.  A workgroup is 8 waves on
+// 128 points; waves w and w + 4 share a SIMD:
+//   * M waves 0..3 do nothing but multiply: weight fragments from an LDS ring that LDS-DMA fills once per workgroup
+//     (half the L2 -> CU stream per point of the 64-point tiles; ds_read_b128, 1 KB contiguous per instruction), the
+//     B operand (three bf16 planes of the step's 8 k per lane) from LDS, 48 MFMAs per 16-k step, ~2000 instruction issue
+//     slots per layer for 768 MFMAs.  A finished 32-feature block goes to the partner wave through a 4.6 KB LDS tile;
+//   * V waves 4..7 do everything else, for the 32 points of their M wave, in a layout of their own (lane = 4 features x
+//     4 points; 8 lanes = one 128-byte line of a row-major state matrix, so every global access is whole lines): bias,
+//     softplus and its derivative, the saved state, the sdf head, the skip connection — and the split of the next layer's
+//     operand into bf16 planes, ONCE per activation, written to LDS in the MFMA's B layout.  Their vector instructions
+//     execute beside the partner's MFMAs on the same SIMD (measured: 190 vector instructions per step in the V waves leave
+//     the M waves' 28.9 k clocks per layer unchanged; the same instructions inside the M wave's own stream cost 10 k: one
+//     wave has ~8 issue slots per MFMA).
+// One s_barrier per 16-k step (the ring's publish / recycle point) paces both kinds of wave: V writes the planes of step
+// k two windows ahead of their use, so the barrier alone orders plane writes and reads; only the hand-over of finished
+// accumulator blocks and the first planes of a layer go through LDS counters.
+//
+//   sweep_mv_forward_kernel   positional encoding + F sweep (+ sdf head, + feature head)
+//                             models/embedder.py:40-46, models/fields.py:82-104
+#include <type_traits>
+
+#include "fused_common.hip.h"
+
+namespace rnb {
+
+constexpr int MV_MW = 4;                            // matrix waves per workgroup (and vector waves)
+constexpr int MV_PT = 32 * MV_MW;                   // points per workgroup
+constexpr int MV_PIECE = 1024;                      // one plane of one fragment: one LDS-DMA instruction (64 lanes x 16 B)
+constexpr int MV_SLOT = 8 * 3 * MV_PIECE;           // ring slot: one 16-k step of a 256-row matrix (8 row blocks x 3 planes)
+constexpr int MV_NSLOT = 4;                         // ring depth (k-steps)
+constexpr int MV_ACCP = 36;                         // pitch (floats) of the hand-over tile [32 points][32 features]
+constexpr int MV_ACC_BYTES = 32 * MV_ACCP * 4;      // 4608
+constexpr int MV_PLS = 3 * 1024 + 32;               // stride of one step's planes [plane][M lane] (+32: spreads the V waves' writes)
+constexpr int MV_PLN = 3;                           // planes ring depth (steps)
+constexpr int MV_PAIR_BYTES = MV_ACC_BYTES + MV_PLN * MV_PLS;   // per M / V pair: 13,920 B
+constexpr int MV_EP = 68;                           // pitch (floats) of the PE staging tile (aliases the planes ring, prologue only)
+constexpr int MV_SYNC = 4;                          // ints per pair: blocks handed over, blocks drained, layers with first planes, error
+constexpr int MV_MAXM = RNB_MAX_LIN + 1;
+constexpr int MV_MAXB = 8;                          // hidden layers whose bias rows fit the LDS table (+ the sdf row)
+
+// feature (k index of the next layer) held by accumulator register r of 32-feature block j in lane half h
+__host__ __device__ constexpr int mv_kfeat(int j, int r, int h) { return 32 * j + 4 * h + (r & 3) + 8 * (r >> 2); }
+
+struct MvStream {            // the matrices streamed through the ring, in order
+  int nmat;
+  int nks[MV_MAXM];          // 16-k steps of matrix i (a multiple of 4: every matrix starts at ring slot 0)
+  unsigned boff[MV_MAXM];    // byte offset of its mirror in the split mirror
+};
+struct MvFwdArgs {
+  FusedFwdArgs f;
+  MvStream st;
+  unsigned long long* stamps;   // tools/mv_bench (RNB_MV_STAMP builds): [workgroup][64] shader clocks of wave 0; else unused
+  int* err;                     // != nullptr: set to 1 when a bounded wait gave up (never expected)
+};
+#ifdef RNB_MV_STAMP
+#define MV_STAMP(i) do { if (tid == 0) ga.stamps[(size_t)blockIdx.x * 64 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define MV_STAMP_REAL(i) do { if (tid == 0) ga.stamps[(size_t)blockIdx.x * 64 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define MV_STAMP(i) do { } while (0)
+#define MV_STAMP_REAL(i) do { } while (0)
+#endif
+
+// LDS pointers carry their address space: through a struct member or a function argument hipcc otherwise falls back to
+// generic pointers, i.e. flat_load / flat_store (a volatile counter poll became a system-scope flat load: ~10 x the latency)
+#define LDSP(T) __attribute__((address_space(3))) T*
+template <int B, int E, class F>
+__device__ __attribute__((always_inline)) inline void static_for(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_for<B + 1, E>(f);
+  }
+}
+
+// ---- LDS-DMA ----------------------------------------------------------------------------------------------------
+// One piece: 64 lanes x 16 bytes from (rs, voff + soff) to LDS bytes [lds_addr, lds_addr + 1024).  Inline assembly on
+// purpose: hipcc's wait-count pass treats the builtin form as a store to LDS that may alias every later ds_read and puts
+// s_waitcnt vmcnt(0) in front of them — the ring's whole point is that the DMAs of later steps stay in flight while the
+// current step is read (their completion is waited for explicitly, counted, before the barrier that publishes a slot).
+__device__ __attribute__((always_inline)) inline void mv_dma16(vu4x rs, unsigned lds_addr, unsigned voff, unsigned soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs), "s"(soff)
+               : "memory");
+}
+__device__ inline unsigned lds_addr_of(const void* p) {
+  return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
+}
+struct MvRing {
+  vu4x rs;           // buffer resource over the split mirror
+  unsigned lds;      // LDS byte address of the ring
+};
+struct MvMat {
+  unsigned base;     // byte offset of the matrix in the mirror
+  int nks;           // its 16-k steps
+  int clamp;         // 1: there is no such matrix (request its last step again: keeps the consumer's vmcnt arithmetic uniform)
+};
+__device__ inline MvRing mv_ring_init(const x3raw* w3, const char* ring) {
+  const unsigned long long a = (unsigned long long)w3;
+  MvRing q;
+  q.rs = vu4x{(unsigned)a, (unsigned)(a >> 32) & 0xffffu, 0x7fffffffu, 0x00020000u};
+  q.lds = lds_addr_of(ring);
+  return q;
+}
+// matrix wave `wave`'s share of k-step ks of matrix m into ring slot `slot`: row blocks 2 wave, 2 wave + 1 (6 pieces of 1 KB)
+__device__ __attribute__((always_inline)) inline void mv_issue(const MvRing& q, const MvMat& m, int ks, int slot, int wave, unsigned lane16) {
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int nt = 2 * wave + u;
+    const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((int)(m.base + (unsigned)((nt * m.nks + ks) * 3) * (unsigned)MV_PIECE));
+    const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(q.lds + (unsigned)(slot * MV_SLOT + nt * 3 * MV_PIECE)));
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) mv_dma16(q.rs, dst + pl * MV_PIECE, lane16, soff + pl * MV_PIECE);
+  }
+}
+
+// ---- LDS counters between a matrix wave and its vector wave -----------------------------------------------------
+// An LDS instruction of one wave executes after the LDS instructions that wave issued before it: a counter store behind
+// the data stores needs no wait in front of it.  The waits are bounded: a wave that has polled for ~20 ms gives up and
+// sets the error word (wrong results, but every wave still reaches every barrier and the grid drains; later waits
+// of the pair return at once).
+__device__ __attribute__((always_inline)) inline void mv_signal(LDSP(int) c, int v, int lane) {
+  asm volatile("" ::: "memory");
+  if (lane == 0) *(LDSP(volatile int))c = v;
+  asm volatile("" ::: "memory");
+}
+template <bool SLEEP = true>
+__device__ __attribute__((always_inline)) inline void mv_wait(LDSP(int) c, int target, LDSP(int) errw) {
+  asm volatile("" ::: "memory");
+  for (int spin = 0; spin < (1 << 18); ++spin) {
+    if (__builtin_amdgcn_readfirstlane(*(LDSP(volatile int))c) >= target) {
+      asm volatile("" ::: "memory");
+      return;
+    }
+    if (spin > 64 && __builtin_amdgcn_readfirstlane(*(LDSP(volatile int))errw) != 0) return;   // (a wait already gave up: drain quickly)
+    if (SLEEP) __builtin_amdgcn_s_sleep(1);
+  }
+  *(LDSP(volatile int))errw = 1;
+  asm volatile("" ::: "memory");
+}
+// the same with the counter's value already requested (`seen`, read a block of MFMAs earlier): the common case costs a
+// compare, not an LDS round trip behind every outstanding fragment read
+__device__ __attribute__((always_inline)) inline void mv_wait_seen(int seen, LDSP(int) c, int target, LDSP(int) errw) {
+  if (__builtin_amdgcn_readfirstlane(seen) >= target) return;
+  mv_wait<false>(c, target, errw);
+}
+
+// the six terms of one (32 features x 32 points x 16 k) block, small ones first (x3_mfma)
+template <bool FIRST>
+__device__ __attribute__((always_inline)) inline void mv_block(const vu4x (&a)[3], const vu4x (&b)[3], v16f& acc) {
+  constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
+  constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+  for (int t = 0; t < 6; ++t) {
+    if (FIRST && t == 0) {
+      const v16f zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(x3bf8, a[PA[t]]), __builtin_bit_cast(x3bf8, b[PB[t]]), zero, 0, 0, 0);
+    } else {
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(x3bf8, a[PA[t]]), __builtin_bit_cast(x3bf8, b[PB[t]]), acc, 0, 0, 0);
+    }
+  }
+}
+
+// softplus (+ derivative) of NV values in lockstep (stage by stage: NV independent chains), scalar fp32
+template <bool SAVE, int NV>
+__device__ __attribute__((always_inline)) inline void mv_softplus(const float (&z)[NV], float (&a)[NV], float (&D)[NV]) {
+  constexpr float L2E = 1.44269504088896341f, LN2 = 0.693147180559945309f;
+  float tt[NV], nt[NV], pp[NV], qq[NV], w[NV], u[NV], r[NV], lg[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) tt[i] = z[i] * 100.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) nt[i] = -fabsf(tt[i]);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) pp[i] = nt[i] * L2E;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) qq[i] = __builtin_fmaf(nt[i], L2E, -pp[i]) * LN2;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) w[i] = __builtin_amdgcn_exp2f(pp[i]);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) w[i] = __builtin_fmaf(w[i], qq[i], w[i]);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) u[i] = 1.f + w[i];
+  if constexpr (SAVE) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) r[i] = __builtin_amdgcn_rcpf(u[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) lg[i] = __builtin_amdgcn_logf(u[i]);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const float d = w[i] - (u[i] - 1.f);
+    float l1p;
+    if constexpr (SAVE) l1p = __builtin_fmaf(lg[i], LN2, d * r[i]);          // (softplus_aD)
+    else l1p = __builtin_fmaf(lg[i], LN2, __builtin_fmaf(-d, w[i], d));      // (softplus_a: no reciprocal)
+    a[i] = __builtin_fmaf(l1p, 0.01f, fmaxf(z[i], 0.f));
+    if constexpr (SAVE) D[i] = tt[i] >= 0.f ? r[i] : w[i] * r[i];
+  }
+}
+// The first step of the next layer, by the matrix wave itself.  Registers 0..7 of block 0 in lane (p, h) ARE the lane's
+// eight k of step 0 of the next product: bias, softplus, split — 8 values, ~190 instructions once per layer, while the V
+// wave is still busy draining the other blocks.  (Left to the V wave, block 0's whole epilogue — drain, 16 values per lane,
+// plane stores, counter — sat on the critical path between two layers: ~2 k clocks of the matrix pipe per layer.)  The V
+// wave computes the same values again for the saved state and the sdf head: same function, same operations, same bits.
+template <bool SAVE>
+__device__ __attribute__((always_inline)) inline void mv_m_first_planes(const v16f& blk0, LDSP(const float) bias_h, vu4x (&pl0)[3]) {
+  float z[8], a[8], D[8];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const vf4 bv = *(LDSP(const vf4))(bias_h + 8 * q);
+#pragma unroll
+    for (int x = 0; x < 4; ++x) z[4 * q + x] = blk0[4 * q + x] + bv[x];
+  }
+  mv_softplus<SAVE, 8>(z, a, D);
+#pragma unroll
+  for (int pr = 0; pr < 4; ++pr) {
+    const float va = a[2 * pr], vb = a[2 * pr + 1];
+    unsigned uh = x3_pack2(va, vb);
+    asm("" : "+v"(uh));
+    const float ra = va - __builtin_bit_cast(float, uh << 16);
+    const float rb = __builtin_fmaf(__builtin_bit_cast(float, uh & 0xffff0000u), -1.f, vb);
+    unsigned um = x3_pack2(ra, rb);
+    asm("" : "+v"(um));
+    const float sa = ra - __builtin_bit_cast(float, um << 16);
+    const float sb = __builtin_fmaf(__builtin_bit_cast(float, um & 0xffff0000u), -1.f, rb);
+    pl0[0][pr] = uh;
+    pl0[1][pr] = um;
+    pl0[2][pr] = x3_pack2(sa, sb);
+  }
+}
+
+// ===============================================================================================================
+// matrix wave
+// ===============================================================================================================
+struct MvPair {
+  LDSP(char) acc;   // hand-over tile [32][MV_ACCP] fp32
+  LDSP(char) pl;    // planes ring [MV_PLN][MV_PLS]
+  LDSP(int) sync;   // [0] blocks handed over, [1] blocks drained, [2] layers whose first two steps' planes are written, [3] error
+};
+// One product of NKS 16-k steps: acc[j] = W[32 j .. + 32][:] x (the planes of the steps).  `pl`: B operand of the current /
+// next step (registers); the planes of step s + 1 are read from the ring behind block 5 of step s — written by the V wave
+// at least one barrier earlier, so the barrier orders them (the first step's planes of a product are the exception: they
+// come out of the hand-over of the previous product's accumulators, `mv_wait` on sync[2]).
+// Ring protocol per step s (global step t): blocks 0..3 (last step: block 0) | s_waitcnt vmcnt(6): this wave's pieces of step
+// t + 1 have landed | s_barrier: so have everybody's, and everybody has finished reading step t - 1 | request step t + 3 into
+// the slot of t - 1 | the remaining blocks (whose fragment prefetch already reaches into step t + 1).
+// The last step hands every finished block to the V wave (block j behind the MFMAs of block j + 1, whose issue covers the
+// latency of j's last MFMA): wait until the V wave has drained the tile, four 16-byte stores per lane, counter.
+template <int NKS>
+__device__ __attribute__((always_inline)) inline void mv_m_product(v16f (&acc)[8], vu4x (&pl)[2][3], LDSP(const char) ring, const MvRing& rq,
+                                                                   const MvMat& cur, const MvMat& nxt, const MvPair& pr, int& nblk,
+                                                                   int& pslot, int wave, int lane, unsigned long long* stamp = nullptr) {
+  LDSP(const char) fr = ring + lane * 16;
+  const unsigned lane16 = (unsigned)lane * 16u;
+  const int p = lane & 31, h = lane >> 5;
+  LDSP(float) const atile = (LDSP(float))pr.acc + p * MV_ACCP + 4 * h;
+  vu4x a[3][3];
+  auto rd = [&](int slot, int j, vu4x (&d)[3]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) d[q] = *(LDSP(const vu4x))(fr + slot * MV_SLOT + (j * 3 + q) * MV_PIECE);
+  };
+  int seen = 0;   // acc_free as read one block earlier
+  auto handover = [&](const v16f& blk) __attribute__((always_inline)) {
+    mv_wait_seen(seen, pr.sync + 1, nblk, pr.sync + 3);   // the V wave has drained the previous block
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *(LDSP(vf4))(atile + 8 * q) = vf4{blk[4 * q], blk[4 * q + 1], blk[4 * q + 2], blk[4 * q + 3]};
+    ++nblk;
+    mv_signal(pr.sync, nblk, lane);
+  };
+  rd(0, 0, a[0]);
+  rd(0, 1, a[1]);
+  __builtin_amdgcn_sched_barrier(0);
+#ifdef RNB_MV_STAMP
+  if (stamp && threadIdx.x == 0) stamp[0] = __builtin_amdgcn_s_memtime();
+#endif
+  static_for<0, NKS>([&](auto sc) __attribute__((always_inline)) {
+    constexpr int s = decltype(sc)::value;
+#ifdef RNB_MV_STAMP
+    if constexpr (s == NKS - 1) { if (stamp && threadIdx.x == 0) stamp[1] = __builtin_amdgcn_s_memtime(); }
+#endif
+    static_for<0, 8>([&](auto jc) __attribute__((always_inline)) {
+      constexpr int j = decltype(jc)::value;
+      constexpr int blk = s * 8 + j;
+      constexpr int nj = (j + 2) & 7, ns = s + ((j + 2) >> 3);
+      if constexpr (ns < NKS) rd(ns & (MV_NSLOT - 1), nj, a[(blk + 2) % 3]);
+      if constexpr (s == NKS - 1) seen = *(LDSP(volatile int))(pr.sync + 1);
+      mv_block<s == 0>(a[blk % 3], pl[s & 1], acc[j]);
+      if constexpr (ns < NKS) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      // (the LAST step's barrier sits behind block 0: the V wave drains the finished blocks in the window that this barrier
+      // opens, so every hand-over must come after it — and block 0, the one on the critical path, is final right there)
+      if constexpr (j == (s == NKS - 1 ? 0 : 3)) {
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if constexpr (s + 3 < NKS) mv_issue(rq, cur, s + 3, (s + 3) & (MV_NSLOT - 1), wave, lane16);
+        else mv_issue(rq, nxt, nxt.clamp ? nxt.nks - 1 : s + 3 - NKS, (s + 3) & (MV_NSLOT - 1), wave, lane16);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (j == 5 && s + 1 < NKS) {   // the next step's B operand
+        if constexpr (s == 0 && NKS == 16) mv_wait(pr.sync + 2, nblk >> 3, pr.sync + 3);   // (step 1's: out of the hand-over just made)
+        pslot = pslot + 1 == MV_PLN ? 0 : pslot + 1;
+        LDSP(const char) ps = pr.pl + pslot * MV_PLS + lane * 16;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) pl[(s + 1) & 1][q] = *(LDSP(const vu4x))(ps + q * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (s == NKS - 1 && j >= 1) {
+        handover(acc[j - 1]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    });
+  });
+  seen = *(LDSP(volatile int))(pr.sync + 1);
+  handover(acc[7]);
+#ifdef RNB_MV_STAMP
+  if (stamp && threadIdx.x == 0) stamp[2] = __builtin_amdgcn_s_memtime();
+#endif
+  pslot = pslot + 1 == MV_PLN ? 0 : pslot + 1;   // (the next product's first step)
+}
+
+// ===============================================================================================================
+// vector wave
+// ===============================================================================================================
+// Layout: lane (p8 = lane >> 3, c = lane & 7) owns, of every 32-feature block, features 4 c .. 4 c + 3 of the four points
+// P_i = 8 i + p8 (i = 0..3) of its matrix wave's 32: a 16-byte access per point, 8 lanes = one 128-byte line of a
+// row-major [point][256] matrix.  In the MFMA's B operand of step 2 j + (c >> 2) these four features are elements
+// 4 ((c >> 1) & 1) .. + 4 of M lane (P_i, h = c & 1): 8 bytes of each plane.
+struct MvV {
+  int p8, c;
+  int64_t row[4];        // global rows of the four points
+  LDSP(char) plw;        // planes ring + the lane's byte offset inside a step's plane [(8 i + p8 + 32 h) * 16 + 8 half], for i = 0
+};
+// four consecutive k of one point -> the 8 bytes of each plane (x3_split4 of a row quad)
+__device__ __attribute__((always_inline)) inline void mv_split4(const float (&v)[4], vu2& hi, vu2& mid, vu2& lo) {
+#pragma unroll
+  for (int pr = 0; pr < 2; ++pr) {
+    const float a = v[2 * pr], b = v[2 * pr + 1];
+    unsigned uh = x3_pack2(a, b);
+    asm("" : "+v"(uh));
+    const float ra = a - __builtin_bit_cast(float, uh << 16);
+    const float rb = __builtin_fmaf(__builtin_bit_cast(float, uh & 0xffff0000u), -1.f, b);
+    unsigned um = x3_pack2(ra, rb);
+    asm("" : "+v"(um));
+    const float sa = ra - __builtin_bit_cast(float, um << 16);
+    const float sb = __builtin_fmaf(__builtin_bit_cast(float, um & 0xffff0000u), -1.f, rb);
+    hi[pr] = uh;
+    mid[pr] = um;
+    lo[pr] = x3_pack2(sa, sb);
+  }
+}
+// the planes of one point's four values into ring slot `slot` (the lane's step is 2 j + (c >> 2): the caller picks the slot)
+__device__ __attribute__((always_inline)) inline void mv_put_planes(const MvV& v, int slot, int i, const float (&x)[4]) {
+  vu2 hi, mid, lo;
+  mv_split4(x, hi, mid, lo);
+  LDSP(char) w = v.plw + slot * MV_PLS + i * 8 * 16;
+  *(LDSP(vu2))(w) = hi;
+  *(LDSP(vu2))(w + 1024) = mid;
+  *(LDSP(vu2))(w + 2048) = lo;
+}
+
+// epilogue of one hidden layer as the V wave sees it
+struct MvEpi {
+  LDSP(const float) bias; // LDS: bias row + 4 c
+  LDSP(const float) ws;   // LDS: sdf row + 4 c (last hidden layer) or nullptr
+  float* a;               // SAVE: a_l, D_l (global, row-major [Mp][256]) + 4 c
+  float* D;
+  int n_real;             // real output width (the skip-feeding layer: 256 - pe; its columns beyond are the PE: `sk`)
+  bool pe_tail;
+};
+// Block j of a hidden layer for points i0 .. i0 + NI - 1: bias, softplus, skip columns, saved state, sdf head; the
+// activations stay in `act` for the split.
+template <bool SAVE, int NI>
+__device__ __attribute__((always_inline)) inline void mv_v_act(const MvV& v, const MvEpi& e, int j, int i0, const vf4 (&vacc)[4], const vf4 (&sk)[2][4],
+                                                               float (&act)[4][4], float (&sacc)[4]) {
+  constexpr int NV = 4 * NI;
+  const vf4 bv = *(LDSP(const vf4))(e.bias + 32 * j);
+  vf4 wv = {0.f, 0.f, 0.f, 0.f};
+  if (e.ws) wv = *(LDSP(const vf4))(e.ws + 32 * j);
+  float z[NV], a[NV], D[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) z[k] = vacc[i0 + (k >> 2)][k & 3] + bv[k & 3];
+  mv_softplus<SAVE, NV>(z, a, D);
+  // columns beyond the layer's real width (n_real >= 192: blocks 6 and 7 only): the PE columns of the skip connection or 0
+  if (j >= 6) {
+    const int f0 = 32 * j + 4 * v.c - e.n_real;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const bool beyond = f0 + (k & 3) >= 0;
+      const float pv = e.pe_tail ? sk[j - 6][i0 + (k >> 2)][k & 3] : 0.f;
+      a[k] = beyond ? pv : a[k];
+      if constexpr (SAVE) D[k] = beyond ? 0.f : D[k];
+    }
+  }
+#pragma unroll
+  for (int ii = 0; ii < NI; ++ii) {
+    const int i = i0 + ii;
+#pragma unroll
+    for (int x = 0; x < 4; ++x) act[i][x] = a[4 * ii + x];
+    if constexpr (SAVE) {
+      __builtin_nontemporal_store(vf4{a[4 * ii], a[4 * ii + 1], a[4 * ii + 2], a[4 * ii + 3]},
+                                  reinterpret_cast<vf4*>(e.a + v.row[i] * FH + 32 * j));
+      __builtin_nontemporal_store(vf4{D[4 * ii], D[4 * ii + 1], D[4 * ii + 2], D[4 * ii + 3]},
+                                  reinterpret_cast<vf4*>(e.D + v.row[i] * FH + 32 * j));
+    }
+    sacc[i] = fmaf(a[4 * ii + 3], wv[3], fmaf(a[4 * ii + 2], wv[2], fmaf(a[4 * ii + 1], wv[1], fmaf(a[4 * ii], wv[0], sacc[i]))));
+  }
+}
+// one finished block from the hand-over tile into registers
+__device__ __attribute__((always_inline)) inline void mv_v_drain(const MvV& v, const MvPair& pr, int& nblk, vf4 (&dst)[4], int lane) {
+  mv_wait<false>(pr.sync, nblk + 1, pr.sync + 3);
+  LDSP(const float) t = (LDSP(const float))pr.acc + v.p8 * MV_ACCP + 4 * v.c;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) dst[i] = *(LDSP(const vf4))(t + 8 * i * MV_ACCP);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  ++nblk;
+  mv_signal(pr.sync + 1, nblk, lane);
+}
+
+template <bool SAVE>
+__global__ __launch_bounds__(128 * MV_MW, 2) void sweep_mv_forward_kernel(MvFwdArgs ga) {
+  const FusedFwdArgs& g = ga.f;
+  const MvStream& st = ga.st;
+  __shared__ __attribute__((aligned(1024))) char lds[MV_NSLOT * MV_SLOT + MV_MW * MV_PAIR_BYTES + MV_MW * MV_SYNC * 4 + (MV_MAXB + 1) * FH * 4];
+  LDSP(char) const lds3 = (LDSP(char))lds;
+  LDSP(char) const ring = lds3;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = wave_id();
+  const int m = wave & (MV_MW - 1);                  // the pair
+  const int64_t row0 = (int64_t)blockIdx.x * MV_PT + m * 32;   // first row of the pair's 32 points
+  MvPair pr;
+  pr.acc = lds3 + MV_NSLOT * MV_SLOT + m * MV_PAIR_BYTES;
+  pr.pl = pr.acc + MV_ACC_BYTES;
+  pr.sync = (LDSP(int))(lds3 + MV_NSLOT * MV_SLOT + MV_MW * MV_PAIR_BYTES) + m * MV_SYNC;
+  LDSP(float) const Bsh = (LDSP(float))(lds3 + MV_NSLOT * MV_SLOT + MV_MW * MV_PAIR_BYTES + MV_MW * MV_SYNC * 4);   // [nh + 1][256]
+  const int nprod = g.nh + (g.with_feat ? 1 : 0);
+  MV_STAMP(0);
+  MV_STAMP_REAL(60);
+
+  if (wave < MV_MW) {
+    // ============================== matrix wave ==============================
+    const MvRing rq = mv_ring_init(g.w3, lds);
+    auto mat = [&](int i, bool clamp) __attribute__((always_inline)) {
+      MvMat mm = {(unsigned)__builtin_amdgcn_readfirstlane((int)st.boff[i]), __builtin_amdgcn_readfirstlane(st.nks[i]), clamp ? 1 : 0};
+      return mm;
+    };
+    {
+      const MvMat m0 = mat(0, false);
+#pragma unroll
+      for (int t = 0; t < 3; ++t) mv_issue(rq, m0, t, t, wave, (unsigned)lane * 16u);
+    }
+    __syncthreads();   // the V waves' prologue: planes of steps 0..2 are written, counters zeroed (and ring steps 0..2 have landed)
+    v16f acc[8];
+    vu4x pl[2][3];
+    int nblk = 0, pslot = 0;
+    {
+      LDSP(const char) ps = pr.pl + lane * 16;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) pl[0][q] = *(LDSP(const vu4x))(ps + q * 1024);
+    }
+    mv_m_product<4>(acc, pl, ring, rq, mat(0, false), mat(nprod > 1 ? 1 : 0, nprod <= 1), pr, nblk, pslot, wave, lane);
+    MV_STAMP(2);
+    for (int i = 1; i < nprod; ++i) {
+      // the planes of this product's step 0: block 0 of the layer just finished (still in acc[0]), by this wave itself; those
+      // of step 1 come from the V wave (counter sync[2], waited for inside the product)
+      mv_m_first_planes<SAVE>(acc[0], Bsh + (i - 1) * FH + 4 * (lane >> 5), pl[0]);
+      mv_m_product<16>(acc, pl, ring, rq, mat(i, false), mat(i + 1 < nprod ? i + 1 : i, i + 1 >= nprod), pr, nblk, pslot, wave, lane,
+                       ga.stamps ? ga.stamps + (size_t)blockIdx.x * 64 + 8 + 4 * i : nullptr);
+      MV_STAMP(2 + i);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the over-requested steps have landed before the LDS is released
+    MV_STAMP(40);
+    MV_STAMP_REAL(61);
+    if (ga.err && lane == 0 && *(LDSP(volatile int))(pr.sync + 3)) *ga.err = 1;
+    return;
+  }
+
+  // ============================== vector wave ==============================
+  MvV v;
+  v.p8 = lane >> 3;
+  v.c = lane & 7;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v.row[i] = row0 + 8 * i + v.p8;
+  v.plw = pr.pl + (v.p8 + 32 * (v.c & 1)) * 16 + 8 * ((v.c >> 1) & 1);
+  if (lane < MV_SYNC) pr.sync[lane] = 0;
+  // bias rows of the hidden layers and the sdf row -> LDS (a global load in front of every block's activation would put its
+  // latency into a barrier-paced window)
+  {
+    const int t4 = tid - 64 * MV_MW;   // 0..255 over the four V waves
+    for (int l = 0; l < g.nh; ++l) Bsh[l * FH + t4] = g.packed[g.b_off[l] + t4];
+    Bsh[g.nh * FH + t4] = g.packed[g.wsdf_off + t4];
+  }
+
+  // ---- positional encoding of the pair's 32 points -> staging tile (aliases the planes ring) ----------------------
+  LDSP(float) const E = (LDSP(float))pr.pl;
+  {
+    const int pp = lane & 31, hh = lane >> 5;
+    const int64_t row = row0 + pp;
+    float x[3] = {0.f, 0.f, 0.f};
+    if (row < g.M) {
+      if (g.grid.on) {   // row = ((ix - x_begin) * res + iy) * res + iz of the slab
+        const int res = g.grid.res;
+        int64_t r = row;
+        const int iz = (int)(r % res);
+        r /= res;
+        const int iy = (int)(r % res);
+        const int ix = (int)(r / res) + g.grid.x_begin;
+        x[0] = linspace_at(g.grid.bmin[0], g.grid.bmax[0], res, ix) * g.scale;
+        x[1] = linspace_at(g.grid.bmin[1], g.grid.bmax[1], res, iy) * g.scale;
+        x[2] = linspace_at(g.grid.bmin[2], g.grid.bmax[2], res, iz) * g.scale;
+      } else {
+        x[0] = g.pts[row * 3] * g.scale;
+        x[1] = g.pts[row * 3 + 1] * g.scale;
+        x[2] = g.pts[row * 3 + 2] * g.scale;
+      }
+    }
+    LDSP(float) er = E + pp * MV_EP;
+    if (hh == 0) {
+      er[0] = x[0]; er[1] = x[1]; er[2] = x[2];
+      for (int cc = g.pe; cc < 64; ++cc) er[cc] = 0.f;
+      if (SAVE) *reinterpret_cast<vf4*>(g.x4 + row * 4) = vf4{x[0], x[1], x[2], 0.f};
+    }
+    for (int k = hh; k < g.multires; k += 2) {   // the two lanes of a point share the frequencies
+      const float f = (float)(1 << k);
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        float s, co;
+        sincosf(x[d] * f, &s, &co);
+        const int cc = 3 + 6 * k + d;
+        er[cc] = s;
+        er[cc + 3] = co;
+      }
+    }
+  }
+  // (one wave wrote the tile and reads it: LDS instructions of a wave execute in order)
+  vf4 pe0[2][4];      // PE in the V layout: blocks 0, 1 (features 0..63) of the four points
+#pragma unroll
+  for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pe0[jb][i] = *(LDSP(const vf4))(E + (8 * i + v.p8) * MV_EP + 32 * jb + 4 * v.c);
+  // the PE columns of the skip connection as they will sit in blocks 6, 7 of the layer that feeds it
+  vf4 sk[2][4];
+  {
+    const int nr = g.skip >= 1 ? g.n_real[g.skip - 1] : FH;
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float t[4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          const int idx = 32 * (6 + jb) + 4 * v.c + x - nr;
+          const int ic = idx < 0 ? 0 : (idx > 63 ? 63 : idx);
+          const float pv = E[(8 * i + v.p8) * MV_EP + ic];
+          t[x] = (idx >= 0 && idx < g.pe) ? pv : 0.f;
+        }
+        sk[jb][i] = vf4{t[0], t[1], t[2], t[3]};
+      }
+  }
+  if (SAVE) {   // e is an operand of the backward (dW of layer 0) and of the R sweep: [points][64]
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) *reinterpret_cast<vf4*>(g.e + v.row[i] * 64 + 32 * jb + 4 * v.c) = pe0[jb][i];
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every read of the staging tile is done: the ring may be written
+  // planes of layer 0's steps 0, 1 (block 0) and 2 (block 1, lanes c < 4); step 3 (block 1, lanes c >= 4) waits for slot 0
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float x0[4] = {pe0[0][i][0], pe0[0][i][1], pe0[0][i][2], pe0[0][i][3]};
+    mv_put_planes(v, v.c >> 2, i, x0);
+    const float x1[4] = {pe0[1][i][0], pe0[1][i][1], pe0[1][i][2], pe0[1][i][3]};
+    if (v.c < 4) mv_put_planes(v, 2, i, x1);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+  // NOTE: after this point the V wave executes exactly one s_barrier per 16-k step of the M waves.
+
+  vf4 vacc[8][4];
+  float act[4][4];
+  float sacc[4] = {0.f, 0.f, 0.f, 0.f};
+  int nblk = 0;
+  int gs = 0;   // ring slot of the current product's step 0 planes (global step mod MV_PLN)
+  auto vbar = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  // (register-only work is free to move across the barrier's asm statement: hipcc merged the two halves of a block's task
+  // into one window; what a window computes is pinned to it by passing its inputs through an asm statement behind the barrier)
+  auto pin = [&](vf4& x) __attribute__((always_inline)) { asm volatile("" : "+v"(x)); };
+  auto pin_act = [&](int i) __attribute__((always_inline)) { asm volatile("" : "+v"(act[i][0]), "+v"(act[i][1]), "+v"(act[i][2]), "+v"(act[i][3])); };
+  auto epi = [&](int l) __attribute__((always_inline)) {
+    MvEpi e;
+    e.bias = Bsh + l * FH + 4 * v.c;
+    e.ws = (l + 1 == g.nh) ? Bsh + g.nh * FH + 4 * v.c : nullptr;
+    e.a = SAVE ? g.a[l] + 4 * v.c : nullptr;
+    e.D = SAVE ? g.D[l] + 4 * v.c : nullptr;
+    e.n_real = g.n_real[l];
+    e.pe_tail = (l + 1 == g.skip);
+    return e;
+  };
+  // the whole task of block j (both halves) + its planes into steps 2 j, 2 j + 1 of the NEXT product (first step slot nslot0)
+  auto task_planes = [&](int j, int nslot0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mv_put_planes(v, (nslot0 + 2 * j + (v.c >> 2)) % MV_PLN, i, act[i]);
+  };
+
+  // ---- product 0 (layer 0, 4 steps) -----------------------------------------------------------------------------
+  vbar();   // B(0)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {   // planes of step 3 into slot 0 (the M wave took step 0's before its first MFMA)
+    const float x1[4] = {pe0[1][i][0], pe0[1][i][1], pe0[1][i][2], pe0[1][i][3]};
+    if (v.c >= 4) mv_put_planes(v, 0, i, x1);
+  }
+  vbar();   // B(1)
+  vbar();   // B(2)
+  vbar();   // B(3): the M wave's last step of layer 0
+
+  for (int pi = 0; pi < nprod; ++pi) {
+    // ---- window of product pi's last step: drain its 8 blocks; block 0's task is on the M wave's critical path -------
+    const int nks = pi == 0 ? 4 : 16;
+    const int nslot0 = (gs + nks) % MV_PLN;       // ring slot of the next product's step 0
+    const bool hidden = pi < g.nh;
+    MvEpi e = epi(hidden ? pi : 0);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) mv_v_drain(v, pr, nblk, vacc[b], lane);   // (nothing else meanwhile: the M wave hands a block over every ~230 clocks)
+    if (hidden && pi + 1 < nprod) {
+      // block 0: the M wave makes the planes of step 0' itself; step 1' (this block's features 16..31: lanes c >= 4) is due
+      // when the M wave reaches block 5 of step 0'
+      mv_v_act<SAVE, 2>(v, e, 0, 0, vacc[0], sk, act, sacc);
+      mv_v_act<SAVE, 2>(v, e, 0, 2, vacc[0], sk, act, sacc);
+      if (v.c >= 4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) mv_put_planes(v, (nslot0 + 1) % MV_PLN, i, act[i]);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      mv_signal(pr.sync + 2, pi + 1, lane);
+    }
+    gs = nslot0;
+    if (pi + 1 >= nprod) {
+      // ---- nothing follows: the exposed tail ---------------------------------------------------------------
+      if (hidden) {   // the last hidden layer's activations: saved state and sdf head only
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          mv_v_act<SAVE, 2>(v, e, j, 0, vacc[j], sk, act, sacc);
+          mv_v_act<SAVE, 2>(v, e, j, 2, vacc[j], sk, act, sacc);
+        }
+      } else {        // feature head: rows 1.. of the output layer into the albedo network's input
+        const float* bf = g.packed + g.bf_off + 4 * v.c;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const vf4 bv = *reinterpret_cast<const vf4*>(bf + 32 * j);
+          if (32 * j + 4 * v.c < g.F) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              __builtin_nontemporal_store(vacc[j][i] + bv, reinterpret_cast<vf4*>(g.cin + v.row[i] * g.Cinp + 32 * j + 4 * v.c));
+          }
+        }
+      }
+      break;
+    }
+    // ---- the next product's 16 windows: tasks of blocks 1..7 (block j's planes are written in window 2 j - 2) --------
+    vbar();   // B(0')
+    mv_v_act<SAVE, 2>(v, e, 1, 0, vacc[1], sk, act, sacc);
+    mv_v_act<SAVE, 2>(v, e, 1, 2, vacc[1], sk, act, sacc);
+    task_planes(1, nslot0);
+#pragma unroll
+    for (int j = 2; j < 8; ++j) {
+      vbar();   // window 2 j - 3
+      pin(vacc[j][0]); pin(vacc[j][1]);
+      mv_v_act<SAVE, 2>(v, e, j, 0, vacc[j], sk, act, sacc);
+      pin_act(0); pin_act(1);
+      vbar();   // window 2 j - 2
+      pin(vacc[j][2]); pin(vacc[j][3]);
+      mv_v_act<SAVE, 2>(v, e, j, 2, vacc[j], sk, act, sacc);
+      task_planes(j, nslot0);
+    }
+    vbar();   // window 13
+    vbar();   // window 14
+    vbar();   // window 15: the next product's last step
+  }
+  // ---- sdf head: row 0 of the output layer (models/fields.py:104, :106-108); its dot product rode in the tasks ----
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float s = sacc[i];
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    if (v.c == 0) {
+      const float val = (s + g.packed[g.bsdf_off]) / g.scale;
+      if (!g.grid.on) g.sdf[v.row[i]] = val;
+      else if (v.row[i] < g.M) g.sdf[v.row[i]] = val * g.grid.out_scale;   // the volume has exactly M entries
+    }
+  }
+}
+
+bool sweep_mv_supported(const Layout& L) {
+  if (!is_x3(L) || !fused_supported(L)) return false;
+  if (L.Ep != 64 || L.hid[0].Kp != 64) return false;
+  if (L.nh < 2 || L.nh > MV_MAXB) return false;
+  for (int l = 0; l < L.nh; ++l)
+    if (L.hid[l].N < 192) return false;   // (the skip-connection columns live in the last two 32-feature blocks)
+  if (L.F > 0 && (L.feat.Np != FH || L.feat.Kp != FH || (L.F & 3))) return false;
+  return true;
+}
+
+int sweep_mv_forward(const Layout& L, const float* packed, const float* pts, int64_t M, PointBufs& pb, bool save,
+                     bool need_feat, bool need_gz_last, hipStream_t s, const GridGen* grid) {
+  if (need_gz_last) RNB_FAIL(RNB_E_INVALID, "M/V forward: the fused reverse sweep seeds itself (no gz_last)");
+  MvFwdArgs ga;
+  memset(&ga, 0, sizeof(ga));
+  FusedFwdArgs& g = ga.f;
+  if (grid) g.grid = *grid;
+  g.pts = pts;
+  g.M = M;
+  g.packed = packed;
+  g.w3 = reinterpret_cast<const x3raw*>(packed + L.total);
+  g.nh = L.nh;
+  g.skip = L.skip;
+  g.pe = L.pe;
+  g.multires = L.multires;
+  g.Ep = L.Ep;
+  g.scale = L.sdf_scale;
+  for (int l = 0; l < L.nh; ++l) {
+    g.n_real[l] = L.hid[l].N;
+    g.Kp[l] = L.hid[l].Kp;
+    g.w_off[l] = L.hid[l].w_off;
+    g.b_off[l] = L.hid[l].b_off;
+    g.a[l] = pb.a[l];
+    g.D[l] = pb.D[l];
+    ga.st.nks[l] = L.hid[l].Kp / 16;
+    ga.st.boff[l] = (unsigned)(6 * L.hid[l].w_off);
+  }
+  ga.st.nmat = L.nh;
+  if (need_feat) {
+    ga.st.nks[L.nh] = L.feat.Kp / 16;
+    ga.st.boff[L.nh] = (unsigned)(6 * L.feat.w_off);
+    ga.st.nmat = L.nh + 1;
+  }
+  g.wsdf_off = L.wsdf_off;
+  g.bsdf_off = L.bsdf_off;
+  g.with_feat = need_feat ? 1 : 0;
+  g.F = L.F;
+  g.Cinp = L.Cinp;
+  g.wf_off = L.feat.w_off;
+  g.bf_off = L.feat.b_off;
+  g.cin = pb.cin;
+  g.sdf = pb.sdf;
+  g.x4 = pb.x;
+  g.e = pb.e;
+  double fl = 0;
+  for (int l = 0; l < L.nh; ++l) fl += 2.0 * (double)M * L.hid[l].N * L.hid[l].K;
+  fl += 2.0 * (double)M * L.H;
+  if (need_feat) fl += 2.0 * (double)M * L.F * L.H;
+  ProfScope prof(fl, s, save ? "F_sweep(save)" : "F_sweep(forward_only)");
+  const unsigned blocks = (unsigned)(pb.Mp / MV_PT);   // (Mp is a multiple of 128)
+  if (save) hipLaunchKernelGGL((sweep_mv_forward_kernel<true>), dim3(blocks), dim3(128 * MV_MW), 0, s, ga);
+  else hipLaunchKernelGGL((sweep_mv_forward_kernel<false>), dim3(blocks), dim3(128 * MV_MW), 0, s, ga);
+  RNB_CHECK_LAUNCH();
+  return RNB_OK;
+}
+
+}  // namespace rnb

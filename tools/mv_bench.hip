@@ -1,5 +1,5 @@
-// Stand-alone timing of the register-tile forward sweep (development aid; not part of the library).
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DRNB_T_STAMP tools/t_bench.hip -o tools/t_bench && tools/t_bench [points] [save]
+// Stand-alone timing of the M/V forward sweep (development aid; not part of the library).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -DRNB_MV_STAMP tools/mv_bench.hip -o tools/mv_bench && tools/mv_bench [points] [save]
 // Random weights (mirror filled with random bf16 planes: timing only), random points.  Prints the launch time, the
 // matrix-pipe share it implies at 2.4 GHz and, from s_memtime stamps of wave 0 of every workgroup, where a tile's clocks
 // go: prologue / matrix loop / epilogue per layer, and the clock the chip held (s_memrealtime).
@@ -9,7 +9,7 @@
 
 #include <vector>
 
-#include "../rnb-neus-fork_amd/csrc/fused_t.hip"
+#include "../rnb-neus-fork_amd/csrc/sweep_mv.hip"
 
 using namespace rnb;
 
@@ -62,11 +62,11 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&pts, hpts.size() * 4));
   CK(hipMemcpy(pts, hpts.data(), hpts.size() * 4, hipMemcpyHostToDevice));
   CK(hipMalloc(&sdf, (size_t)M * 4));
-  const unsigned blocks = (unsigned)(M / TPT);
+  const unsigned blocks = (unsigned)(M / MV_PT);
   unsigned long long* stamps;
   CK(hipMalloc(&stamps, (size_t)blocks * 64 * 8));
   CK(hipMemset(stamps, 0, (size_t)blocks * 64 * 8));
-  TFwdArgs ga;
+  MvFwdArgs ga;
   memset(&ga, 0, sizeof(ga));
   FusedFwdArgs& g = ga.f;
   g.pts = pts; g.M = M; g.packed = packed;
@@ -89,12 +89,16 @@ int main(int argc, char** argv) {
   g.wsdf_off = wsdf; g.bsdf_off = bsdf;
   g.sdf = sdf; g.x4 = x4; g.e = ebuf;
   ga.stamps = stamps;
+  int* errw;
+  CK(hipMalloc(&errw, 4));
+  CK(hipMemset(errw, 0, 4));
+  ga.err = errw;
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
   auto launch = [&]() {
-    if (save) hipLaunchKernelGGL((fused_forward_t_kernel<true>), dim3(blocks), dim3(T_LAUNCH_THREADS), 0, 0, ga);
-    else hipLaunchKernelGGL((fused_forward_t_kernel<false>), dim3(blocks), dim3(T_LAUNCH_THREADS), 0, 0, ga);
+    if (save) hipLaunchKernelGGL((sweep_mv_forward_kernel<true>), dim3(blocks), dim3(128 * MV_MW), 0, 0, ga);
+    else hipLaunchKernelGGL((sweep_mv_forward_kernel<false>), dim3(blocks), dim3(128 * MV_MW), 0, 0, ga);
   };
   for (int it = 0; it < 3; ++it) launch();
   CK(hipDeviceSynchronize());
@@ -105,12 +109,13 @@ int main(int argc, char** argv) {
   CK(hipDeviceSynchronize());
   float ms;
   CK(hipEventElapsedTime(&ms, e0, e1));
+  { int eh = 0; CK(hipMemcpy(&eh, errw, 4, hipMemcpyDeviceToHost)); if (eh) printf("!! a bounded wait gave up (error word set)\n"); }
   ms /= iters;
   // MFMAs per wave: (4 + 7 * 16) steps x 48; one wave per SIMD; tiles per CU = blocks / 256
   const double mfma_clk = (4 + 7 * 16) * 48 * 32.0 * blocks / 256.0;
-  printf("fused_forward_t_kernel<%s>: %lld points: %.3f ms;  matrix pipe %.1f %% at 2.4 GHz;  %.1f TFLOP/s algorithmic\n", save ? "save" : "fwd",
+  printf("sweep_mv_forward_kernel<%s>: %lld points: %.3f ms;  matrix pipe %.1f %% at 2.4 GHz;  %.1f TFLOP/s algorithmic\n", save ? "save" : "fwd",
          (long long)M, ms, 100.0 * mfma_clk / (ms * 1e-3 * 2.4e9), 1.049e6 * M / (ms * 1e-3) / 1e12);
-#ifdef RNB_T_STAMP
+#ifdef RNB_MV_STAMP
   std::vector<unsigned long long> st((size_t)blocks * 64);
   CK(hipMemcpy(st.data(), stamps, st.size() * 8, hipMemcpyDeviceToHost));
   double pro = 0, prod[16] = {0}, all = 0, real = 0, tail = 0;
@@ -124,8 +129,17 @@ int main(int argc, char** argv) {
   }
   printf("per tile (wave 0, shader clocks): prologue %.0f | tail %.0f | whole tile %.0f clocks = %.2f us => %.2f GHz\n", pro / blocks,
          tail / blocks, all / blocks, real / blocks / 100.0, all / real / 10.0);
-  for (int l = 0; l < nh; ++l)
-    printf("  product %d: %.0f clocks (matrix work %d)\n", l, prod[l] / blocks, (l == 0 ? 4 : 16) * 48 * 32);
+  for (int l = 0; l < nh; ++l) {
+    double a = 0, b = 0, c = 0;
+    if (l >= 1)
+      for (unsigned bb = 0; bb < blocks; ++bb) {
+        const unsigned long long* s = &st[(size_t)bb * 64 + 8 + 4 * l];
+        a += (double)(s[1] - s[0]); b += (double)(s[2] - s[1]);
+        c += (double)(s[0] - st[(size_t)bb * 64 + 8 + 4 * (l - 1) + 2]);
+      }
+    printf("  product %d: %.0f clocks (matrix work %d) | steps 0..14 %.0f  last step + hand-over %.0f  wait for first planes %.0f\n", l, prod[l] / blocks,
+           (l == 0 ? 4 : 16) * 48 * 32, a / blocks, b / blocks, l >= 2 ? c / blocks : 0.0);
+  }
 #endif
   return 0;
 }

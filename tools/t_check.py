@@ -42,6 +42,8 @@ def main():
         print(f"{tag}: sdf-only vs with-feature max diff {float((o1 - outs[tag][:, :1]).abs().max()):.3e}")
     d = (outs["reg"] - outs["lds"]).abs()
     print(f"reg vs lds: sdf {float(d[:, 0].max()):.3e} feat {float(d[:, 1:].max()):.3e}")
+    if len(sys.argv) > 2 and sys.argv[2] == "notime":
+        return
     # timing: forward-only sweep over 1M points
     big = (torch.rand(1 << 20, 3, device=dev) * 2 - 1) * 0.9
     for tag, kw in (("lds", dict(lds_tile=True)), ("reg", dict(reg_tile=True)), ("lds", dict(lds_tile=True)), ("reg", dict(reg_tile=True))):
