@@ -38,18 +38,23 @@ HBM_PEAK_GBS = 8000.0           # same guide, "HBM3E peak BW 8.0 TB/s spec"
 PROFILES = os.path.join(ROOT, "profiles")
 
 
-def measured_traffic(name, n_gpus, rays, samples):
+def measured_traffic(name, n_gpus, rays, samples, build_id):
     """HBM bytes per MFMA-family launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
     see profiles/README.md).  PMC collection needs its own rocprofv3 runs, so bench.py reports the stored
-    measurement of the same workload and null for any other shape."""
+    measurement — only for the same workload AND the same build of the library: the profile carries the `build_id`
+    (rnb_build_id(): hash of csrc/ + flags) of the library it was collected with, and bytes measured on other kernels are
+    not quoted.  Returns (profile or None, note or None)."""
     try:
         with open(os.path.join(PROFILES, name)) as f:
             t = json.load(f)
-        if n_gpus == 1 and rays == t.get("rays", 512) and samples == t.get("samples", 128):
-            return t
     except Exception:
-        pass
-    return None
+        return None, f"profiles/{name}: not found"
+    if not (n_gpus == 1 and rays == t.get("rays", 512) and samples == t.get("samples", 128)):
+        return None, f"profiles/{name} holds another workload"
+    if t.get("build_id") != build_id:
+        return None, (f"profiles/{name} was collected on build {t.get('build_id', '(none recorded)')}, this library is "
+                      f"{build_id}: stored bytes not quoted")
+    return t, None
 
 
 # kernel class tag (rnb_profile_report) -> substring of the kernel names whose PMC traffic belongs to it
@@ -124,6 +129,12 @@ def parse():
     ap.add_argument("--bwd-ti", type=int, default=0, help="A/B knob: tile rows per wave of the backward sweeps (1 | 2)")
     ap.add_argument("--fwd-nw", type=int, default=0, help="A/B knob: waves per workgroup of the forward sweep (4 | 8)")
     ap.add_argument("--bwd-nw", type=int, default=0, help="A/B knob: waves per workgroup of the backward sweeps (4 | 8)")
+    ap.add_argument("--reg-tile", action="store_true", help="A/B knob: M/V kernels for the large forward-only sweeps (RNB_VARIANT_REG_TILE)")
+    ap.add_argument("--lds-tile", action="store_true", help="A/B knob: force the LDS-tile sweep kernels (RNB_VARIANT_LDS_TILE)")
+    ap.add_argument("--no-also", action="store_true",
+                    help="skip the short extra legs (no-albedo, bf16 x 256 samples, render, fp32 MFMA) that the default "
+                         "--gpus 1 train run appends under `also`")
+    ap.add_argument("--also-steps", type=int, default=20, help="timed steps of each `also` leg")
     ap.add_argument("--torch-train-ops", action="store_true",
                     help="loss as the reference's chain of torch ops and torch.optim.Adam(fused=True) instead of "
                          "the library's one-launch loss and flat Adam")
@@ -295,6 +306,12 @@ def init_distributed(args):
             raise RuntimeError(f"process group has {dist.get_world_size()} ranks, expected {world}")
     if args.gpus != world and rank == 0:
         print(f"[bench] --gpus {args.gpus} but WORLD_SIZE {world}: using {world}", file=sys.stderr)
+    # a box with a device per rank must give an RCCL measurement: anything else (RNB_SHARE_GPU / RNB_DIST_BACKEND forced by
+    # the environment) would print a rehearsal line where a scaling point is expected — refuse instead
+    if world > 1 and torch.cuda.device_count() >= world and (rehearsal or backend != "nccl") and not os.environ.get("RNB_ALLOW_REHEARSAL"):
+        raise SystemExit(f"[bench] {torch.cuda.device_count()} devices for {world} ranks, but the ranks would not talk RCCL "
+                         f"(backend {backend}, shared device {rehearsal}): not a scaling measurement "
+                         "(set RNB_ALLOW_REHEARSAL=1 to run the functional rehearsal anyway)")
     return world, rank, dev, backend, rehearsal
 
 
@@ -343,7 +360,8 @@ def synthetic_capture(R, dev, n_views, H, W, n_lights=3):
     return R.DeviceRays(images, None, masks, lights, lw, Kinv, pose, dev)
 
 
-def build_model(R, dev, samples, dtype, deterministic, fwd_ti=0, bwd_ti=0, dw_staged=False, x3=False, fwd_nw=0, bwd_nw=0, f32_mfma=False):
+def build_model(R, dev, samples, dtype, deterministic, fwd_ti=0, bwd_ti=0, dw_staged=False, x3=False, fwd_nw=0, bwd_nw=0, f32_mfma=False,
+                reg_tile=False, lds_tile=False):
     import torch
     # confs/wmask_rnb.conf:53-90, constructed in the order of exp_runner.py:95-100 under seed 0
     torch.manual_seed(0)
@@ -355,14 +373,16 @@ def build_model(R, dev, samples, dtype, deterministic, fwd_ti=0, bwd_ti=0, dw_st
     ren = R.NeuSRenderer(None, sdf, devnet, col, n_samples=samples // 2, n_importance=samples // 2, n_outside=0,
                          up_sample_steps=4, perturb=1.0)
     ren.set_variant(bf16=(dtype == "bf16"), deterministic=deterministic, fwd_ti=fwd_ti, bwd_ti=bwd_ti, dw_staged=dw_staged, x3=x3,
-                    fwd_nw=fwd_nw, bwd_nw=bwd_nw, f32_mfma=f32_mfma)
+                    fwd_nw=fwd_nw, bwd_nw=bwd_nw, f32_mfma=f32_mfma, reg_tile=reg_tile, lds_tile=lds_tile)
     return sdf, devnet, col, ren
 
 
-def run_train(args):
+def measure_train(args, ctx, with_cpu=True):
+    """One measurement of `args` on the process group `ctx` (init_distributed): warm-up, K timed steps, the line as a dict on
+    rank 0 (None elsewhere).  Emits nothing and leaves the process group alone."""
     import torch
     import torch.distributed as dist
-    world, rank, dev, backend, rehearsal = init_distributed(args)
+    world, rank, dev, backend, rehearsal = ctx
 
     # the measured leg uses the product only (package + librnbneus_hip.so); oracle/ is touched by
     # cpu_baseline() alone
@@ -373,7 +393,7 @@ def run_train(args):
 
     S = args.samples
     sdf, devnet, col, ren = build_model(R, dev, S, args.dtype, args.deterministic, args.fwd_ti, args.bwd_ti, args.dw_staged, args.x3,
-                                        args.fwd_nw, args.bwd_nw, args.f32_mfma)
+                                        args.fwd_nw, args.bwd_nw, args.f32_mfma, args.reg_tile, args.lds_tile)
     exact_dp = not args.torch_train_ops     # the reference's torch-op loss knows nothing about shards
     if world > 1:
         P.broadcast_parameters([sdf, devnet, col])
@@ -505,7 +525,8 @@ def run_train(args):
         roof = None
         traffic_file = ("hbm_traffic_bf16.json" if bf16 else
                         ("r02_hbm_traffic_f32_mfma.json" if args.f32_mfma else "hbm_traffic.json"))
-        tr = None if (forward_only or capture is not None) else measured_traffic(traffic_file, world, B, S)
+        bid = R.native.build_id()
+        tr, tr_note = (None, None) if (forward_only or capture is not None) else measured_traffic(traffic_file, world, B, S, bid)
         if use_events and gemm_n.value > 0:
             ach = gemm_fl.value / (gemm_ms.value * 1e-3) / 1e12
             step_tf = tf.value / (ms_per_step * 1e-3) / 1e12
@@ -528,6 +549,7 @@ def run_train(args):
                         "frac_of_fp32_mfma_peak": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
                         "traffic": round(tr["hbm_bytes_per_launch"]) if tr else None,
                         "traffic_unit": "HBM bytes per launch",
+                        "traffic_note": tr_note,
                         "traffic_detail": ({"hbm_bytes_per_step": round(tr["hbm_bytes_per_step"]),
                                             "launches_per_step": tr["launches_per_step"],
                                             "source": "profiles/" + traffic_file} if tr else None),
@@ -561,6 +583,7 @@ def run_train(args):
                         "frac": round(gbs / HBM_PEAK_GBS, 4) if gbs else None,
                         "traffic": round(tr["hbm_bytes_per_launch"]) if tr else None,
                         "traffic_unit": "HBM bytes per launch",
+                        "traffic_note": tr_note,
                         "algorithmic_bytes_per_step": alg,
                         "kernel": "bf16-MFMA family: bf_forward/reverse/ra/fb_kernel, bf_color_fwd/bwd_kernel, bf_dw_kernel",
                         "mfma_tflops": round(ach, 2), "mfma_frac_of_bf16_peak": round(ach / BF16_MFMA_PEAK_TFLOPS, 4),
@@ -570,7 +593,7 @@ def run_train(args):
                 if by:
                     roof["by_kernel_class"] = by
         cpu = None
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and with_cpu:
             cpu = (cpu_baseline_render(B, S, args.cpu_steps) if forward_only else
                    cpu_baseline(B, S, args.cpu_steps, args.warmup_mode, args.no_albedo))
         line = {
@@ -580,7 +603,16 @@ def run_train(args):
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "ms_per_step_median": round(median_ms, 3), "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            # `dtype` is the type of the results and of everything stored; the products themselves:
+            "arithmetic": ("bf16 operands, fp32 accumulate (v_mfma_f32_32x32x16_bf16); masters, gradients, epilogues fp32" if bf16 else
+                           ("fp32 MFMA (v_mfma_f32_32x32x2_f32)" if args.f32_mfma else
+                            "x3: every fp32 operand as 3 bf16 terms (hi + mid + lo = x exactly), 6 of the 9 cross terms per product "
+                            "on v_mfma_f32_32x32x16_bf16, fp32 accumulate; dropped terms < 2^-26 |ab|")),
+            "build_id": bid,
             "rccl_ranks": world if backend == "nccl" else (1 if world == 1 else 0),
+            # the flat gradient buffer is all-reduced after the backward sweeps have finished (renderer.py: one all_reduce on
+            # the compute stream): nothing overlaps it — 2.7 MB, latency-bound on xGMI
+            "grad_allreduce_overlap": (False if world > 1 else None),
             "config": {"workload": "DiLiGenT-MV-shaped synthetic rays, wmask_rnb.conf networks (8x256 SDF MLP + "
                                    "2x256 albedo MLP), train_rnb step "
                                    f"({'render_rnb_warmup' if args.warmup_mode else 'render_rnb'}), "
@@ -616,6 +648,53 @@ def run_train(args):
                                       "scaling measurement")
         if cpu:
             line["gpu_over_cpu"] = round(value / cpu["value"], 1)
+        return line
+    return None
+
+
+# the configurations the default --gpus 1 run measures beside the headline: BASELINE configs 3 and 5
+# (1-GPU legs), the forward-only render, and the native-fp32-MFMA arithmetic — short passes, in this process, under `also`
+ALSO_LEGS = (
+    ("config 3: wmask_rnb_noalbedo.conf (normal-only loss path)", dict(no_albedo=True)),
+    ("config 5 (1-GPU leg): bf16 sweeps, 256 samples per ray", dict(dtype="bf16", samples=256)),
+    ("NeuSRenderer.render, forward only (no_grad)", dict(mode="render")),
+    ("A/B: native fp32 MFMA arithmetic (RNB_VARIANT_F32_MFMA)", dict(f32_mfma=True)),
+)
+
+
+def run_train(args):
+    import copy
+    import torch.distributed as dist
+    ctx = init_distributed(args)
+    world, rank = ctx[0], ctx[1]
+    line = measure_train(args, ctx, with_cpu=False)
+    plain = (world == 1 and args.mode == "train" and not args.no_also and not args.device_rays and not args.no_albedo
+             and args.dtype == "f32" and not args.f32_mfma and not args.warmup_mode and args.rays == 512 and args.samples == 128)
+    if plain:
+        also = []
+        for name, kw in ALSO_LEGS:
+            la = copy.copy(args)
+            for k, v in kw.items():
+                setattr(la, k, v)
+            la.steps, la.warmup = args.also_steps, 5
+            l = measure_train(la, ctx, with_cpu=False)
+            r = l.get("roofline") or {}
+            also.append({"leg": name, "metric": l["metric"], "value": l["value"], "unit": l["unit"], "ms_per_step": l["ms_per_step"],
+                         "steps": l["steps"], "warmup": l["warmup"], "dtype": l["dtype"], "arithmetic": l["arithmetic"],
+                         "config": {"workload": l["config"]["workload"], "no_albedo": l["config"]["no_albedo"],
+                                    "samples_per_ray": l["config"]["samples_per_ray"]},
+                         "roofline": {"bound": r.get("bound"), "frac": r.get("frac"), "achieved": r.get("achieved"),
+                                      "peak": r.get("peak"), "unit": r.get("unit"), "step_frac": r.get("step_frac")}})
+            print(f"[bench] also: {name}: {l['value']:.0f} {l['unit']}, {l['ms_per_step']} ms/step", file=sys.stderr, flush=True)
+        line["also"] = also
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            forward_only = args.mode == "render"
+            B = args.rays if args.scaling == "weak" else args.global_rays // world
+            cpu = (cpu_baseline_render(B, args.samples, args.cpu_steps) if forward_only else
+                   cpu_baseline(B, args.samples, args.cpu_steps, args.warmup_mode, args.no_albedo))
+            line["cpu_baseline"] = cpu
+            line["gpu_over_cpu"] = round(line["value"] / cpu["value"], 1)
         emit(line)
     if world > 1:
         dist.barrier()
@@ -631,7 +710,7 @@ def run_mesh(args):
     import rnb_neus_fork_amd as R
     lib = R.native.load()
     sdf, devnet, col, ren = build_model(R, dev, 128, args.dtype, False, x3=args.x3, f32_mfma=args.f32_mfma, fwd_ti=args.fwd_ti,
-                                        fwd_nw=args.fwd_nw)
+                                        fwd_nw=args.fwd_nw, reg_tile=args.reg_tile, lds_tile=args.lds_tile)
     if world > 1:
         from rnb_neus_fork_amd import parallel as P
         P.broadcast_parameters([sdf, devnet, col])

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RNB_ABI_VERSION 3
+#define RNB_ABI_VERSION 4
 #define RNB_MAX_LIN 16 /* linear layers per MLP */
 
 enum {
@@ -134,6 +134,10 @@ typedef struct rnb_mlp_grads { /* same shapes as rnb_mlp_params, written (not ac
 } rnb_mlp_grads;
 
 int rnb_abi_version(void);
+/* Identity of this build of the library: 16 hex digits hashed from every source file and the compiler flags
+ * (rnb-neus-fork_amd/buildid.py), or "unknown" for a library built without the project's build script.  Profiles and
+ * bench lines carry it, so that stored measurements are only quoted for the build they were taken on.  [ABI 4] */
+const char* rnb_build_id(void);
 const char* rnb_last_error_string(void);
 
 /* ---- weight norm ------------------------------------------------------------------------------

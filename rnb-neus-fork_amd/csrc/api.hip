@@ -10,7 +10,15 @@ using namespace rnb;
 #define RNB_REQUIRE(p, name) \
   if (!(p)) RNB_FAIL(RNB_E_NULL, name " is NULL")
 
+#if __has_include("../build/build_id.h")
+#include "../build/build_id.h"   // written by __graft_entry__.build_native: hash of csrc/, include/ and the compiler flags
+#endif
+#ifndef RNB_BUILD_ID
+#define RNB_BUILD_ID "unknown"
+#endif
+
 RNB_API int rnb_abi_version(void) { return RNB_ABI_VERSION; }
+RNB_API const char* rnb_build_id(void) { return RNB_BUILD_ID; }
 RNB_API const char* rnb_last_error_string(void) { return rnb::last_error(); }
 
 RNB_API int rnb_packed_floats(const rnb_model_desc* desc, int64_t* n_floats) {

@@ -270,7 +270,7 @@ bool fused_supported(const Layout& L) {
 // Fused replacement of launch_pe_points + sweep_forward (same outputs; pb.a / pb.D only when `save`).
 int fused_forward(const Layout& L, const float* packed, const float* pts, int64_t M, PointBufs& pb, bool save,
                   bool need_feat, bool need_gz_last, hipStream_t s, const GridGen* grid) {
-  if (use_reg_tile(L, pb.Mp)) return sweep_mv_forward(L, packed, pts, M, pb, save, need_feat, need_gz_last, s, grid);
+  if (!save && use_reg_tile(L, pb.Mp)) return sweep_mv_forward(L, packed, pts, M, pb, save, need_feat, need_gz_last, s, grid);
   FusedFwdArgs g;
   memset(&g, 0, sizeof(g));
   if (grid) g.grid = *grid;

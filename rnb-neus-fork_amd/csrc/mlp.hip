@@ -717,8 +717,11 @@ struct DwBatch {
   int64_t part_left;
   float* slab;        // slabs of the staged 256 x 256 kernel (always; the tail of the same workspace)
   int64_t slab_left;
-  DwBatch(int64_t M_, hipStream_t s_, bool lds_path_, float* part_, int64_t part_floats, float* slab_, int64_t slab_floats)
-      : M(M_), s(s_), lds_path(lds_path_), part(part_), part_left(part_floats), slab(slab_), slab_left(slab_floats) {
+  float* const slab_base;         // the slab workspace as handed in: every flushed group starts from it again
+  const int64_t slab_floats;
+  DwBatch(int64_t M_, hipStream_t s_, bool lds_path_, float* part_, int64_t part_floats, float* slab_, int64_t slab_floats_)
+      : M(M_), s(s_), lds_path(lds_path_), part(part_), part_left(part_floats), slab(slab_), slab_left(slab_floats_),
+        slab_base(slab_), slab_floats(slab_floats_) {
     for (int v = 0; v < 4; ++v) { grp[v].njobs = 0; grp[v].M = (int)M_; flops[v] = 0.0; }
   }
   // the staged kernel: every job of the group is split the same way, decided when the group is complete
@@ -769,6 +772,11 @@ struct DwBatch {
     }
     g.njobs = 0;
     flops[3] = 0.0;
+    // the reduction above has read every slab of this group and the next group's kernels follow it on the same
+    // stream: the workspace (sized for ONE group of kMaxDwJobs, dw_slab_floats) is free again.  Without this a model
+    // with more 256-wide gradient jobs than one group holds ran out of slabs on its second group.
+    slab = slab_base;
+    slab_left = slab_floats;
     RNB_CHECK_LAUNCH();
     return RNB_OK;
   }

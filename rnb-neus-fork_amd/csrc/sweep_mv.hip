@@ -707,6 +707,8 @@ bool sweep_mv_supported(const Layout& L) {
 int sweep_mv_forward(const Layout& L, const float* packed, const float* pts, int64_t M, PointBufs& pb, bool save,
                      bool need_feat, bool need_gz_last, hipStream_t s, const GridGen* grid) {
   if (need_gz_last) RNB_FAIL(RNB_E_INVALID, "M/V forward: the fused reverse sweep seeds itself (no gz_last)");
+  // (the saved-state form exists and is correct, but its vector waves spill — round 4 state, DESIGN 4 — and it is not wired in)
+  if (save) RNB_FAIL(RNB_E_INVALID, "M/V forward: forward-only sweeps only");
   MvFwdArgs ga;
   memset(&ga, 0, sizeof(ga));
   FusedFwdArgs& g = ga.f;

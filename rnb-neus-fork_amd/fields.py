@@ -45,6 +45,20 @@ class _WNLinear(nn.Module):
         return [self.weight, self.bias]
 
 
+def _forward_only_guard(module: nn.Module, what: str, *inputs):
+    """The direct network calls run the native forward sweeps and return tensors WITHOUT a grad_fn; the reference's are
+    ordinary autograd modules (models/fields.py:82-127, :177-215; `gradient` even builds a graph, create_graph=True).  A loss
+    written on them would train nothing without being told — so under grad mode with anything trainable in sight the call
+    fails loudly instead of detaching silently."""
+    if not torch.is_grad_enabled():
+        return
+    if any(p.requires_grad for p in module.parameters()) or any(torch.is_tensor(t) and t.requires_grad for t in inputs):
+        raise RuntimeError(
+            f"{what} is forward-only in rnb_neus_fork_amd: it returns a tensor without grad_fn, so gradients would silently "
+            "not flow.  Training gradients flow through NeuSRenderer.render / render_rnb / render_rnb_warmup (whose backward is "
+            "native); for evaluation wrap the call in torch.no_grad() (or freeze the parameters with requires_grad_(False)).")
+
+
 def _mlp_struct(lins, weight_norm, grads=None):
     """rnb_mlp_params / rnb_mlp_grads for a list of _WNLinear (grads: dict leaf -> tensor)."""
     s = native.MlpParams()
@@ -128,14 +142,16 @@ class SDFNetwork(nn.Module):
         from .runtime import StandaloneSDF
         return StandaloneSDF(self)
 
-    # -- reference API (forward only; training gradients flow through NeuSRenderer.render*) -----------
+    # -- reference API (forward only, and loud about it; training gradients flow through NeuSRenderer.render*) -----------
     def forward(self, inputs):
-        """[N,3] -> [N,d_out] = [sdf, feature]  (models/fields.py:82-104)."""
+        """[N,3] -> [N,d_out] = [sdf, feature]  (models/fields.py:82-104).  Forward only: raises under grad mode."""
+        _forward_only_guard(self, "SDFNetwork.forward", inputs)
         ctx = self._standalone()
         return ctx.sdf_forward(inputs, with_feature=True)
 
     def sdf(self, x):
-        """[N,3] -> [N,1]  (models/fields.py:106-108)."""
+        """[N,3] -> [N,1]  (models/fields.py:106-108).  Forward only: raises under grad mode."""
+        _forward_only_guard(self, "SDFNetwork.sdf", x)
         ctx = self._standalone()
         return ctx.sdf_forward(x, with_feature=False)
 
@@ -143,7 +159,9 @@ class SDFNetwork(nn.Module):
         return self.forward(x)
 
     def gradient(self, x):
-        """[N,3] -> [N,1,3] = d sdf / d x  (models/fields.py:114-127), analytic reverse sweep."""
+        """[N,3] -> [N,1,3] = d sdf / d x  (models/fields.py:114-127), analytic reverse sweep.  Forward only (the
+        reference returns a differentiable graph, create_graph=True): raises under grad mode."""
+        _forward_only_guard(self, "SDFNetwork.gradient", x)
         ctx = self._standalone()
         return ctx.sdf_gradient(x).unsqueeze(1)
 
@@ -181,7 +199,9 @@ class RenderingNetwork(nn.Module):
         return out
 
     def forward(self, points, normals, view_dirs, feature_vectors):
-        """models/fields.py:177-215 (view_dirs are encoded and discarded by the reference in this mode)."""
+        """models/fields.py:177-215 (view_dirs are encoded and discarded by the reference in this mode).  Forward only:
+        raises under grad mode."""
+        _forward_only_guard(self, "RenderingNetwork.forward", points, normals, feature_vectors)
         from .runtime import standalone_color
         return standalone_color(self, points, normals, feature_vectors)
 

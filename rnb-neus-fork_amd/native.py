@@ -7,7 +7,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librnbneus_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_LIN = 16
 
 MODE_CORE = 0
@@ -82,6 +82,7 @@ _P = C.POINTER
 _SIGNATURES = {
     "rnb_abi_version": (C.c_int, []),
     "rnb_last_error_string": (C.c_char_p, []),
+    "rnb_build_id": (C.c_char_p, []),
     "rnb_packed_floats": (C.c_int, [_P(ModelDesc), _P(C.c_int64)]),
     "rnb_weightnorm_fwd": (C.c_int, [_P(ModelDesc), _P(MlpParams), _P(MlpParams), C.c_void_p, C.c_void_p]),
     "rnb_weightnorm_bwd": (C.c_int, [_P(ModelDesc), _P(MlpParams), _P(MlpParams), C.c_void_p, _P(MlpGrads),
@@ -163,6 +164,11 @@ def load():
         raise NativeError(f"ABI version mismatch: library {v}, binding {ABI_VERSION}")
     _lib = lib
     return lib
+
+
+def build_id() -> str:
+    """rnb_build_id(): the hash of sources + flags this library was compiled from (buildid.source_build_id of that tree)."""
+    return load().rnb_build_id().decode()
 
 
 def check(rc: int):

@@ -62,6 +62,23 @@ def global_mask_count(mask: torch.Tensor, use_mask: bool, group=None) -> torch.T
     return cnt
 
 
+def grid_slab(resolution: int, rank: int, world_size: int):
+    """x-planes of an extract_fields grid owned by `rank`: (planes per rank, first plane, one past the last).  Every rank
+    gets ceil(res / world) planes except the last ones, which get what is left — possibly nothing (models/renderer.py:10-25
+    evaluates the grid in 64^3 blocks; here the unit is an x-slab)."""
+    per = (resolution + world_size - 1) // world_size
+    return per, min(rank * per, resolution), min((rank + 1) * per, resolution)
+
+
+def gather_grid_slabs(slab: torch.Tensor, resolution: int, group=None):
+    """All-gather of the ranks' x-slabs ([per, res, res], rows beyond a short slab zero) into the whole volume
+    [res, res, res] on every rank."""
+    world = dist.get_world_size(group)
+    full = torch.empty((world * slab.shape[0],) + tuple(slab.shape[1:]), dtype=slab.dtype, device=slab.device)
+    dist.all_gather_into_tensor(full, slab.contiguous(), group=group)
+    return full[:resolution]
+
+
 def broadcast_parameters(modules, src=0, group=None):
     for m in modules:
         for p in m.parameters():

@@ -25,14 +25,17 @@ Differences that are deliberate and documented in DESIGN.md:
 from __future__ import annotations
 
 import ctypes as C
+import logging
 
 import numpy as np
 import torch
 import torch.distributed as dist
 
-from . import native, runtime
+from . import native, parallel, runtime
 from .fields import _mlp_struct, model_desc
 from .parallel import allreduce_mean_, allreduce_sum_
+
+_MESH_BACKEND_LOGGED = False
 
 
 class ExactDPToken:
@@ -367,8 +370,7 @@ class NeuSRenderer:
         res = int(resolution)
         group = group if group is not None else self.dp_group
         rank, world = (dist.get_rank(group), dist.get_world_size(group)) if group is not None else (0, 1)
-        per = (res + world - 1) // world                  # x-planes per rank (the last slab may be shorter)
-        x0, x1 = min(rank * per, res), min((rank + 1) * per, res)
+        per, x0, x1 = parallel.grid_slab(res, rank, world)   # x-planes per rank (the last slabs may be shorter, or empty)
         gd = native.GridDesc()
         for d in range(3):
             gd.bound_min[d] = float(bound_min[d])
@@ -386,9 +388,7 @@ class NeuSRenderer:
             if x1 - x0 < per:
                 slab[x1 - x0:].zero_()
             if world > 1:
-                full = torch.empty(world * per, res, res, dtype=torch.float32, device=dev)
-                dist.all_gather_into_tensor(full, slab, group=group)
-                u = full[:res]
+                u = parallel.gather_grid_slabs(slab, res, group)
             else:
                 u = slab[:res]
         return u.cpu().numpy() if to_host else u
@@ -399,14 +399,23 @@ class NeuSRenderer:
         `backend`: "native" — the library's own marching cubes on the volume still resident in HBM
         (csrc/mcubes.hip); "mcubes" — PyMCubes on the host copy, exactly the reference's call (raises ImportError when
         PyMCubes is not installed); None (default) — "mcubes" when it is importable (the reference-faithful default),
-        else "native".  The native mesh has the same vertices (one per crossed grid edge, same interpolation); its
-        triangulation of ambiguous cells / quad diagonals may differ from PyMCubes' table (parity unpinned: DESIGN)."""
+        else "native".  The choice made for None is logged once per process (logger `rnb_neus_fork_amd`, INFO) and kept in
+        `self.last_mesh_backend`, so the same script cannot silently produce different triangulations on two machines.
+        The native mesh has the same vertices (one per crossed grid edge, same interpolation); its triangulation of
+        ambiguous cells / quad diagonals may differ from PyMCubes' table (parity unpinned: DESIGN)."""
         if backend is None:
             try:
                 import mcubes  # noqa: F401
                 backend = "mcubes"
             except ImportError:
                 backend = "native"
+            global _MESH_BACKEND_LOGGED
+            if not _MESH_BACKEND_LOGGED:
+                _MESH_BACKEND_LOGGED = True
+                logging.getLogger("rnb_neus_fork_amd").info(
+                    "extract_geometry(backend=None): using %r (%s); pass backend= to fix the choice", backend,
+                    "PyMCubes is importable" if backend == "mcubes" else "PyMCubes is not installed")
+        self.last_mesh_backend = backend
         if backend not in ("native", "mcubes"):
             raise ValueError(f"extract_geometry: unknown backend {backend!r}")
         b_max = bound_max.detach().cpu().numpy()

@@ -167,3 +167,45 @@ def test_large_batch_gradients_are_additive_over_shards(R):
                                + [n for n, _ in col.named_parameters()]):
         ref = ga + gb
         assert float((x - ref).norm()) <= 2e-4 * float(ref.norm()) + 1e-6, name
+
+
+@pytest.mark.parametrize("warmup", [True, False])
+def test_validate_image_call_shape_one_light_ragged_chunks(R, warmup):
+    """`validate_image` (exp_runner.py:389-516) renders one view with ONE light, in chunks of `batch_size` rays: warm-up
+    `render_rnb_warmup(..., lights_dir [1,1,1,3])` (:431-433), afterwards `render_rnb(..., lights_dir [1,b,1,3])` (:448), then
+    builds the normal image `sum_s gradients * weights * inside_sphere` (:463-470).  Here: 37 rays in chunks of 16 / 16 / 5
+    under no_grad (the forward-only path of the library), against the oracle on the depths the device sampled."""
+    mc, p, (sdf, dev, col, ren) = _tiny(R, seed=5)
+    B, chunk = 37, 16
+    batch = O.synthetic_batch(B, seed=21, step=2, warmup=warmup)
+    g = torch.Generator().manual_seed(9)
+    one = torch.randn(1, 1, 1, 3, generator=g)
+    one = one / one.norm()
+    per_ray = torch.randn(1, B, 1, 3, generator=g)
+    per_ray = per_ray / per_ray.norm(dim=-1, keepdim=True)
+    colors, normals, n_chunks = [], [], 0
+    with torch.no_grad():
+        for lo in range(0, B, chunk):
+            hi = min(B, lo + chunk)
+            b = {k: batch[k][lo:hi].to(_dev()) for k in ("rays_o", "rays_d", "near", "far", "t_rand")}
+            lights = one if warmup else per_ray[:, lo:hi]
+            fn = ren.render_rnb_warmup if warmup else ren.render_rnb
+            out = fn(b["rays_o"], b["rays_d"], b["near"], b["far"], lights.to(_dev()), cos_anneal_ratio=1.0,
+                     t_rand=b["t_rand"])
+            assert out["color_fine"].shape == (1, hi - lo, 3)
+            assert out["gradients"].shape == (hi - lo, 32, 3) and out["inside_sphere"].shape == (hi - lo, 32)
+            assert out["color_fine"].grad_fn is None
+            z = ren.last_z_vals.cpu()
+            ref = O.render_rnb(p, mc, batch["rays_o"][lo:hi], batch["rays_d"][lo:hi], batch["near"][lo:hi],
+                               batch["far"][lo:hi], lights, cos_anneal_ratio=1.0, warmup=warmup, z_vals=z)
+            for k in ("color_fine", "weights", "gradients", "inside_sphere", "weight_sum", "cdf_fine"):
+                torch.testing.assert_close(out[k].cpu(), ref[k].detach(), rtol=1e-4, atol=2e-5, msg=lambda m: f"{k}: {m}")
+            # the normal image of validate_image (exp_runner.py:463-470)
+            n_img = (out["gradients"] * out["weights"][:, :32, None] * out["inside_sphere"][..., None]).sum(dim=1).cpu()
+            n_ref = (ref["gradients"] * ref["weights"][:, :32, None] * ref["inside_sphere"][..., None]).sum(dim=1).detach()
+            torch.testing.assert_close(n_img, n_ref, rtol=1e-4, atol=2e-5)
+            colors.append(out["color_fine"].cpu())
+            normals.append(n_img)
+            n_chunks += 1
+    assert n_chunks == 3 and torch.cat(colors, dim=1).shape == (1, B, 3) and torch.cat(normals).shape == (B, 3)
+    assert float(torch.cat(normals).abs().max()) > 1e-3      # a surface was hit: the image is not empty

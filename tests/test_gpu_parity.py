@@ -14,6 +14,10 @@ import ctypes as C
 import zlib
 
 import numpy as np
+import json
+import math
+import os
+
 import pytest
 import torch
 
@@ -30,6 +34,44 @@ GRAD_CAP = 1e-2                  # ... capped: a gradient the fp32 reference res
 
 def _grad_bound(rel32s):
     return min(GRAD_CAP, max(1e-4, K_GRAD * rel32s))
+
+
+# SURVEY 8c states |d| <= 1e-5 + 1e-4 |ref| (outputs) and rel-L2 <= 1e-4 per gradient tensor.  The calibrated bounds above
+# replace them where the fp32 reference itself is further than that from fp64; how many tensors still meet the ORIGINAL
+# bounds is counted, printed, and held to the floor measured on MI355X in round 4 (tests/golden/survey_tol_floor.json:
+# a drift towards the calibrated bounds' 3 x would otherwise pass unseen).
+def _survey_counts(got_all, ref32_all, grads_mine, grads_ref):
+    n_out = ok_out = n_g = ok_g = 0
+    for k, ref in ref32_all.items():
+        if k == "inside_sphere":
+            continue
+        d = (got_all[k].double() - ref.double()).abs()
+        n_out += 1
+        ok_out += int(bool((d <= 1e-5 + 1e-4 * ref.double().abs()).all()))
+    for k, ref in grads_ref.items():
+        rn = float(ref.double().norm())
+        if rn < 1e-10:
+            continue
+        n_g += 1
+        ok_g += int(float((grads_mine[k].double() - ref.double()).norm()) / rn <= 1e-4)
+    return ok_out, n_out, ok_g, n_g
+
+
+def _survey_floor(tag):
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "survey_tol_floor.json")
+    if not os.path.exists(path):
+        return None
+    return json.load(open(path)).get(tag)
+
+
+def _check_survey(tag, counts):
+    ok_out, n_out, ok_g, n_g = counts
+    print(f"SURVEYTOL {tag}: outputs within 1e-5 + 1e-4|ref| of the fp32 reference: {ok_out}/{n_out}; "
+          f"gradient tensors within rel-L2 1e-4: {ok_g}/{n_g}")
+    floor = _survey_floor(tag)
+    if floor is not None:
+        assert ok_out >= floor["outputs_ok"], f"{tag}: {ok_out} outputs meet SURVEY 8c's bound, {floor['outputs_ok']} did in round 4"
+        assert ok_g >= floor["grads_ok"], f"{tag}: {ok_g} gradient tensors meet SURVEY 8c's bound, {floor['grads_ok']} did in round 4"
 
 
 def _assert_has_surface(out, dvariance=None):
@@ -80,10 +122,12 @@ def test_sdf_forward_matches_oracle(R, name):
     p, sdf, dev, col, ren = _build(R, g)
     pts = _fine_points(g)
     ref = O.sdf_forward(p, g.mc.sdf, pts)
-    out = sdf(pts.to(_dev())).cpu()
+    with torch.no_grad():   # (the direct network calls are forward-only and raise under grad mode)
+        out = sdf(pts.to(_dev())).cpu()
     assert out.shape == ref.shape
     torch.testing.assert_close(out, ref, rtol=1e-4, atol=2e-5)
-    out1 = sdf.sdf(pts.to(_dev())).cpu()
+    with torch.no_grad():
+        out1 = sdf.sdf(pts.to(_dev())).cpu()
     torch.testing.assert_close(out1, ref[:, :1], rtol=1e-4, atol=2e-5)
 
 
@@ -93,7 +137,8 @@ def test_sdf_gradient_matches_oracle(R, name):
     p, sdf, dev, col, ren = _build(R, g)
     pts = _fine_points(g)
     ref = O.sdf_gradient(p, g.mc.sdf, pts, create_graph=False)
-    out = sdf.gradient(pts.to(_dev())).cpu()
+    with torch.no_grad():
+        out = sdf.gradient(pts.to(_dev())).cpu()
     assert out.shape == (pts.shape[0], 1, 3)
     torch.testing.assert_close(out[:, 0, :], ref, rtol=2e-4, atol=5e-5)
 
@@ -107,7 +152,8 @@ def test_color_forward_matches_oracle(R, name):
     normals = torch.randn(pts.shape[0], 3, generator=gen)
     feats = torch.randn(pts.shape[0], g.mc.color.d_feature, generator=gen) * 0.3
     ref = O.color_forward(p, g.mc.color, pts, normals, normals, feats)
-    out = col(pts.to(_dev()), normals.to(_dev()), normals.to(_dev()), feats.to(_dev())).cpu()
+    with torch.no_grad():
+        out = col(pts.to(_dev()), normals.to(_dev()), normals.to(_dev()), feats.to(_dev())).cpu()
     torch.testing.assert_close(out, ref, rtol=1e-4, atol=2e-5)
     out2 = ren.color(pts.to(_dev()), normals.to(_dev()), None, feats.to(_dev())).cpu()
     torch.testing.assert_close(out2, ref, rtol=1e-4, atol=2e-5)
@@ -192,9 +238,11 @@ def test_gather_sdf(R):
     assert torch.equal(out.cpu(), ref)
 
 
+@torch.no_grad()
 def _device_sampling_trace(R, g, sdf, b, z0):
     """The up-sampling loop of rnb_sample_rays composed from the public per-step entry points (rnb_up_sample_step,
-    rnb_sdf_forward, rnb_gather_sdf), so that the integer outputs of every step are visible."""
+    rnb_sdf_forward, rnb_gather_sdf), so that the integer outputs of every step are visible.  (no_grad, like the reference's
+    loop, models/renderer.py:590: the direct network calls raise under grad mode.)"""
     lib = R.native.load()
     d = _dev()
     rc = g.mc.render
@@ -226,62 +274,119 @@ def _device_sampling_trace(R, g, sdf, b, z0):
     return inds_all, z
 
 
-# measured on MI355X (round 2; `pytest -s` prints them): fraction of z_vals within 1e-4 of the reference's and
-# fraction of rays whose four searchsorted index rows ALL equal the reference's, per fixture; the thresholds sit just
-# under the measurements.  (The CPU oracle itself drops to 0.984 / 232 of 240 rays when only its weight-norm
-# expression is re-associated: tests/test_oracle_golden.py::test_weight_norm_rounding_is_amplified...)
-E2E_MIN = {    # name -> (min frac of z within 1e-4, min frac of rays with identical indices); measured in comments
-    "full_main_noalbedo": (0.993, 0.85),    # 0.9951, 28/32
-    "full_main_sharp": (0.995, 0.95),       # 0.9967, 63/64
-    "full_render_sharp": (0.996, 0.93),     # 0.9983, 31/32
-    "full_warmup_geo": (0.995, 0.95),       # 0.9965, 63/64
-    "full_main_b512": (0.997, 0.97),        # 0.9987, 503/512 (round 3)
-}
-E2E_DEFAULT = (1.0, 1.0)                    # tiny_*: every z within 1e-4 (max 9e-6), every index identical
+# End-to-end sampling cannot be bit-exact across implementations: the up-sampling loop amplifies a last-bit difference of
+# the coarse SDF into other searchsorted results two steps later.  The yardstick is the reference-pinned CPU oracle ITSELF
+# under such a perturbation (tests/test_oracle_golden.py::test_weight_norm_rounding_is_amplified_by_the_up_sampling_loop:
+# the mathematically equal weight-norm expression): 8 of 240 fixture rays change at least one index row, 98.4 % of the
+# depths stay within 1e-4.  The device is held to that class — not to its own last measurement:
+ORACLE_FLIP_RATE = 8.0 / 240.0     # rays with any differing index row, oracle vs re-associated oracle
+ORACLE_CLOSE = 0.984               # fraction of depths within 1e-4, same experiment
 
 
-@pytest.mark.parametrize("name", CASES)
-def test_sample_rays_end_to_end(R, name):
-    """Whole prologue on the device.  1-ulp differences of the coarse SDF are amplified by the sharp
-    sigmoids of the up-sampling loop (the CPU oracle shows the same when its weight-norm rounding is
-    changed), so end to end the z_vals are compared statistically, with thresholds at the measured level."""
-    g = Golden(name)
+def _max_flipped(n_rays):
+    """Rays of one fixture that may differ: 3 x the oracle's own rate (small fixtures: at least one)."""
+    return max(1, math.ceil(3.0 * ORACLE_FLIP_RATE * n_rays))
+
+
+def _e2e_run(R, g):
+    """Device sampling of one fixture: (flipped rays, rays, fraction of depths within 1e-4, max |dz|, z, z0)."""
     p, sdf, dev, col, ren = _build(R, g)
     b = {k: v.to(_dev()) for k, v in g.batch.items()}
     perturb = g.mc.render.perturb if g.perturb_overwrite < 0 else g.perturb_overwrite
     packed = ren._pack(False)
     z = ren.sample_z_vals(b["rays_o"], b["rays_d"], b["near"], b["far"], packed, perturb, b["t_rand"])
-    ref = g.z_fine
-    assert z.shape == ref.shape
-    assert bool((z[:, 1:] >= z[:, :-1]).all())
-    # coarse depths (before any up-sampling) must be bit-exact
     ren0 = R.NeuSRenderer(None, sdf, dev, col, n_samples=g.mc.render.n_samples, n_importance=0, n_outside=0,
                           up_sample_steps=1, perturb=g.mc.render.perturb)
     z0 = ren0.sample_z_vals(b["rays_o"], b["rays_d"], b["near"], b["far"], packed, perturb, b["t_rand"])
+    if g.n_steps == 0:
+        return 0, z.shape[0], 1.0, 0.0, z, z0, None
+    inds_all, z_composed = _device_sampling_trace(R, g, sdf, b, z0)
+    same = torch.ones(z.shape[0], dtype=torch.bool)
+    for mine, st in zip(inds_all, g.steps):
+        same &= (mine == st["inds"]).all(dim=1)
+    diff = (z.cpu() - g.z_fine).abs()
+    return int((~same).sum()), same.numel(), (diff < 1e-4).float().mean().item(), float(diff.max()), z, z0, z_composed
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_sample_rays_end_to_end(R, name):
+    """Whole prologue on the device.  Coarse depths bit-exact; rnb_sample_rays equal to the loop composed from the per-step
+    entry points; the final depths and index rows against the reference's within the class the oracle's own re-association
+    experiment defines (above)."""
+    g = Golden(name)
+    flipped, n_rays, frac_close, dmax, z, z0, z_composed = _e2e_run(R, g)
+    ref = g.z_fine
+    assert z.shape == ref.shape
+    assert bool((z[:, 1:] >= z[:, :-1]).all())
     z0_ref = g.steps[0]["z_in"] if g.n_steps else g.z_fine
     assert torch.equal(z0.cpu(), z0_ref), "initial depths must be bit-exact"
     if g.n_steps == 0:
         assert torch.equal(z.cpu(), ref)
         return
-    inds_all, z_composed = _device_sampling_trace(R, g, sdf, b, z0)
     assert torch.equal(z_composed, z), "rnb_sample_rays must equal the loop composed from the per-step entry points"
-    same = torch.ones(z.shape[0], dtype=torch.bool)
-    for mine, st in zip(inds_all, g.steps):
-        same &= (mine == st["inds"]).all(dim=1)
-    frac_rays = same.float().mean().item()
-    diff = (z.cpu() - ref).abs()
-    frac_close = (diff < 1e-4).float().mean().item()
-    print(f"E2E {name}: z_vals within 1e-4: {frac_close:.4f}; rays with all {g.n_steps} index rows identical: "
-          f"{frac_rays:.4f} ({int(same.sum())}/{same.numel()}); max |dz| {diff.max():.3e}")
-    lo_close, lo_rays = E2E_MIN.get(name, E2E_DEFAULT)
-    assert frac_close >= lo_close
-    assert frac_rays >= lo_rays
-    assert diff.mean().item() < 5e-4
+    print(f"E2E {name}: z_vals within 1e-4: {frac_close:.4f} (oracle experiment: {ORACLE_CLOSE}); rays with a differing index row: "
+          f"{flipped}/{n_rays} (allowed {_max_flipped(n_rays)} = 3 x the oracle experiment's rate); max |dz| {dmax:.3e}")
+    assert frac_close >= ORACLE_CLOSE
+    assert flipped <= _max_flipped(n_rays)
+    assert (z.cpu() - ref).abs().mean().item() < 5e-4
+
+
+def test_sample_rays_end_to_end_aggregate_rate(R):
+    """Over all full-size fixtures together (704 rays) the device changes index rows at no more than 1.5 x the rate of the
+    oracle's own re-association experiment (3.3 %), and keeps at least its fraction of depths within 1e-4."""
+    flipped = rays = 0
+    close = []
+    for name in [c for c in CASES if c.startswith("full") and Golden(c).n_steps > 0]:
+        f, n, fc, _, _, _, _ = _e2e_run(R, Golden(name))
+        flipped += f
+        rays += n
+        close.append(fc * n)
+    rate = flipped / rays
+    print(f"E2E aggregate: {flipped}/{rays} rays differ = {rate:.4f} (oracle experiment {ORACLE_FLIP_RATE:.4f}); depths within 1e-4: "
+          f"{sum(close) / rays:.4f} (oracle experiment {ORACLE_CLOSE})")
+    assert rays >= 600
+    assert rate <= 1.5 * ORACLE_FLIP_RATE
+    assert sum(close) / rays >= ORACLE_CLOSE
 
 
 # ---------------------------------------------------------------------------------------------------
 # fine pass forward + backward on the reference's own z_vals
 # ---------------------------------------------------------------------------------------------------
+def test_more_weight_gradient_jobs_than_one_launch_group_holds(R):
+    """A 12-hidden-layer SDF network and a 4-hidden-layer albedo network, all 256 wide: 17 weight-gradient jobs of the
+    256-row kernel, more than the 12 one launch group carries, so the group is flushed mid-way and its slab workspace
+    must be handed to the next group (DwBatch::flush_staged).  Every parameter gradient against the oracle's autograd."""
+    mc = O.ModelConf(sdf=O.SDFConf(n_layers=12, skip_in=(4,)), color=O.ColorConf(n_layers=4),
+                     render=O.RenderConf(n_samples=32, n_importance=32, up_sample_steps=2))
+    torch.manual_seed(6)
+    p = O.init_params(mc)
+    with torch.no_grad():
+        p["dev.variance"].fill_(0.3)
+    sdf, dev, col, ren = R.build_from_named_params(mc, p, _dev())
+    batch = O.synthetic_batch(64, seed=37, step=1, warmup=False)
+    b = {k: v.to(_dev()) for k, v in batch.items()}
+    out = ren.render_rnb(b["rays_o"], b["rays_d"], b["near"], b["far"], b["lights_dir"], cos_anneal_ratio=1.0,
+                         t_rand=b["t_rand"])
+    O.rnb_loss(out, b["true_rgb"], b["mask"])[0].backward()
+    z = ren.last_z_vals.cpu()
+    pr = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    ref = O.render_rnb(pr, mc, batch["rays_o"], batch["rays_d"], batch["near"], batch["far"], batch["lights_dir"],
+                       cos_anneal_ratio=1.0, warmup=False, z_vals=z)
+    O.rnb_loss(ref, batch["true_rgb"], batch["mask"])[0].backward()
+    for k in ("color_fine", "weights", "gradients"):
+        torch.testing.assert_close(out[k].detach().cpu(), ref[k].detach(), rtol=1e-4, atol=2e-5, msg=lambda m: f"{k}: {m}")
+    n_checked = 0
+    for name, leaf in _named(sdf, dev, col).items():
+        gr = pr[name].grad
+        assert leaf.grad is not None and bool(torch.isfinite(leaf.grad).all()), name
+        if float(gr.norm()) < 1e-12:
+            continue
+        rel = float((leaf.grad.cpu().reshape(gr.shape) - gr).norm() / gr.norm())
+        assert rel < 2e-3, (name, rel)
+        n_checked += 1
+    assert n_checked >= 3 * (13 + 5)
+
+
 def _render(ren, g, b, z_vals):
     kw = dict(perturb_overwrite=g.perturb_overwrite, cos_anneal_ratio=g.cos_anneal_ratio, z_vals=z_vals)
     if g.api == "render":
@@ -365,6 +470,8 @@ def test_fine_pass_golden(R, name):
             f"{k}: rel-L2 vs the fp32 reference {rel:.3e}"
     print(f"FINE {name}: worst output error ratio hip/ref32 = {worst_out[1]:.2f} ({worst_out[0]}); worst gradient: "
           f"{worst[0]} rel-L2 vs fp64 {worst[2]:.2e} = {worst[1]:.2f} of its bound")
+    mine_g = {k: named[k].grad.detach().cpu().reshape(-1)[:: g.grad_stride] for k in g.grads}
+    _check_survey(name, _survey_counts(got_all, g.out, mine_g, g.grads))
 
 
 def test_full_batch_512_matches_oracle(R):
@@ -423,6 +530,10 @@ def test_full_batch_512_matches_oracle(R):
         assert rel <= bound, f"{k}: rel-L2 {rel:.3e} > {bound:.3e} (fp32 CPU oracle: {rel32:.3e})"
     print(f"B=512 vs fp64 oracle: weight_sum mean {float(out['weight_sum'].mean()):.3f}; worst gradient {worst[0]}: "
           f"rel-L2 {worst[2]:.2e} = {worst[1]:.2f} of its bound")
+    # SURVEY 8c's original bounds, against the fp32 oracle (the reference's arithmetic) on the same depths
+    keys = ("color_fine", "weights", "weight_sum", "gradients", "cdf_fine", "gradient_error")
+    _check_survey("b512_end_to_end", _survey_counts({k: out[k].detach().cpu() for k in keys}, {k: ref32[k].detach() for k in keys},
+                                                    {k: v.grad.cpu() for k, v in named.items()}, {k: p32[k].grad for k in named}))
 
 
 def test_size_independent_properties(R):
@@ -490,6 +601,66 @@ def test_256_samples_per_ray_matches_oracle(R):
     assert float((g - gr).norm() / gr.norm()) < 1e-3
 
 
+def test_direct_network_calls_are_loud_under_grad(R):
+    """models/fields.py:82-127, :177-215 are autograd modules in the reference (`gradient` with create_graph=True); here the
+    direct calls are native forward sweeps without a grad_fn.  Under grad mode with trainable parameters (or an input that
+    requires grad) they must raise and name NeuSRenderer.render*, not detach silently (missing item 1); under
+    no_grad, or with frozen parameters, they work."""
+    mc = O.ModelConf(sdf=O.SDFConf(d_out=65, d_hidden=64), color=O.ColorConf(d_feature=64, d_hidden=64))
+    torch.manual_seed(0)
+    p = O.init_params(mc)
+    sdf, devn, col, ren = R.build_from_named_params(mc, p, _dev())
+    pts = (torch.rand(100, 3) - 0.5).to(_dev())
+    nrm = torch.randn(100, 3, device=_dev())
+    feat = torch.randn(100, 64, device=_dev())
+    assert torch.is_grad_enabled() and sdf.lin0.bias.requires_grad
+    for call in (lambda: sdf(pts), lambda: sdf.sdf(pts), lambda: sdf.gradient(pts), lambda: sdf.sdf_hidden_appearance(pts),
+                 lambda: col(pts, nrm, nrm, feat)):
+        with pytest.raises(RuntimeError, match="NeuSRenderer.render"):
+            call()
+    with torch.no_grad():
+        out = sdf(pts)
+        g = sdf.gradient(pts)
+        c = col(pts, nrm, nrm, feat)
+    assert out.shape == (100, 65) and g.shape == (100, 1, 3) and c.shape == (100, 3)
+    assert out.grad_fn is None and not out.requires_grad
+    # frozen parameters + plain inputs: nothing could receive a gradient, the call is allowed under grad mode
+    for q in list(sdf.parameters()) + list(col.parameters()):
+        q.requires_grad_(False)
+    assert torch.equal(sdf(pts), out)
+    with pytest.raises(RuntimeError, match="NeuSRenderer.render"):
+        sdf.sdf(pts.clone().requires_grad_(True))
+
+
+def test_mv_forward_variant_matches_the_default(R):
+    """RNB_VARIANT_REG_TILE: the M/V kernels (csrc/sweep_mv.hip: matrix waves + vector waves, transposed products, weights
+    through an LDS-DMA ring) for forward-only sweeps of >= 25,600 points, against the default LDS-tile kernels and the
+    oracle — sdf alone (the sampling passes' call) and sdf + feature."""
+    mc = O.ModelConf()
+    torch.manual_seed(3)
+    p = O.init_params(mc)
+    gen = torch.Generator().manual_seed(4)
+    for k in p:                       # no layer of the geometric init is special any more
+        if k.endswith("weight_v"):
+            p[k] = p[k] + 0.02 * torch.randn(p[k].shape, generator=gen)
+    sdf, devn, col, ren = R.build_from_named_params(mc, p, _dev())
+    n = 128 * 230 + 57               # ragged: the last workgroup is partly padding
+    pts = (torch.rand(n, 3, generator=gen) * 2 - 1) * 0.9
+    ref = O.sdf_forward(p, mc.sdf, pts[:3000])
+    from rnb_neus_fork_amd import runtime
+    outs = {}
+    for tag, kw in (("lds", dict(lds_tile=True)), ("mv", dict(reg_tile=True))):
+        ren.set_variant(**kw)
+        packed = ren._pack(True)
+        outs[tag] = (runtime.sdf_forward(ren.desc, packed, pts.to(_dev()), True).cpu(),
+                     runtime.sdf_forward(ren.desc, packed, pts.to(_dev()), False).cpu())
+    ren.set_variant()
+    for tag in outs:
+        torch.testing.assert_close(outs[tag][0][:3000], ref, rtol=1e-4, atol=2e-5, msg=lambda m: f"{tag} vs oracle: {m}")
+        assert torch.equal(outs[tag][0][:, :1], outs[tag][1]), f"{tag}: sdf-only and sdf+feature sweeps must agree bit for bit"
+    torch.testing.assert_close(outs["mv"][0], outs["lds"][0], rtol=1e-5, atol=5e-6)
+
+
 def test_fused_and_generic_paths_agree(R):
     """The 256-wide network runs through the fused sweep kernels; RNB_VARIANT_GENERIC (rnb_model_desc.variant) forces
     the per-layer GEMM path (the one other widths use), RNB_VARIANT_DW_LDS the LDS-staged weight-gradient GEMMs, the
@@ -507,7 +678,7 @@ def test_fused_and_generic_paths_agree(R):
                     ("bwd_ti1", dict(bwd_ti=1, bwd_nw=4)), ("bwd_ti2", dict(bwd_ti=2, bwd_nw=4)),
                     ("bwd_ti2_nw8", dict(bwd_ti=2, bwd_nw=8)), ("fwd_ti1", dict(fwd_ti=1, fwd_nw=4)),
                     ("deterministic", dict(deterministic=True)), ("x3", dict(x3=True)),
-                    ("p3_forward", dict(fwd_ti=2, fwd_nw=8)), ("f32_mfma", dict(f32_mfma=True)), ("f32_mfma_ti2", dict(f32_mfma=True, bwd_ti=2, bwd_nw=4)),
+                    ("fwd_ti2_nw8", dict(fwd_ti=2, fwd_nw=8)), ("f32_mfma", dict(f32_mfma=True)), ("f32_mfma_ti2", dict(f32_mfma=True, bwd_ti=2, bwd_nw=4)),
                     ("x3_ti1_nw4", dict(x3=True, bwd_ti=1, bwd_nw=4, fwd_ti=1, fwd_nw=4)),
                     ("x3_ti2_nw8", dict(x3=True, bwd_ti=2, bwd_nw=8, fwd_ti=2))):
         ren.set_variant(**kw)

@@ -27,7 +27,55 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/rnbneus.h but not exported"
     assert set(declared) == set(R.native.EXPORTED_SYMBOLS)
-    assert lib.rnb_abi_version() == 3
+    assert lib.rnb_abi_version() == 4
+
+
+def test_build_id_ties_stored_profiles_to_the_library(tmp_path, monkeypatch):
+    """rnb_build_id() = hash of csrc/ + include/ + compiler flags (buildid.source_build_id).  bench.py quotes stored PMC
+    traffic only for the build it was measured on: one byte of one source changed -> another id -> `traffic: null`."""
+    import json
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    from rnb_neus_fork_amd import buildid
+    lib_id = R.native.build_id()
+    assert re.fullmatch(r"[0-9a-f]{16}", lib_id), lib_id
+    assert lib_id == buildid.source_build_id(), "the library in the tree was not built from the sources in the tree"
+    # one byte of one kernel source differs -> a different id
+    name, path = [f for f in buildid.source_files() if f[0] == "csrc/fused.hip"][0]
+    data = bytearray(open(path, "rb").read())
+    data[len(data) // 2] ^= 1
+    other = buildid.source_build_id(overrides={name: bytes(data)})
+    assert other != lib_id
+    prof = {"build_id": lib_id, "rays": 512, "samples": 128, "hbm_bytes_per_launch": 1.0, "hbm_bytes_per_step": 13.0,
+            "launches_per_step": 13.0}
+    (tmp_path / "hbm_traffic.json").write_text(json.dumps(prof))
+    monkeypatch.setattr(bench, "PROFILES", str(tmp_path))
+    t, note = bench.measured_traffic("hbm_traffic.json", 1, 512, 128, lib_id)
+    assert t is not None and note is None and t["hbm_bytes_per_step"] == 13.0
+    t, note = bench.measured_traffic("hbm_traffic.json", 1, 512, 128, other)          # the flipped build
+    assert t is None and "not quoted" in note
+    t, note = bench.measured_traffic("hbm_traffic.json", 1, 256, 128, lib_id)         # another workload
+    assert t is None and note
+    prof.pop("build_id")                                                               # a profile from before the ids
+    (tmp_path / "hbm_traffic.json").write_text(json.dumps(prof))
+    t, note = bench.measured_traffic("hbm_traffic.json", 1, 512, 128, lib_id)
+    assert t is None and "none recorded" in note
+
+
+def test_direct_network_calls_refuse_to_detach_silently():
+    """The direct calls sdf_network(x) / .sdf / .gradient / color_network(...) are native forward sweeps without a grad_fn;
+    the reference's are autograd modules (models/fields.py:82-127, :177-215).  With grad mode on and trainable parameters the
+    call raises (before anything touches a device) and points at NeuSRenderer.render*."""
+    sdf = R.SDFNetwork(d_in=3, d_out=33, d_hidden=32, n_layers=2, skip_in=[], multires=2)
+    col = R.RenderingNetwork(d_feature=32, mode="no_view_dir", d_in=6, d_out=3, d_hidden=32, n_layers=1, multires_view=2)
+    x = torch.zeros(4, 3)
+    for call in (lambda: sdf(x), lambda: sdf.sdf(x), lambda: sdf.gradient(x), lambda: col(x, x, x, torch.zeros(4, 32))):
+        with pytest.raises(RuntimeError, match="forward-only.*NeuSRenderer.render"):
+            call()
+    with torch.no_grad():   # allowed — and then fails only because there is no CPU path
+        with pytest.raises(RuntimeError, match="GPU"):
+            sdf.sdf(x)
 
 
 def _desc(**over):

@@ -4,8 +4,12 @@ usage: python tools/traffic_summary.py <fetch_counter_collection.csv> <write_cou
 import collections
 import csv
 import json
+import os
 import re
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 
 
 def load(path, counter):
@@ -32,7 +36,10 @@ for k in sorted(fam):
     tot_f += sum(f.get(k, [0]))
     tot_w += sum(w.get(k, [0]))
     n += nf
-out = {"rays": rays, "samples": samples, "steps": steps, "launches_per_step": n / steps,
+# the build the passes ran on: the library in this tree right now (collect and summarise in one go, on one box)
+import rnb_neus_fork_amd as R  # noqa: E402
+
+out = {"build_id": R.native.build_id(), "rays": rays, "samples": samples, "steps": steps, "launches_per_step": n / steps,
        "fetch_size_raw_bytes_per_step": tot_f / steps * 1024,
        "fetch_bytes_per_step_corrected_x2": 2 * tot_f / steps * 1024,
        "write_bytes_per_step": tot_w / steps * 1024,
