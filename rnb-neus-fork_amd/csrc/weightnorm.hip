@@ -46,8 +46,25 @@ __device__ inline float block_sum(float v, float* red) {
   return t;
 }
 
+__device__ inline double block_sum_f64(double v, double* red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  double t = 0.0;
+  for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += red[i];
+  return t;
+}
+
+// The row factor g / ||v|| multiplies a whole row: an fp32 rounding error in it is the SAME relative error in every
+// product of that row, for every point — for the SDF output row a common offset of the whole SDF field (measured:
+// -1.1e-7 with the factor in fp32, profiles/r04_sdf_bias.txt), which a sharp surface (inv_s ~ 400) turns into twice the
+// weight_sum error of the fp32 CPU oracle.  So the factor is formed in fp64 and every W element is rounded once, from
+// the fp64 product (675k elements per step: nothing).
 __global__ __launch_bounds__(256) void wn_fwd_kernel(WnTable tab, float* __restrict__ packed) {
-  __shared__ float red[4];
+  __shared__ double red[4];
   int ei = 0;
   while (ei + 1 < tab.n && (int)blockIdx.x >= tab.e[ei + 1].row_begin) ++ei;
   const WnEntry& en = tab.e[ei];
@@ -64,16 +81,18 @@ __global__ __launch_bounds__(256) void wn_fwd_kernel(WnTable tab, float* __restr
   }
   const int src = en.src_row0 + r;
   const float* vrow = en.v + (long long)src * en.K;
-  float mult = en.scale;
+  // the skip layer's 1/sqrt(2) (models/fields.py:93 divides the activations by np.sqrt(2)) at fp64 precision
+  const double scale = en.scale == 0.70710678118654752440f ? 0.70710678118654752440 : (double)en.scale;
+  double mult = scale;
   if (en.g != nullptr) {
-    float ss = 0.f;
-    for (int i = threadIdx.x; i < en.K; i += blockDim.x) ss = fmaf(vrow[i], vrow[i], ss);
-    ss = block_sum(ss, red);
-    mult = en.scale * (en.g[src] / sqrtf(ss));
+    double ss = 0.0;
+    for (int i = threadIdx.x; i < en.K; i += blockDim.x) ss = fma((double)vrow[i], (double)vrow[i], ss);
+    ss = block_sum_f64(ss, red);
+    mult = scale * ((double)en.g[src] / sqrt(ss));
   }
   for (int i = threadIdx.x; i < en.K; i += blockDim.x) {
     const int c = cmap(en, i);
-    const float w = vrow[i] * mult;
+    const float w = (float)((double)vrow[i] * mult);
     wrow[c] = w;
     if (wT) wT[(long long)c * en.Nrows] = w;
   }

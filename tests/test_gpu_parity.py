@@ -42,19 +42,26 @@ def _grad_bound(rel32s):
 # a drift towards the calibrated bounds' 3 x would otherwise pass unseen).
 def _survey_counts(got_all, ref32_all, grads_mine, grads_ref):
     n_out = ok_out = n_g = ok_g = 0
+    missed = []
     for k, ref in ref32_all.items():
         if k == "inside_sphere":
             continue
         d = (got_all[k].double() - ref.double()).abs()
         n_out += 1
-        ok_out += int(bool((d <= 1e-5 + 1e-4 * ref.double().abs()).all()))
+        ok = bool((d <= 1e-5 + 1e-4 * ref.double().abs()).all())
+        ok_out += int(ok)
+        if not ok:
+            missed.append(f"{k} (max excess {float((d - 1e-5 - 1e-4 * ref.double().abs()).max()):.1e})")
     for k, ref in grads_ref.items():
         rn = float(ref.double().norm())
         if rn < 1e-10:
             continue
         n_g += 1
-        ok_g += int(float((grads_mine[k].double() - ref.double()).norm()) / rn <= 1e-4)
-    return ok_out, n_out, ok_g, n_g
+        rel = float((grads_mine[k].double() - ref.double()).norm()) / rn
+        ok_g += int(rel <= 1e-4)
+        if rel > 1e-4:
+            missed.append(f"d {k} ({rel:.1e})")
+    return ok_out, n_out, ok_g, n_g, missed
 
 
 def _survey_floor(tag):
@@ -65,9 +72,9 @@ def _survey_floor(tag):
 
 
 def _check_survey(tag, counts):
-    ok_out, n_out, ok_g, n_g = counts
+    ok_out, n_out, ok_g, n_g, missed = counts
     print(f"SURVEYTOL {tag}: outputs within 1e-5 + 1e-4|ref| of the fp32 reference: {ok_out}/{n_out}; "
-          f"gradient tensors within rel-L2 1e-4: {ok_g}/{n_g}")
+          f"gradient tensors within rel-L2 1e-4: {ok_g}/{n_g}" + (f"; outside: {', '.join(missed)}" if missed else ""))
     floor = _survey_floor(tag)
     if floor is not None:
         assert ok_out >= floor["outputs_ok"], f"{tag}: {ok_out} outputs meet SURVEY 8c's bound, {floor['outputs_ok']} did in round 4"
