@@ -60,7 +60,8 @@ def measured_traffic(name, n_gpus, rays, samples, build_id):
 # kernel class tag (rnb_profile_report) -> substring of the kernel names whose PMC traffic belongs to it
 CLASS_KERNELS = {"RA_sweep": "fused_ra_kernel", "FB_sweep": "fused_fb_kernel", "R_sweep": "fused_reverse_kernel",
                  "F_sweep(save)": "fused_forward_kernel<2, true", "dW(x3: 256x256 + narrow jobs + reduce)": "gemm_dw_x3_kernel",
-                 "dW(all)": "bf_dw_kernel", "dW(other)": "gemm_dw_direct_kernel", "layer_gemm": "gemm_rows_x3"}
+                 "dW(all)": "bf_dw_kernel", "dW(other)": "gemm_dw_direct_kernel", "layer_gemm": ("EpiReluMask", "EpiStore"),
+                 "layer_gemm(forward)": "EpiRelu>"}
 HBM_BOUND_TBS = 4.0    # a class that moves more than this (PMC bytes / event time) is labelled hbm-bound: half of the 8 TB/s
                        # spec, ~2/3 of what a plain copy reaches (6.3 TB/s)
 
@@ -84,7 +85,8 @@ def kernel_classes(lib, steps, peak_tflops, traffic=None):
         key = CLASS_KERNELS.get(tag)
         if traffic and key:
             b = sum((2.0 * v["fetch_size_raw_kb_per_launch"] + v["write_size_kb_per_launch"]) * 1024.0 * v["launches_per_step"]
-                    for k, v in traffic.get("per_kernel", {}).items() if key in k)
+                    for k, v in traffic.get("per_kernel", {}).items()
+                    if any(kk in k for kk in (key if isinstance(key, tuple) else (key,))))
             if b > 0:
                 tbs = b / (ms / steps * 1e-3) / 1e12
                 d.update(hbm_gb_per_step=round(b / 1e9, 3), hbm_tb_per_s=round(tbs, 2),
@@ -131,6 +133,8 @@ def parse():
     ap.add_argument("--bwd-nw", type=int, default=0, help="A/B knob: waves per workgroup of the backward sweeps (4 | 8)")
     ap.add_argument("--reg-tile", action="store_true", help="A/B knob: M/V kernels for the large forward-only sweeps (RNB_VARIANT_REG_TILE)")
     ap.add_argument("--lds-tile", action="store_true", help="A/B knob: force the LDS-tile sweep kernels (RNB_VARIANT_LDS_TILE)")
+    ap.add_argument("--no-x2h", dest="x2h", action="store_false", default=None,
+                    help="A/B knob: forward-type sweeps on six bf16 terms like the backward ones (RNB_VARIANT_NO_X2H)")
     ap.add_argument("--no-also", action="store_true",
                     help="skip the short extra legs (no-albedo, bf16 x 256 samples, render, fp32 MFMA) that the default "
                          "--gpus 1 train run appends under `also`")
@@ -361,7 +365,7 @@ def synthetic_capture(R, dev, n_views, H, W, n_lights=3):
 
 
 def build_model(R, dev, samples, dtype, deterministic, fwd_ti=0, bwd_ti=0, dw_staged=False, x3=False, fwd_nw=0, bwd_nw=0, f32_mfma=False,
-                reg_tile=False, lds_tile=False):
+                reg_tile=False, lds_tile=False, x2h=None):
     import torch
     # confs/wmask_rnb.conf:53-90, constructed in the order of exp_runner.py:95-100 under seed 0
     torch.manual_seed(0)
@@ -373,7 +377,7 @@ def build_model(R, dev, samples, dtype, deterministic, fwd_ti=0, bwd_ti=0, dw_st
     ren = R.NeuSRenderer(None, sdf, devnet, col, n_samples=samples // 2, n_importance=samples // 2, n_outside=0,
                          up_sample_steps=4, perturb=1.0)
     ren.set_variant(bf16=(dtype == "bf16"), deterministic=deterministic, fwd_ti=fwd_ti, bwd_ti=bwd_ti, dw_staged=dw_staged, x3=x3,
-                    fwd_nw=fwd_nw, bwd_nw=bwd_nw, f32_mfma=f32_mfma, reg_tile=reg_tile, lds_tile=lds_tile)
+                    fwd_nw=fwd_nw, bwd_nw=bwd_nw, f32_mfma=f32_mfma, reg_tile=reg_tile, lds_tile=lds_tile, x2h=x2h)
     return sdf, devnet, col, ren
 
 
@@ -393,7 +397,7 @@ def measure_train(args, ctx, with_cpu=True):
 
     S = args.samples
     sdf, devnet, col, ren = build_model(R, dev, S, args.dtype, args.deterministic, args.fwd_ti, args.bwd_ti, args.dw_staged, args.x3,
-                                        args.fwd_nw, args.bwd_nw, args.f32_mfma, args.reg_tile, args.lds_tile)
+                                        args.fwd_nw, args.bwd_nw, args.f32_mfma, args.reg_tile, args.lds_tile, args.x2h)
     exact_dp = not args.torch_train_ops     # the reference's torch-op loss knows nothing about shards
     if world > 1:
         P.broadcast_parameters([sdf, devnet, col])
@@ -710,7 +714,7 @@ def run_mesh(args):
     import rnb_neus_fork_amd as R
     lib = R.native.load()
     sdf, devnet, col, ren = build_model(R, dev, 128, args.dtype, False, x3=args.x3, f32_mfma=args.f32_mfma, fwd_ti=args.fwd_ti,
-                                        fwd_nw=args.fwd_nw, reg_tile=args.reg_tile, lds_tile=args.lds_tile)
+                                        fwd_nw=args.fwd_nw, reg_tile=args.reg_tile, lds_tile=args.lds_tile, x2h=args.x2h)
     if world > 1:
         from rnb_neus_fork_amd import parallel as P
         P.broadcast_parameters([sdf, devnet, col])

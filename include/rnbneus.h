@@ -97,7 +97,14 @@ typedef struct rnb_model_desc {
  *   RNB_VARIANT_REG_TILE /    which family of fused x3 sweeps runs: REG_TILE = the M/V kernels (sweep_mv.hip: matrix waves
  *   RNB_VARIANT_LDS_TILE      with 32 points each and the weights through an LDS-DMA ring + vector waves for the
  *                             epilogues), LDS_TILE = the 64-point LDS-tile kernels (fused.hip / fused_bwd.hip).  Neither
- *                             bit: the measured default per sweep and batch size.  A/B switches. */
+ *                             bit: the measured default per sweep and batch size.  A/B switches.
+ *   RNB_VARIANT_X2H /         (with X3; ON by default, NO_X2H switches it off) the FORWARD-type sweeps (SDF forward and
+ *   RNB_VARIANT_NO_X2H        its saved-state form, sampling passes, grid queries, the normal's reverse sweep) take every fp32
+ *                             product as THREE fp16 matrix terms (x = hi + lo in fp16 after a power-of-two scale) instead of
+ *                             six bf16 ones: half the matrix time, operands represented to 2^-22 (rms 2^-23.6; the measured SDF error
+ *                             is below the six-term scheme's), but a bounded operand
+ *                             range: |weight| < 255, |activation| < 1023 (beyond: inf / NaN outputs, never silently wrong
+ *                             ones).  The backward sweeps keep the bf16 scheme (adjoints have no a-priori range). */
 enum {
   RNB_VARIANT_BF16 = 1,
   RNB_VARIANT_DETERMINISTIC = 2,
@@ -111,7 +118,9 @@ enum {
   RNB_VARIANT_FWD_TI_SHIFT = 12,
   RNB_VARIANT_FWD_NW_SHIFT = 14,
   RNB_VARIANT_REG_TILE = 1 << 16,
-  RNB_VARIANT_LDS_TILE = 1 << 17
+  RNB_VARIANT_LDS_TILE = 1 << 17,
+  RNB_VARIANT_X2H = 1 << 18,
+  RNB_VARIANT_NO_X2H = 1 << 19
 };
 
 /* Trainable leaves of one MLP in the reference's state_dict naming (linN.weight_g [out,1],

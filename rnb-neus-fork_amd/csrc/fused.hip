@@ -23,8 +23,16 @@ namespace rnb {
 // every CU still gets a workgroup).  NW = waves per workgroup: 4 (each wave 64 output columns) or 8 (32 columns
 // each) — the latter for batches so small that a CU holds a single workgroup: two waves per SIMD instead of one
 // hide each other's LDS / L2 waits.
-template <int TI, bool SAVE, int NW = 4, bool X3 = false>
+// H2 (with X3): the products on the fp16 matrix pipe in three terms instead of six bf16 ones (gemm.hip.h, "x2h"): the
+// LDS tile then holds the activations times SA, the mirror the weights times kH2WScale, and the accumulators come out
+// scaled by the product — undone by the fma that adds the bias.
+template <int TI, bool SAVE, int NW = 4, bool X3 = false, bool H2 = false>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_forward_kernel(FusedFwdArgs g) {
+  static_assert(!H2 || X3, "x2h is a form of the split-operand path");
+  constexpr float SA = H2 ? kH2ActScale : 1.f;                         // scale of the activations in LDS
+  constexpr float ISA = 1.f / SA;
+  constexpr float INV = H2 ? 1.f / (kH2ActScale * kH2WScale) : 1.f;    // accumulator -> pre-activation
+  constexpr int WP = H2 ? 2 : 3;                                       // planes of the weight mirror
   constexpr int FT = 32 * TI;
   constexpr int NT = 64 * NW;     // threads
   constexpr int TJ = 8 / NW;      // 32-column tiles per wave
@@ -67,7 +75,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_forward_kernel
     float* xr = X + p * FP;
     float* er = E + p * FEP;
     if (part == 0) {
-      xr[0] = x[0]; xr[1] = x[1]; xr[2] = x[2];
+      xr[0] = x[0] * SA; xr[1] = x[1] * SA; xr[2] = x[2] * SA;
       er[0] = x[0]; er[1] = x[1]; er[2] = x[2];
       for (int c = g.pe; c < g.Ep; ++c) xr[c] = 0.f;
       if (SAVE) {
@@ -81,7 +89,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_forward_kernel
         float s, co;
         sincosf(x[d] * f, &s, &co);
         const int c = 3 + 6 * k + d;
-        xr[c] = s; xr[c + 3] = co;
+        xr[c] = s * SA; xr[c + 3] = co * SA;
         er[c] = s; er[c + 3] = co;
       }
     }
@@ -90,18 +98,18 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_forward_kernel
   if (SAVE) {   // e is an operand of the backward (dW of layer 0) and of the R sweep: FT x Ep floats
     for (int idx = tid; idx < FT * g.Ep; idx += NT) {
       const int r = idx / g.Ep, c = idx - r * g.Ep;
-      g.e[(row0 + r) * g.Ep + c] = X[r * FP + c];
+      g.e[(row0 + r) * g.Ep + c] = X[r * FP + c] * ISA;
     }
   }
 
   const int h = lane >> 5, cl = lane & 31;
   v16f acc[TI][TJ];
-  [[maybe_unused]] X3Mma<TI, TJ> mm;
-  if constexpr (X3) mm.request(g.w3 + 3 * g.w_off[0], g.Kp[0], n0, lane);
+  [[maybe_unused]] X3Mma<TI, TJ, WP> mm;
+  if constexpr (X3) mm.request(g.w3 + WP * g.w_off[0], g.Kp[0], n0, lane);
   for (int l = 0; l < g.nh; ++l) {
     if constexpr (X3) {   // the next product's first weight steps are requested before this layer's epilogue
-      const x3raw* wn = l + 1 < g.nh ? g.w3 + 3 * g.w_off[l + 1] : (g.with_feat ? g.w3 + 3 * g.wf_off : nullptr);
-      mm.run(X, g.w3 + 3 * g.w_off[l], g.Kp[l], n0, lane, acc, wn, FH, n0);
+      const x3raw* wn = l + 1 < g.nh ? g.w3 + WP * g.w_off[l + 1] : (g.with_feat ? g.w3 + WP * g.wf_off : nullptr);
+      mm.run(X, g.w3 + WP * g.w_off[l], g.Kp[l], n0, lane, acc, wn, FH, n0);
     } else layer_mma_nt<TI, NoHook, TJ>(X, g.packed + g.w_off[l], g.Kp[l], n0, lane, acc);
     if constexpr (NBUF == 1) lds_barrier();   // every wave has finished reading the input activations
     const float* bias = g.packed + g.b_off[l];
@@ -129,15 +137,17 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_forward_kernel
           const int rowc = ti * 32 + (r & 3) + 8 * (r >> 2);   // compile-time part of the row
           const int row = rowc + 4 * h;
           vf2 a, D;
-          if constexpr (SAVE) softplus_aD_sel<X3 && RNB_X3_SCALAR_EPI>(vf2{acc[ti][tj][r] + bc, acc[ti][tj][r + 1] + bc}, a, D);
-          else a = softplus_a_sel<X3 && RNB_X3_SCALAR_EPI>(vf2{acc[ti][tj][r] + bc, acc[ti][tj][r + 1] + bc});
+          const vf2 z = H2 ? vf2{__builtin_fmaf(acc[ti][tj][r], INV, bc), __builtin_fmaf(acc[ti][tj][r + 1], INV, bc)}
+                           : vf2{acc[ti][tj][r] + bc, acc[ti][tj][r + 1] + bc};
+          if constexpr (SAVE) softplus_aD_sel<X3 && RNB_X3_SCALAR_EPI>(z, a, D);
+          else a = softplus_a_sel<X3 && RNB_X3_SCALAR_EPI>(z);
           if (!tile_full && col >= n_real) {   // only the tile straddling the skip connection's PE columns
             const bool pe_col = pe_tail && col < n_real + g.pe;
             a = vf2{pe_col ? E[row * FEP + (col - n_real)] : 0.f, pe_col ? E[(row + 1) * FEP + (col - n_real)] : 0.f};
             D = vf2{0.f, 0.f};
           }
-          Y[row * FP + col] = a.x;
-          Y[(row + 1) * FP + col] = a.y;
+          Y[row * FP + col] = a.x * SA;
+          Y[(row + 1) * FP + col] = a.y * SA;
           if (SAVE) {
             bstore(ra, voff, rowc * FH * 4, a.x);
             bstore(ra, voff, (rowc + 1) * FH * 4, a.y);
@@ -170,7 +180,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_forward_kernel
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
       if (lane == 0) {
-        const float v = (s + bs) / g.scale;
+        const float v = (H2 ? __builtin_fmaf(s, ISA, bs) : s + bs) / g.scale;
         if (!g.grid.on) g.sdf[row0 + row] = v;
         else if (row0 + row < g.M) g.sdf[row0 + row] = v * g.grid.out_scale;   // the volume has exactly M entries
       }
@@ -178,7 +188,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_forward_kernel
   }
   // ---- feature head: rows 1.. of the output layer, written into the albedo network's input ------------
   if (g.with_feat) {
-    if constexpr (X3) mm.run(X, g.w3 + 3 * g.wf_off, FH, n0, lane, acc, nullptr, 0, 0);   // (requested by the last hidden layer)
+    if constexpr (X3) mm.run(X, g.w3 + WP * g.wf_off, FH, n0, lane, acc, nullptr, 0, 0);   // (requested by the last hidden layer)
     else layer_mma_nt<TI, NoHook, TJ>(X, g.packed + g.wf_off, FH, n0, lane, acc);
     const float* bias = g.packed + g.bf_off;
     const BufRsrc rc = tile_rsrc(g.cin + (size_t)row0 * g.Cinp, FT * g.Cinp * 4);
@@ -194,7 +204,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_forward_kernel
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int rowc = ti * 32 + (r & 3) + 8 * (r >> 2);
-            bstore(rc, voff, rowc * rowb, acc[ti][tj][r] + bc);
+            bstore(rc, voff, rowc * rowb, H2 ? __builtin_fmaf(acc[ti][tj][r], INV, bc) : acc[ti][tj][r] + bc);
           }
         }
       }
@@ -229,6 +239,25 @@ __global__ void x3_pack_kernel(const float* __restrict__ src, X3Table t, x3raw* 
   *reinterpret_cast<vu4x*>(dp + 512) = mid;
   *reinterpret_cast<vu4x*>(dp + 1024) = lo;
 }
+// the fp16 mirror of the forward-type kernels (x2h): same fragments, two planes, weights times kH2WScale
+__global__ void x2h_pack_kernel(const float* __restrict__ src, X3Table t, x3raw* __restrict__ dst) {
+  const int u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= t.total_units) return;
+  int ei = 0;
+  while (ei + 1 < t.n && u >= t.e[ei + 1].unit_begin) ++ei;
+  const X3Entry en = t.e[ei];
+  const int lu = u - en.unit_begin;
+  const int frag = lu >> 6, lane = lu & 63;
+  const int nks = en.K >> 4;
+  const int nt = frag / nks, ks = frag - nt * nks;
+  const int c = lane & 31, h = lane >> 5;
+  const float* sp = src + en.off + (size_t)(nt * 32 + c) * en.K + ks * 16 + h * (en.tperm ? 4 : 8);
+  vu4x hi, lo;
+  x2h_split8(*reinterpret_cast<const vf4*>(sp) * kH2WScale, *reinterpret_cast<const vf4*>(sp + (en.tperm ? 8 : 4)) * kH2WScale, hi, lo);
+  x3raw* dp = dst + 2 * en.off + ((size_t)frag * 2 * 64 + lane) * 8;
+  *reinterpret_cast<vu4x*>(dp) = hi;
+  *reinterpret_cast<vu4x*>(dp + 512) = lo;
+}
 int x3_pack_weights(const Layout& L, float* packed, hipStream_t s) {
   x3raw* dst = reinterpret_cast<x3raw*>(packed + L.total);
   X3Table t;
@@ -254,6 +283,26 @@ int x3_pack_weights(const Layout& L, float* packed, hipStream_t s) {
   }
   hipLaunchKernelGGL(x3_pack_kernel, dim3((unsigned)((t.total_units + 255) / 256)), dim3(256), 0, s, packed, t, dst);
   RNB_CHECK_LAUNCH();
+  if (is_x2h(L)) {   // what the forward-type products read: W of both networks (F sweeps, albedo forward), W^T of the SDF net (R sweep)
+    X3Table th;
+    th.n = 0;
+    th.total_units = 0;
+    for (int q = 0; q < t.n; ++q) {
+      const X3Entry& e = t.e[q];
+      bool fwd = false;
+      for (int l = 0; l < L.nh; ++l) fwd = fwd || e.off == L.hid[l].w_off || e.off == L.hid[l].wT_off;
+      fwd = fwd || (L.F > 0 && e.off == L.feat.w_off);
+      for (int l = 0; l < L.nc; ++l) fwd = fwd || e.off == L.col[l].w_off;   // the albedo network's forward layers
+      if (!fwd) continue;
+      X3Entry& d = th.e[th.n++];
+      d = e;
+      d.unit_begin = th.total_units;
+      th.total_units += e.N * e.K / 8;
+    }
+    hipLaunchKernelGGL(x2h_pack_kernel, dim3((unsigned)((th.total_units + 255) / 256)), dim3(256), 0, s, packed, th,
+                       x2h_mirror(L, packed));
+    RNB_CHECK_LAUNCH();
+  }
   return RNB_OK;
 }
 
@@ -277,7 +326,8 @@ int fused_forward(const Layout& L, const float* packed, const float* pts, int64_
   g.pts = pts;
   g.M = M;
   g.packed = packed;
-  g.w3 = reinterpret_cast<const x3raw*>(packed + L.total);
+  const bool h2 = is_x2h(L);
+  g.w3 = h2 ? x2h_mirror(L, packed) : reinterpret_cast<const x3raw*>(packed + L.total);
   g.nh = L.nh;
   g.skip = L.skip;
   g.pe = L.pe;
@@ -321,7 +371,12 @@ int fused_forward(const Layout& L, const float* packed, const float* pts, int64_
   if (small) {
     const unsigned blocks = (unsigned)(pb.Mp / 32);
     const bool wide = force_nw ? (force_nw == 2) : (blocks <= 256);   // at most one workgroup per CU
-    if (x3) {
+    if (h2) {
+      if (save && wide) hipLaunchKernelGGL((fused_forward_kernel<1, true, 8, true, true>), dim3(blocks), dim3(512), 0, s, g);
+      else if (save) hipLaunchKernelGGL((fused_forward_kernel<1, true, 4, true, true>), dim3(blocks), dim3(256), 0, s, g);
+      else if (wide) hipLaunchKernelGGL((fused_forward_kernel<1, false, 8, true, true>), dim3(blocks), dim3(512), 0, s, g);
+      else hipLaunchKernelGGL((fused_forward_kernel<1, false, 4, true, true>), dim3(blocks), dim3(256), 0, s, g);
+    } else if (x3) {
       if (save && wide) hipLaunchKernelGGL((fused_forward_kernel<1, true, 8, true>), dim3(blocks), dim3(512), 0, s, g);
       else if (save) hipLaunchKernelGGL((fused_forward_kernel<1, true, 4, true>), dim3(blocks), dim3(256), 0, s, g);
       else if (wide) hipLaunchKernelGGL((fused_forward_kernel<1, false, 8, true>), dim3(blocks), dim3(512), 0, s, g);
@@ -332,7 +387,10 @@ int fused_forward(const Layout& L, const float* packed, const float* pts, int64_
     else hipLaunchKernelGGL((fused_forward_kernel<1, false>), dim3(blocks), dim3(256), 0, s, g);
   } else {
     const unsigned blocks = (unsigned)(pb.Mp / 64);
-    if (x3) {
+    if (h2) {
+      if (save) hipLaunchKernelGGL((fused_forward_kernel<2, true, 4, true, true>), dim3(blocks), dim3(256), 0, s, g);
+      else hipLaunchKernelGGL((fused_forward_kernel<2, false, 4, true, true>), dim3(blocks), dim3(256), 0, s, g);
+    } else if (x3) {
       if (save) hipLaunchKernelGGL((fused_forward_kernel<2, true, 4, true>), dim3(blocks), dim3(256), 0, s, g);
       else hipLaunchKernelGGL((fused_forward_kernel<2, false, 4, true>), dim3(blocks), dim3(256), 0, s, g);
     } else if (save) hipLaunchKernelGGL((fused_forward_kernel<2, true>), dim3(blocks), dim3(256), 0, s, g);

@@ -114,17 +114,17 @@ __device__ inline void prefetch_tile(const float* base, int64_t row0, int n0, in
 // matrix loop of one layer (weights at float offset `off` of the packed buffer): two alternating weight-register
 // sets, except for 64-point tiles with 64-column waves, which use the one-set ring (register budget).  X3: the same
 // product as six bf16 MFMA terms per 16 k (fused_common.hip.h).
-template <int TI, int TJ = 2, bool X3 = false, class Hook = NoHook>
+template <int TI, int TJ = 2, bool X3 = false, class Hook = NoHook, int NP = 3>
 __device__ inline void layer_mma(const float* __restrict__ X, const FusedBwdArgs& g, long long off, int K, int n0, int lane,
-                                 v16f (&acc)[TI][TJ], X3Mma<TI, TJ>& mm, long long off_next, Hook hook = Hook(),
+                                 v16f (&acc)[TI][TJ], X3Mma<TI, TJ, NP>& mm, long long off_next, Hook hook = Hook(),
                                  int hook_late = 0) {
   // X3: this product's first weight steps were requested through `mm` (before the previous epilogue); off_next >= 0
   // names the product that follows (K = 256), whose first steps are requested as this one finishes
   // (64 x 64-output waves keep no weight registers across the epilogue: its two operand tiles need them)
   if constexpr (X3 && TI == 2 && TJ == 2) {
-    mm.request(g.w3 + 3 * off, K, n0, lane);
-    mm.run(X, g.w3 + 3 * off, K, n0, lane, acc, nullptr, 0, 0, hook);
-  } else if constexpr (X3) mm.run(X, g.w3 + 3 * off, K, n0, lane, acc, off_next >= 0 ? g.w3 + 3 * off_next : nullptr, FH, n0, hook);
+    mm.request(g.w3 + NP * off, K, n0, lane);
+    mm.run(X, g.w3 + NP * off, K, n0, lane, acc, nullptr, 0, 0, hook);
+  } else if constexpr (X3) mm.run(X, g.w3 + NP * off, K, n0, lane, acc, off_next >= 0 ? g.w3 + NP * off_next : nullptr, FH, n0, hook);
   else if constexpr (TI == 2 && TJ == 2) layer_mma_nt_ring<TI>(X, g.packed + off, K, n0, lane, acc, hook);
   else layer_mma_nt<TI, Hook, TJ>(X, g.packed + off, K, n0, lane, acc, hook, hook_late);
 }
@@ -132,8 +132,15 @@ __device__ inline void layer_mma(const float* __restrict__ X, const FusedBwdArgs
 // ---------------------------------------------------------------------------------------------------------
 // R sweep
 // ---------------------------------------------------------------------------------------------------------
-template <int TI, int NW = 4, bool X3 = false>
+// H2 (with X3): the products as three fp16 terms (gemm.hip.h, "x2h"); the LDS tile then holds gz times SG and g.w3 is the
+// fp16 mirror.  The operands are Jacobian rows of the SDF (d sdf / d a_l: bounded by the network's Lipschitz constant,
+// |.| < 1023 assumed like the activations), not loss adjoints: a fixed scale serves.
+template <int TI, int NW = 4, bool X3 = false, bool H2 = false>
 __global__ __launch_bounds__(64 * NW, (NW == 8 && TI == 2) ? 1 : 2) void fused_reverse_kernel(FusedBwdArgs g) {
+  static_assert(!H2 || X3, "x2h is a form of the split-operand path");
+  constexpr float SG = H2 ? kH2ActScale : 1.f;
+  constexpr float INV = H2 ? 1.f / (kH2ActScale * kH2WScale) : 1.f;
+  constexpr int WP = H2 ? 2 : 3;
   constexpr int BT = 32 * TI;
   constexpr int NT = 64 * NW;   // threads
   constexpr int TJ = 8 / NW;    // 32-column tiles per wave
@@ -159,7 +166,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TI == 2) ? 1 : 2) void fused_r
       const vf4 d = *reinterpret_cast<const vf4*>(Dl + r * FH + c4 * 4);
       const vf4 w = *reinterpret_cast<const vf4*>(ws + c4 * 4);
       const vf4 v = d * w;
-      *reinterpret_cast<vf4*>(X + r * FP + c4 * 4) = v;
+      *reinterpret_cast<vf4*>(X + r * FP + c4 * 4) = v * SG;
       *reinterpret_cast<vf4*>(gzl + r * FH + c4 * 4) = v;
     }
     for (int idx = tid; idx < BT * FEP; idx += NT) GE[idx] = 0.f;
@@ -168,9 +175,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TI == 2) ? 1 : 2) void fused_r
 
   v16f acc[TI][TJ];
   AuxTile<TI, TJ> aD;
-  [[maybe_unused]] X3Mma<TI, TJ> mm;
+  [[maybe_unused]] X3Mma<TI, TJ, WP> mm;
   if constexpr (X3 && !(TI == 2 && TJ == 2)) {
-    if (g.nh > 1 || n0 < 64) mm.request(g.w3 + 3 * g.wT_off[g.nh - 1], FH, n0, lane);
+    if (g.nh > 1 || n0 < 64) mm.request(g.w3 + WP * g.wT_off[g.nh - 1], FH, n0, lane);
   }
   for (int l = g.nh - 1; l >= 1; --l) {
     const long long nxt = (l > 1 || n0 < 64) ? g.wT_off[l - 1] : -1;   // layer 0's product: the waves of columns 0..63
@@ -189,12 +196,12 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TI == 2) ? 1 : 2) void fused_r
     for_each_acc_split<TI, TJ>(
         n0, lane_e, ksplit,
         [&](int tj, int ti, int r, int col, int rowc, int row) {
-          const float gzv = acc[ti][tj][r] * aD.v[ti][tj][r];
-          Y[row * FP + col] = gzv;
+          const float gzv = acc[ti][tj][r] * INV * aD.v[ti][tj][r];
+          Y[row * FP + col] = gzv * SG;
           bstore(rg, (unsigned)(4 * h * FH + col) * 4u, rowc * FH * 4, gzv);
         },
         [&](int tj, int ti, int r, int col, int rowc, int row) {
-          const float v = acc[ti][tj][r];
+          const float v = acc[ti][tj][r] * INV;
           float gzv;
           if (col < ksplit) {
             gzv = v * aD.v[ti][tj][r];
@@ -202,7 +209,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TI == 2) ? 1 : 2) void fused_r
             if (col < ksplit + g.pe) GE[row * FEP + (col - ksplit)] = v;   // skip connection: straight to g_e
             gzv = 0.f;
           }
-          Y[row * FP + col] = gzv;
+          Y[row * FP + col] = gzv * SG;
           bstore(rg, (unsigned)(4 * h * FH + col) * 4u, rowc * FH * 4, gzv);
         });
     lds_barrier();
@@ -212,7 +219,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TI == 2) ? 1 : 2) void fused_r
   if (n0 < 64) {
     layer_mma<TI, TJ, X3>(X, g, g.wT_off[0], FH, n0, lane, acc, mm, -1);
     for_each_acc<TI, TJ>(n0, lane, [&](int tj, int ti, int r, int col, int rowc, int row) {
-      if (col < g.pe) GE[row * FEP + col] += acc[ti][tj][r];
+      if (col < g.pe) GE[row * FEP + col] += acc[ti][tj][r] * INV;
     });
   }
   __syncthreads();
@@ -491,7 +498,13 @@ int fused_reverse(const Layout& L, const float* packed, PointBufs& pb, hipStream
   ProfScope prof(hidden_flops(L, pb.M, 0), s, "R_sweep");
   const int ti = bwd_ti(L, is_x3(L) ? 2 : 1), nw = bwd_nw(L, is_x3(L) ? 4 : 8);
   const dim3 grid((unsigned)(pb.Mp / (32 * ti))), block(64 * nw);
-  if (is_x3(L)) {
+  if (is_x2h(L)) {
+    g.w3 = x2h_mirror(L, packed);
+    if (ti == 2 && nw == 8) hipLaunchKernelGGL((fused_reverse_kernel<2, 8, true, true>), grid, block, 0, s, g);
+    else if (ti == 2) hipLaunchKernelGGL((fused_reverse_kernel<2, 4, true, true>), grid, block, 0, s, g);
+    else if (nw == 8) hipLaunchKernelGGL((fused_reverse_kernel<1, 8, true, true>), grid, block, 0, s, g);
+    else hipLaunchKernelGGL((fused_reverse_kernel<1, 4, true, true>), grid, block, 0, s, g);
+  } else if (is_x3(L)) {
     if (ti == 2 && nw == 8) hipLaunchKernelGGL((fused_reverse_kernel<2, 8, true>), grid, block, 0, s, g);
     else if (ti == 2) hipLaunchKernelGGL((fused_reverse_kernel<2, 4, true>), grid, block, 0, s, g);
     else if (nw == 8) hipLaunchKernelGGL((fused_reverse_kernel<1, 8, true>), grid, block, 0, s, g);

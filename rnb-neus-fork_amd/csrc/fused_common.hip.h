@@ -16,7 +16,8 @@ struct FusedFwdArgs {
   const float* pts;     // [M,3]
   int64_t M;
   const float* packed;
-  const x3raw* w3;      // RNB_VARIANT_X3: split mirror of the weight matrices (matrix at 3 x its float offset)
+  const x3raw* w3;      // RNB_VARIANT_X3: split mirror of the weight matrices (matrix at 3 x its float offset;
+                        // the fp16 mirror of the x2h kernels: at 2 x)
   int nh, skip, pe, multires, Ep;
   float scale;
   int n_real[RNB_MAX_LIN];
@@ -197,15 +198,15 @@ __device__ inline void layer_mma_nt_ring(const float* __restrict__ X, const floa
 // Activations stay fp32 in LDS and are split as they are read.
 // (buffer loads: per-lane offset lane * 16 in one VGPR, the fragment's offset in the scalar operand, the plane in the
 // immediate — plain pointer arithmetic cost five 64-bit vector adds per step in front of the loads)
-template <int TJ>
-__device__ inline void x3_load_b(const x3raw* __restrict__ W3, int nks, int n0, int ks, int lane, vu4x (&b)[TJ][3]) {
+template <int TJ, int NP = 3>
+__device__ inline void x3_load_b(const x3raw* __restrict__ W3, int nks, int n0, int ks, int lane, vu4x (&b)[TJ][NP]) {
   const BufRsrc rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<x3raw*>(W3), 0, 0x4000000, 0x00020000);
   const unsigned voff = (unsigned)lane * 16u;
 #pragma unroll
   for (int tj = 0; tj < TJ; ++tj) {
-    const unsigned soff = (unsigned)(((n0 >> 5) + tj) * nks + ks) * 3072u;
+    const unsigned soff = (unsigned)(((n0 >> 5) + tj) * nks + ks) * (NP * 1024u);
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
+    for (int pl = 0; pl < NP; ++pl)
       b[tj][pl] = __builtin_bit_cast(vu4x, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff + pl * 1024, 0));
   }
 }
@@ -217,22 +218,22 @@ __device__ inline void x3_read_a(const float* __restrict__ xp, int ks, vf4 (&a)[
     a[ti][1] = *reinterpret_cast<const vf4*>(xp + ti * 32 * FP + ks * 16 + 8);   //     16 ks + 4 h + 8..11  (the mirror's order)
   }
 }
-template <int TI>
-__device__ inline void x3_split(const vf4 (&raw)[TI][2], vu4x (&a)[TI][3]) {
+template <int TI, int NP = 3>
+__device__ inline void x3_split(const vf4 (&raw)[TI][2], vu4x (&a)[TI][NP]) {
 #pragma unroll
-  for (int ti = 0; ti < TI; ++ti) x3_split8(raw[ti][0], raw[ti][1], a[ti][0], a[ti][1], a[ti][2]);
+  for (int ti = 0; ti < TI; ++ti) xn_split8<NP>(raw[ti][0], raw[ti][1], a[ti]);
 }
 // One pipeline stage: the MFMAs of step s (operands `a`, `b`) with, between them, the split of step s + 1's rows
 // (`raw` -> `an`): the bf16 MFMA leaves about four vector-instruction issue slots free per instruction
 // (tools/overlap_probe), which is where the 36 TI split instructions go.  Then the raw rows of step s + 2 are
 // requested into `raw` (the caller clamps the step index: no branch inside the pipeline, the last re-read is unused).
-template <int TI, int TJ, bool FIRST>
+template <int TI, int TJ, bool FIRST, int NP = 3>
 __device__ inline void x3_stage(const float* __restrict__ xp, int ks_next_raw, vf4 (&raw)[TI][2],
-                                const vu4x (&a)[TI][3], vu4x (&an)[TI][3], const vu4x (&b)[TJ][3], v16f (&acc)[TI][TJ]) {
-  x3_mfma<TI, TJ, FIRST>(a, b, acc);
-  x3_split<TI>(raw, an);
-  constexpr int NM = 6 * TI * TJ;
-  constexpr int PER = (36 * TI + NM - 1) / NM;   // vector instructions behind each MFMA
+                                const vu4x (&a)[TI][NP], vu4x (&an)[TI][NP], const vu4x (&b)[TJ][NP], v16f (&acc)[TI][TJ]) {
+  x3_mfma<TI, TJ, FIRST, NP>(a, b, acc);
+  x3_split<TI, NP>(raw, an);
+  constexpr int NM = (NP == 3 ? 6 : 3) * TI * TJ;
+  constexpr int PER = ((NP == 3 ? 36 : 16) * TI + NM - 1) / NM;   // vector instructions behind each MFMA
 #pragma unroll
   for (int m = 0; m < NM; ++m) {
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA
@@ -248,12 +249,14 @@ __device__ inline void x3_stage(const float* __restrict__ xp, int ks_next_raw, v
 // The weight fragments of steps 0 and 1 are REQUESTED by the caller (`request`) — for the next layer's product before
 // the epilogue of this one, so that they land during the epilogue instead of costing an exposed L2 round trip (and, the
 // memory counter retiring in order, a wait for the epilogue's stores) at the top of every layer.
-template <int TI, int TJ = 2>
+// NP = 3: the bf16 scheme (mirror: three planes per fragment); NP = 2: the fp16 scheme (x2h: two planes; X holds the
+// activations times kH2ActScale, the mirror the weights times kH2WScale, acc comes out scaled by their product).
+template <int TI, int TJ = 2, int NP = 3>
 struct X3Mma {
-  vu4x b0[TJ][3], b1[TJ][3];
+  vu4x b0[TJ][NP], b1[TJ][NP];
   __device__ inline void request(const x3raw* __restrict__ W3, int K, int n0, int lane) {
-    x3_load_b<TJ>(W3, K >> 4, n0, 0, lane, b0);
-    x3_load_b<TJ>(W3, K >> 4, n0, 1, lane, b1);
+    x3_load_b<TJ, NP>(W3, K >> 4, n0, 0, lane, b0);
+    x3_load_b<TJ, NP>(W3, K >> 4, n0, 1, lane, b1);
   }
   // W3n / Kn / n0n: the product that follows (nullptr: none); its first two weight steps are requested as soon as the
   // registers are free
@@ -263,32 +266,32 @@ struct X3Mma {
     const int i = lane & 31, h = lane >> 5;
     const float* xp = X + i * FP + h * 4;   // (k order of the SDF mirror: x3_pack_kernel, tperm)
     const int nks = K >> 4;   // even
-    vu4x a0[TI][3], a1[TI][3];
+    vu4x a0[TI][NP], a1[TI][NP];
     vf4 raw[TI][2];
     x3_read_a<TI>(xp, 0, raw);
-    x3_split<TI>(raw, a0);
+    x3_split<TI, NP>(raw, a0);
     x3_read_a<TI>(xp, 1, raw);
     __builtin_amdgcn_sched_barrier(0);
     const int last = nks - 1;
     // the matrix loop outranks the other workgroup's epilogue on this SIMD: its MFMAs and the split between them then never
     // queue behind the epilogue's vector work (3.97 -> 3.92 ms per step, two runs each on one box)
     __builtin_amdgcn_s_setprio(1);
-    x3_stage<TI, TJ, true>(xp, min(2, last), raw, a0, a1, b0, acc);   // step 0 (splits step 1)
+    x3_stage<TI, TJ, true, NP>(xp, min(2, last), raw, a0, a1, b0, acc);   // step 0 (splits step 1)
     hook();
     for (int ks = 1; ks + 1 < nks; ks += 2) {   // (nks even: ks + 2 <= last inside the loop)
-      x3_load_b<TJ>(W3, nks, n0, ks + 1, lane, b0);
+      x3_load_b<TJ, NP>(W3, nks, n0, ks + 1, lane, b0);
       __builtin_amdgcn_sched_barrier(0);
-      x3_stage<TI, TJ, false>(xp, ks + 2, raw, a1, a0, b1, acc);
-      x3_load_b<TJ>(W3, nks, n0, ks + 2, lane, b1);
+      x3_stage<TI, TJ, false, NP>(xp, ks + 2, raw, a1, a0, b1, acc);
+      x3_load_b<TJ, NP>(W3, nks, n0, ks + 2, lane, b1);
       __builtin_amdgcn_sched_barrier(0);
-      x3_stage<TI, TJ, false>(xp, min(ks + 3, last), raw, a0, a1, b0, acc);
+      x3_stage<TI, TJ, false, NP>(xp, min(ks + 3, last), raw, a0, a1, b0, acc);
     }
-    if (W3n) x3_load_b<TJ>(W3n, Kn >> 4, n0n, 0, lane, b0);
+    if (W3n) x3_load_b<TJ, NP>(W3n, Kn >> 4, n0n, 0, lane, b0);
     __builtin_amdgcn_sched_barrier(0);
-    x3_mfma<TI, TJ, false>(a1, b1, acc);   // the last step: nothing left to split
+    x3_mfma<TI, TJ, false, NP>(a1, b1, acc);   // the last step: nothing left to split
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(0);
-    if (W3n) x3_load_b<TJ>(W3n, Kn >> 4, n0n, 1, lane, b1);
+    if (W3n) x3_load_b<TJ, NP>(W3n, Kn >> 4, n0n, 1, lane, b1);
   }
 };
 template <int TI, int TJ = 2, class Hook = NoHook>

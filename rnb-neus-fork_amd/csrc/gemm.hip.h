@@ -347,25 +347,72 @@ __device__ inline void x3_split8(const vf4& x0, const vf4& x1, vu4x& hi, vu4x& m
     lo[p] = x3_pack2(sa, sb);
   }
 }
-// the six terms of one 16-k step, small ones first, the (ti, tj) accumulators in rotation
-template <int TI, int TJ, bool FIRST>
-__device__ inline void x3_mfma(const vu4x (&a)[TI][3], const vu4x (&b)[TJ][3], v16f (&acc)[TI][TJ]) {
-  constexpr int PA[6] = {2, 0, 1, 1, 0, 0};   // a_lo b_hi, a_hi b_lo, a_mid b_mid, a_mid b_hi, a_hi b_mid, a_hi b_hi
-  constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+// ---- "x2h": the same idea on the fp16 matrix pipe with TWO planes and THREE terms ----------------------------------
+// xs = x * S (S a power of two: exact), hi = fp16(xs), lo = fp16(xs - hi): two 11-bit roundings, |xs - hi - lo| <= 2^-22 |xs|
+// (rms 2^-23.6: about four times the rounding noise of storing x in fp32 at all) as long as lo is a normal fp16 number
+// (|xs| >= 2^-3), and <= 2^-25 absolutely below that; hi overflows at |xs| >= 65520.  a b is taken as
+// a_hi b_hi + a_hi b_lo + a_lo b_hi (the dropped a_lo b_lo is below 2^-22 |a b|), at HALF the matrix time of the six bf16
+// terms.  These per-product errors are independent and far below what the fp32 accumulation of a K = 256 dot product
+// commits (2.7 ulp rms, profiles/r04_sdf_bias.txt): measured on the full network, the SDF comes out closer to fp64 than
+// with the six bf16 terms (rms 8.3e-8 against 1.07e-7, profiles/r04_x2h_check.txt).  What bf16 gave for free — range — is
+// bought with the scales: operands whose magnitudes are known a priori only (weights: S = 2^8, |w| < 255; activations and
+// the reverse sweep's Jacobian rows: S = 2^6, |a| < 1023).  Out-of-range operands give inf / NaN results, never silently
+// wrong ones.  The adjoints of the backward sweeps span too many binades for a fixed scale: they stay on the bf16 scheme.
+typedef _Float16 x2h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 x2h2 __attribute__((ext_vector_type(2)));
+constexpr float kH2ActScale = 64.f, kH2WScale = 256.f;
+__device__ inline unsigned x2h_pack2(float a, float b) {
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f2{a, b}, x2h2));   // v_cvt_pk_f16_f32, round to nearest even
+}
+// x - (float)(low / high half of h) in one instruction (v_fma_mix_f32 reads the fp16 half directly)
+__device__ inline float x2h_resid_lo(float x, unsigned h) {
+  float r;
+  asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(x), "v"(h));
+  return r;
+}
+__device__ inline float x2h_resid_hi(float x, unsigned h) {
+  float r;
+  asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(x), "v"(h));
+  return r;
+}
+// 8 consecutive k of one row (already scaled) -> hi / lo operand registers: 4 instructions per pair
+__device__ inline void x2h_split8(const vf4& x0, const vf4& x1, vu4x& hi, vu4x& lo) {
+  const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
 #pragma unroll
-  for (int t = 0; t < 6; ++t)
+  for (int p = 0; p < 4; ++p) {
+    const unsigned uh = x2h_pack2(x[2 * p], x[2 * p + 1]);
+    hi[p] = uh;
+    lo[p] = x2h_pack2(x2h_resid_lo(x[2 * p], uh), x2h_resid_hi(x[2 * p + 1], uh));
+  }
+}
+// planes -> operand registers of one row, either scheme
+template <int NP>
+__device__ inline void xn_split8(const vf4& x0, const vf4& x1, vu4x (&p)[NP]) {
+  if constexpr (NP == 3) x3_split8(x0, x1, p[0], p[1], p[2]);
+  else x2h_split8(x0, x1, p[0], p[1]);
+}
+// the six (three) terms of one 16-k step, small ones first, the (ti, tj) accumulators in rotation
+template <int TI, int TJ, bool FIRST, int NP = 3>
+__device__ inline void x3_mfma(const vu4x (&a)[TI][NP], const vu4x (&b)[TJ][NP], v16f (&acc)[TI][TJ]) {
+  constexpr int NT = NP == 3 ? 6 : 3;
+  // NP == 3: a_lo b_hi, a_hi b_lo, a_mid b_mid, a_mid b_hi, a_hi b_mid, a_hi b_hi;  NP == 2: a_lo b_hi, a_hi b_lo, a_hi b_hi
+  constexpr int PA[6] = {NP == 3 ? 2 : 1, 0, NP == 3 ? 1 : 0, 1, 0, 0};
+  constexpr int PB[6] = {0, NP == 3 ? 2 : 1, NP == 3 ? 1 : 0, 0, 1, 0};
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int tj = 0; tj < TJ; ++tj)
 #pragma unroll
       for (int ti = 0; ti < TI; ++ti) {
-        if (FIRST && t == 0) {
-          const v16f zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const v16f zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const v16f c = (FIRST && t == 0) ? zero : acc[ti][tj];
+        if constexpr (NP == 3)
           acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(x3bf8, a[ti][PA[t]]),
-                                                                __builtin_bit_cast(x3bf8, b[tj][PB[t]]), zero, 0, 0, 0);
-        } else {
-          acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(x3bf8, a[ti][PA[t]]),
-                                                                __builtin_bit_cast(x3bf8, b[tj][PB[t]]), acc[ti][tj], 0, 0, 0);
-        }
+                                                                __builtin_bit_cast(x3bf8, b[tj][PB[t]]), c, 0, 0, 0);
+        else
+          acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(x2h8, a[ti][PA[t]]),
+                                                               __builtin_bit_cast(x2h8, b[tj][PB[t]]), c, 0, 0, 0);
       }
 }
 
@@ -790,6 +837,15 @@ __device__ inline void x3_split4(const vf4& x, vu2x& hi, vu2x& mid, vu2x& lo) {
     lo[p] = x3_pack2(sa, sb);
   }
 }
+__device__ inline void x2h_split4(const vf4& x, vu2x& hi, vu2x& lo) {   // x already scaled
+  const float v[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const unsigned uh = x2h_pack2(v[2 * p], v[2 * p + 1]);
+    hi[p] = uh;
+    lo[p] = x2h_pack2(x2h_resid_lo(v[2 * p], uh), x2h_resid_hi(v[2 * p + 1], uh));
+  }
+}
 // ROWS x 16 k of a k-contiguous source -> ROWS / 64 float4 per thread (row idx >> 2, k quad idx & 3).  Buffer loads:
 // the thread's (row, k quad) offset is loop-invariant (one VGPR per float4), the k offset of the tile is scalar.
 template <int ROWS, bool GUARD>
@@ -904,12 +960,15 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_x3_kernel(const float* __res
 // (x3_pack_weights; one contiguous 1 KB per load, as in the fused sweeps), two steps ahead in registers.  One 8-wave
 // workgroup per 128 rows; wave w owns ALL 128 rows x the column tiles w and (TJ == 2) w + 8 — every weight fragment is
 // fetched once per workgroup, every activation split once.  N <= 32 * 8 * TJ, N % 32 == 0, K % 32 == 0.
-template <int TJ, class Epi>
+// NP = 2: the fp16 three-term form (x2h; forward layers: the inputs are activations of known range): W3 is then the
+// fp16 mirror (weights times kH2WScale), the rows are scaled by kH2ActScale as they are staged and the accumulators
+// rescaled before the epilogue.
+template <int TJ, class Epi, int NP = 3>
 __global__ __launch_bounds__(512, 1) void gemm_rows_x3m_kernel(const float* __restrict__ A, int lda,
                                                                const x3raw* __restrict__ W3, int N, int K, Epi epi) {
   constexpr int ROWS = 128;
   constexpr int PLB = ROWS * XP;              // bytes of one plane
-  constexpr int BUFB = 3 * PLB;               // one staging buffer (three planes): 18,432 B
+  constexpr int BUFB = NP * PLB;              // one staging buffer (three planes: 18,432 B)
   constexpr int STRIP = 16 * (32 + 4) * 4;    // epilogue strip of one wave (one 32-column tile at a time)
   __shared__ __attribute__((aligned(16))) char smem[2 * BUFB > 8 * STRIP ? 2 * BUFB : 8 * STRIP];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -929,12 +988,12 @@ __global__ __launch_bounds__(512, 1) void gemm_rows_x3m_kernel(const float* __re
   const char* const fa = smem + i * XP + h * 16;
   const BufRsrc rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<x3raw*>(W3), 0, 0x7ffffff0, 0x00020000);
   const unsigned boff = (unsigned)lane * 16u;
-  auto load_b = [&](int ks, vu4x (&b)[TJ][3]) {
+  auto load_b = [&](int ks, vu4x (&b)[TJ][NP]) {
 #pragma unroll
     for (int tj = 0; tj < TJ; ++tj) {
-      const unsigned soff = (unsigned)((on[tj] ? nt[tj] : 0) * nks + ks) * 3072u;
+      const unsigned soff = (unsigned)((on[tj] ? nt[tj] : 0) * nks + ks) * (NP * 1024u);
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl)
+      for (int pl = 0; pl < NP; ++pl)
         b[tj][pl] = __builtin_bit_cast(vu4x, __builtin_amdgcn_raw_buffer_load_b128(rsW, boff, soff + pl * 1024, 0));
     }
   };
@@ -942,12 +1001,19 @@ __global__ __launch_bounds__(512, 1) void gemm_rows_x3m_kernel(const float* __re
     return __builtin_bit_cast(vf4, __builtin_amdgcn_raw_buffer_load_b128(rsA, aoff, (unsigned)ks * 64u, RNB_AUX_LD));
   };
   auto stage = [&](const vf4& x, int buf) {
-    vu2x hi, mid, lo;
-    x3_split4(x, hi, mid, lo);
     char* w = swr + buf * BUFB;
-    *reinterpret_cast<vu2x*>(w) = hi;
-    *reinterpret_cast<vu2x*>(w + PLB) = mid;
-    *reinterpret_cast<vu2x*>(w + 2 * PLB) = lo;
+    if constexpr (NP == 3) {
+      vu2x hi, mid, lo;
+      x3_split4(x, hi, mid, lo);
+      *reinterpret_cast<vu2x*>(w) = hi;
+      *reinterpret_cast<vu2x*>(w + PLB) = mid;
+      *reinterpret_cast<vu2x*>(w + 2 * PLB) = lo;
+    } else {
+      vu2x hi, lo;
+      x2h_split4(x * kH2ActScale, hi, lo);
+      *reinterpret_cast<vu2x*>(w) = hi;
+      *reinterpret_cast<vu2x*>(w + PLB) = lo;
+    }
   };
   v16f acc[4][TJ];
 #pragma unroll
@@ -956,34 +1022,40 @@ __global__ __launch_bounds__(512, 1) void gemm_rows_x3m_kernel(const float* __re
     for (int tj = 0; tj < TJ; ++tj)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[ti][tj][r] = 0.f;
-  vu4x b0[TJ][3], b1[TJ][3];
+  vu4x b0[TJ][NP], b1[TJ][NP];
   load_b(0, b0);
   load_b(1, b1);
   vf4 x = load_a(0);
   stage(x, 0);
   x = load_a(1);
-  auto step = [&](int ks, vu4x (&b)[TJ][3]) {
+  auto step = [&](int ks, vu4x (&b)[TJ][NP]) {
     // buffer ks & 1 holds step ks (written before the barrier); buffer (ks + 1) & 1 was read in step ks - 1: free
     lds_barrier();
     stage(x, (ks + 1) & 1);                        // step ks + 1 (past the end: a harmless re-stage of the last step)
     x = load_a(min(ks + 2, nks - 1));
     const char* f = fa + (ks & 1) * BUFB;
-    vu4x a[4][3];
+    vu4x a[4][NP];
 #pragma unroll
     for (int ti = 0; ti < 4; ++ti)
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) a[ti][pl] = *reinterpret_cast<const vu4x*>(f + pl * PLB + ti * 32 * XP);
-    constexpr int PA[6] = {2, 0, 1, 1, 0, 0};   // small terms first (x3_mfma)
-    constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+      for (int pl = 0; pl < NP; ++pl) a[ti][pl] = *reinterpret_cast<const vu4x*>(f + pl * PLB + ti * 32 * XP);
+    constexpr int NT = NP == 3 ? 6 : 3;
+    constexpr int PA[6] = {NP == 3 ? 2 : 1, 0, NP == 3 ? 1 : 0, 1, 0, 0};   // small terms first (x3_mfma)
+    constexpr int PB[6] = {0, NP == 3 ? 2 : 1, NP == 3 ? 1 : 0, 0, 1, 0};
 #pragma unroll
     for (int tj = 0; tj < TJ; ++tj) {
       if (TJ == 2 && tj == 1 && !on[1]) continue;   // (wave-uniform)
 #pragma unroll
-      for (int t = 0; t < 6; ++t)
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int ti = 0; ti < 4; ++ti)
-          acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(x3bf8, a[ti][PA[t]]),
-                                                                __builtin_bit_cast(x3bf8, b[tj][PB[t]]), acc[ti][tj], 0, 0, 0);
+        for (int ti = 0; ti < 4; ++ti) {
+          if constexpr (NP == 3)
+            acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(x3bf8, a[ti][PA[t]]),
+                                                                  __builtin_bit_cast(x3bf8, b[tj][PB[t]]), acc[ti][tj], 0, 0, 0);
+          else
+            acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(x2h8, a[ti][PA[t]]),
+                                                                 __builtin_bit_cast(x2h8, b[tj][PB[t]]), acc[ti][tj], 0, 0, 0);
+        }
     }
     load_b(min(ks + 2, nks - 1), b);
   };
@@ -998,7 +1070,7 @@ __global__ __launch_bounds__(512, 1) void gemm_rows_x3m_kernel(const float* __re
     if (!on[tj]) continue;
     v16f t[4][1];
 #pragma unroll
-    for (int ti = 0; ti < 4; ++ti) t[ti][0] = acc[ti][tj];
+    for (int ti = 0; ti < 4; ++ti) t[ti][0] = NP == 3 ? acc[ti][tj] : acc[ti][tj] * (1.f / (kH2ActScale * kH2WScale));
     run_epilogue<1, Epi, 4>(t, strip, m_blk, nt[tj] * 32, lane, 1u, epi);
   }
 }

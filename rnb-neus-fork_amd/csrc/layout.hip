@@ -44,7 +44,7 @@ int make_layout(const rnb_model_desc* d, Layout* L) {
   if (d->sdf_multires < 0 || d->sdf_multires > 16) RNB_FAIL(RNB_E_INVALID, "bad sdf_multires");
   if (!(d->sdf_scale > 0.f)) RNB_FAIL(RNB_E_INVALID, "sdf_scale must be positive");
   L->variant = d->variant;
-  if (d->variant & ~0x3FF7F) RNB_FAIL(RNB_E_INVALID, "unknown bits in rnb_model_desc.variant (0x%x)", d->variant);
+  if (d->variant & ~0xFFF7F) RNB_FAIL(RNB_E_INVALID, "unknown bits in rnb_model_desc.variant (0x%x)", d->variant);
   L->nh = d->sdf_n_layers;
   L->multires = d->sdf_multires;
   L->pe = 3 * (1 + 2 * d->sdf_multires);
@@ -122,6 +122,13 @@ int make_layout(const rnb_model_desc* d, Layout* L) {
     L->variant |= RNB_VARIANT_X3;
   if (L->variant & RNB_VARIANT_X3)
     L->total_all = L->total + L->total / 2 * 3;   // hi / mid / lo bf16 mirror of the weights behind the fp32 ones
+  if ((d->variant & RNB_VARIANT_X2H) && (d->variant & RNB_VARIANT_NO_X2H))
+    RNB_FAIL(RNB_E_INVALID, "RNB_VARIANT_X2H and RNB_VARIANT_NO_X2H exclude each other");
+  if ((d->variant & RNB_VARIANT_X2H) && !(L->variant & RNB_VARIANT_X3))
+    RNB_FAIL(RNB_E_INVALID, "RNB_VARIANT_X2H is a form of the x3 path (256-wide SDF network, fp32)");
+  // forward-type sweeps of the x3 path: three fp16 terms unless switched off
+  if ((L->variant & RNB_VARIANT_X3) && !(d->variant & RNB_VARIANT_NO_X2H)) L->variant |= RNB_VARIANT_X2H;
+  if (L->variant & RNB_VARIANT_X2H) L->total_all += L->total;   // + hi / lo fp16 mirror (W and W^T of the SDF network used)
   return RNB_OK;
 }
 

@@ -616,9 +616,16 @@ static inline double mm_flops(int64_t M, const Lin& ln) { return 2.0 * (double)M
 // x3: the product as six bf16 MFMA terms (RNB_VARIANT_X3; k-contiguous weights, N >= 256, K % 16 == 0)
 template <bool B_KMAJOR, class Epi>
 static int launch_rows(const float* A, int lda, const float* W, int ldw, int64_t Mp, int N, int K, const Epi& epi,
-                       double flops, hipStream_t s, bool x3 = false, const x3raw* W3 = nullptr) {
-  ProfScope prof(flops, s, "layer_gemm");
+                       double flops, hipStream_t s, bool x3 = false, const x3raw* W3 = nullptr, const x3raw* Wh2 = nullptr) {
+  ProfScope prof(flops, s, Wh2 ? "layer_gemm(forward)" : "layer_gemm");
   if constexpr (!B_KMAJOR) {
+    // Wh2: this matrix in the fp16 mirror (x2h; forward layers only)
+    if (x3 && Wh2 != nullptr && N % 32 == 0 && N <= 512 && K % 32 == 0 && Mp % 128 == 0) {
+      if (N <= 256) hipLaunchKernelGGL((gemm_rows_x3m_kernel<1, Epi, 2>), dim3((unsigned)(Mp / 128)), dim3(512), 0, s, A, lda, Wh2, N, K, epi);
+      else hipLaunchKernelGGL((gemm_rows_x3m_kernel<2, Epi, 2>), dim3((unsigned)(Mp / 128)), dim3(512), 0, s, A, lda, Wh2, N, K, epi);
+      RNB_CHECK_LAUNCH();
+      return RNB_OK;
+    }
     // W3: this matrix in the split mirror (x3_pack_weights): the weights are then read as ready-made fragments
     if (x3 && W3 != nullptr && N % 32 == 0 && N <= 512 && K % 32 == 0 && Mp % 128 == 0) {
       if (N <= 256) hipLaunchKernelGGL((gemm_rows_x3m_kernel<1, Epi>), dim3((unsigned)(Mp / 128)), dim3(512), 0, s, A, lda, W3, N, K, epi);
@@ -1015,8 +1022,10 @@ int sweep_color(const Layout& L, const float* packed, PointBufs& pb, const float
     const float* in = l == 0 ? pb.cin : pb.ac[l - 1];
     const int lda = l == 0 ? L.Cinp : L.Hcp;
     EpiRelu epi{packed + ln.b_off, pb.ac[l], L.Hcp, ln.N};
+    // forward layers: inputs of known range (points, normals, features, relu outputs) -> the fp16 three-term form
+    const x3raw* wh2 = is_x2h(L) ? x2h_mirror(L, packed) + 2 * ln.w_off : nullptr;
     RNB_TRY((launch_rows<false, EpiRelu>(in, lda, packed + ln.w_off, ln.Kp, pb.Mp, ln.Np, ln.Kp, epi, mm_flops(pb.M, ln), s, is_x3(L),
-                                         x3_mirror(L, packed, ln.w_off))));
+                                         x3_mirror(L, packed, ln.w_off), wh2)));
   }
   hipLaunchKernelGGL(color_out_kernel, dim3(blocks_for(pb.Mp * 16, 256)), dim3(256), 0, s, pb.ac[L.nc - 1], L.Hcp,
                      L.Hc, packed + L.colo.w_off, L.colo.Kp, packed + L.colo.b_off, L.Co, L.squeeze, pb.Mp, pb.alb);

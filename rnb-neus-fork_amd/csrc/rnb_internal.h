@@ -194,6 +194,14 @@ int launch_scale_copy(const float* src, float scale, int64_t n, float* dst, hipS
 
 // ---- RNB_VARIANT_X3: fp32 products as six bf16 MFMA terms (fused_common.hip.h); the split weight mirror ----
 inline bool is_x3(const Layout& L) { return (L.variant & RNB_VARIANT_X3) != 0; }
+inline bool is_x2h(const Layout& L) { return is_x3(L) && (L.variant & RNB_VARIANT_X2H) != 0; }
+// the fp16 two-plane mirror (RNB_VARIANT_X2H) behind the three bf16 planes: matrix at 2 x its float offset, in 2-byte units
+inline unsigned short* x2h_mirror(const Layout& L, float* packed) {
+  return reinterpret_cast<unsigned short*>(packed + L.total + L.total / 2 * 3);
+}
+inline const unsigned short* x2h_mirror(const Layout& L, const float* packed) {
+  return reinterpret_cast<const unsigned short*>(packed + L.total + L.total / 2 * 3);
+}
 int x3_pack_weights(const Layout& L, float* packed, hipStream_t s);
 
 // ---- RNB_VARIANT_BF16 (bf16.hip): bf16-operand sweeps of the 256-wide network, saved state in bf16 "K8" layout ----

@@ -28,6 +28,8 @@ VARIANT_F32_MFMA = 64
 VARIANT_BWD_TI_SHIFT, VARIANT_BWD_NW_SHIFT, VARIANT_FWD_TI_SHIFT, VARIANT_FWD_NW_SHIFT = 8, 10, 12, 14
 VARIANT_REG_TILE = 1 << 16
 VARIANT_LDS_TILE = 1 << 17
+VARIANT_X2H = 1 << 18
+VARIANT_NO_X2H = 1 << 19
 
 c_float_p = C.c_void_p  # device pointers are passed as integers
 
@@ -178,13 +180,14 @@ def check(rc: int):
 
 
 def variant_bits(bf16=False, deterministic=False, generic=False, dw_lds=False, dw_staged=False, bwd_ti=0, bwd_nw=0,
-                 fwd_ti=0, fwd_nw=0, x3=False, f32_mfma=False, reg_tile=False, lds_tile=False) -> int:
-    """rnb_model_desc.variant from keyword switches (tile heights: 0/1/2; waves: 0/4/8)."""
+                 fwd_ti=0, fwd_nw=0, x3=False, f32_mfma=False, reg_tile=False, lds_tile=False, x2h=None) -> int:
+    """rnb_model_desc.variant from keyword switches (tile heights: 0/1/2; waves: 0/4/8; x2h: None = the library's default
+    (on with the x3 arithmetic), True / False force the fp16 three-term forward sweeps on / off)."""
     nw = {0: 0, 4: 1, 8: 2}
     return ((VARIANT_BF16 if bf16 else 0) | (VARIANT_DETERMINISTIC if deterministic else 0)
             | (VARIANT_GENERIC if generic else 0) | (VARIANT_DW_LDS if dw_lds else 0)
             | (VARIANT_DW_STAGED if dw_staged else 0) | (VARIANT_X3 if x3 else 0) | (VARIANT_F32_MFMA if f32_mfma else 0)
-            | (VARIANT_REG_TILE if reg_tile else 0) | (VARIANT_LDS_TILE if lds_tile else 0)
+            | (VARIANT_REG_TILE if reg_tile else 0) | (VARIANT_LDS_TILE if lds_tile else 0) | (0 if x2h is None else VARIANT_X2H if x2h else VARIANT_NO_X2H)
             | (int(bwd_ti) << VARIANT_BWD_TI_SHIFT) | (nw[int(bwd_nw)] << VARIANT_BWD_NW_SHIFT)
             | (int(fwd_ti) << VARIANT_FWD_TI_SHIFT) | (nw[int(fwd_nw)] << VARIANT_FWD_NW_SHIFT))
 
