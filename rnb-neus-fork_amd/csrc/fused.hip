@@ -283,7 +283,7 @@ int x3_pack_weights(const Layout& L, float* packed, hipStream_t s) {
   }
   hipLaunchKernelGGL(x3_pack_kernel, dim3((unsigned)((t.total_units + 255) / 256)), dim3(256), 0, s, packed, t, dst);
   RNB_CHECK_LAUNCH();
-  if (is_x2h(L)) {   // what the forward-type products read: W of both networks (F sweeps, albedo forward), W^T of the SDF net (R sweep)
+  if (is_x2h(L)) {   // (every matrix by now: the backward sweeps read the fp16 planes too)
     X3Table th;
     th.n = 0;
     th.total_units = 0;
@@ -291,8 +291,8 @@ int x3_pack_weights(const Layout& L, float* packed, hipStream_t s) {
       const X3Entry& e = t.e[q];
       bool fwd = false;
       for (int l = 0; l < L.nh; ++l) fwd = fwd || e.off == L.hid[l].w_off || e.off == L.hid[l].wT_off;
-      fwd = fwd || (L.F > 0 && e.off == L.feat.w_off);
-      for (int l = 0; l < L.nc; ++l) fwd = fwd || e.off == L.col[l].w_off;   // the albedo network's forward layers
+      fwd = fwd || (L.F > 0 && (e.off == L.feat.w_off || e.off == L.feat.wT_off));   // (W_feat^T: the FB sweep's first product)
+      for (int l = 0; l < L.nc; ++l) fwd = fwd || e.off == L.col[l].w_off || e.off == L.col[l].wT_off;   // the albedo network
       if (!fwd) continue;
       X3Entry& d = th.e[th.n++];
       d = e;

@@ -44,6 +44,7 @@ struct FusedBwdArgs {
   const float* sbar;    // [Mp]        (FB)
   const float* fbar;    // [Mp,ld_fbar] first 256 columns, or nullptr (FB, no_albedo)
   int ld_fbar;
+  unsigned* amax;       // PointBufs::amax (RA: slots AMAX_U + l of the u_l it writes; FB: AMAX_ZB + l), or nullptr
 };
 
 // AuxTile<TI, TJ>: one value per accumulator element of the wave's (32 TI) x (32 TJ) block
@@ -259,6 +260,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TI == 2) ? 1 : 2) void fused_r
   float* X = lds;
   float* Y = lds + (NBUF - 1) * BT * FP;
   float* E = lds + NBUF * BT * FP;   // adjoint of g_e of the tile (re-enters at the skip connection)
+  __shared__ float wmx[2][8];        // per-wave maxima of u_{l+1} by layer parity (x2h weight-gradient scales)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = wave_id();
   const int64_t row0 = (int64_t)blockIdx.x * BT;
@@ -314,6 +316,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TI == 2) ? 1 : 2) void fused_r
       break;
     }
     const BufRsrc ru = tile_rsrc(g.u[l + 1] + (size_t)row0 * FH, BT * FH * 4);
+    // max |u_{l+1}| rides in the epilogue.  No row mask: the padding rows of geb are written as zeros (nbar_geb_kernel) and D,
+    // gz of padding rows are the finite state of the point 0 the forward evaluated there, so every u of a padding row is 0.
+    float um[2] = {0.f, 0.f};
     for_each_acc_split<TI, TJ>(
         n0, lane_e, n_real,
         [&](int tj, int ti, int r, int col, int rowc, int row) {
@@ -325,6 +330,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TI == 2) ? 1 : 2) void fused_r
           Y[row * FP + col] = un;
           bstore(rzR, voff, soff, zr);
           bstore(ru, voff, soff, un);
+          um[r & 1] = fmaxf(um[r & 1], fabsf(un));
         },
         [&](int tj, int ti, int r, int col, int rowc, int row) {
           const unsigned voff = (unsigned)(4 * h * FH + col) * 4u;
@@ -341,8 +347,22 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TI == 2) ? 1 : 2) void fused_r
           Y[row * FP + col] = un;
           bstore(rzR, voff, soff, zr);
           bstore(ru, voff, soff, un);
+          um[r & 1] = fmaxf(um[r & 1], fabsf(un));
         });
+    if (g.amax != nullptr) {   // max |u_{l+1}| of the real rows: the scale of its weight-gradient job (x2h).  The waves'
+      // maxima meet in LDS behind the barrier that ends the layer: one atomic per tile, and only when the slot would grow
+      float m = fmaxf(um[0], um[1]);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+      if (lane_e == 0) wmx[l & 1][wave] = m;
+    }
     lds_barrier();
+    if (g.amax != nullptr && tid == 0) {
+      float m = wmx[l & 1][0];
+      for (int w = 1; w < NW; ++w) m = fmaxf(m, wmx[l & 1][w]);
+      const unsigned b = __builtin_bit_cast(unsigned, m);
+      if (b > __atomic_load_n(g.amax + AMAX_U + l + 1, __ATOMIC_RELAXED)) atomicMax(g.amax + AMAX_U + l + 1, b);
+    }
     if constexpr (NBUF == 2) { float* t = X; X = Y; Y = t; }
   }
 }
@@ -411,12 +431,18 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TI == 2) ? 1 : 2) void fused_f
           const float zb = fmaf(acc[ti][tj][r], aD.v[ti][tj][r], aZ.v[ti][tj][r]);
           Y[row * FP + col] = zb;
           bstore(rzb, (unsigned)(4 * h * FH + col) * 4u, rowc * FH * 4, zb);
+          acc[ti][tj][r] = zb;   // (kept for the maximum below)
         },
         [&](int tj, int ti, int r, int col, int rowc, int row) {
           const float zb = col < n_real ? fmaf(acc[ti][tj][r], aD.v[ti][tj][r], aZ.v[ti][tj][r]) : 0.f;
           Y[row * FP + col] = zb;
           bstore(rzb, (unsigned)(4 * h * FH + col) * 4u, rowc * FH * 4, zb);
+          acc[ti][tj][r] = zb;
         });
+    if (g.amax != nullptr) {   // max |zb_l| of the real rows: the scale of its weight-gradient job (x2h)
+      const long long left = g.M - row0;
+      amax_commit(g.amax + AMAX_ZB + l, acc_absmax<TI, TJ>(acc, lane_e, left >= BT ? BT : (int)(left < 0 ? 0 : left)), lane_e);
+    }
     if (l == 0) break;
     lds_barrier();
     if constexpr (NBUF == 2) { float* t = X; X = Y; Y = t; }
@@ -428,6 +454,274 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TI == 2) ? 1 : 2) void fused_f
     if constexpr (X3 && !BOTH_IN_LOOP) prefetch_tile<TI, TJ>(g.D[l - 1], row0, n0, opaque_lane(lane), aD);
     if constexpr (!BOTH_IN_LOOP) prefetch_tile<TI, TJ>(g.zR[l - 1], row0, n0, opaque_lane(lane), aZ);
     if constexpr (NBUF == 1) lds_barrier();   // every wave has finished reading the tile
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// x2h forms of RA and FB (64-point tiles updated in place): the products as three fp16 terms (gemm.hip.h).  The A operand
+// is a loss adjoint, whose magnitude nothing bounds a priori: the tile in LDS carries a power-of-two scale chosen PER TILE
+// AND LAYER from the actual maximum of the values about to be stored (every wave leaves the maximum of its block in LDS
+// before the barrier that already separates the matrix loop from the in-place update, so the exchange costs no barrier) —
+// the largest element of a tile always lands in [2^13, 2^14): no overflow whatever the loss scale, and every element
+// within 2^-16 of its tile's maximum keeps the full two-plane precision.  The same maxima (real rows only), folded
+// over the tiles with one atomic per tile, are the scales of the weight-gradient jobs (PointBufs::amax).
+// ---------------------------------------------------------------------------------------------------------
+// maximum of the NW per-wave values of this layer -> (tile maximum, scale, 1 / scale)
+template <int NW>
+__device__ inline float tile_scale(const float* wm, float& s, float& inv_s) {
+  float m = wm[0];
+#pragma unroll
+  for (int w = 1; w < NW; ++w) m = fmaxf(m, wm[w]);
+  x2h_dyn_scale(__builtin_bit_cast(unsigned, m), s, inv_s);
+  return m;
+}
+__device__ inline float wave_max(float m) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  return m;
+}
+// one atomic per tile, and only when the slot would grow
+__device__ inline void amax_tile_commit(unsigned* slot, float m) {
+  const unsigned b = __builtin_bit_cast(unsigned, m);
+  if (b > __atomic_load_n(slot, __ATOMIC_RELAXED)) atomicMax(slot, b);
+}
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_ra_h2_kernel(FusedBwdArgs g) {
+  constexpr int TI = 2, BT = 64, NT = 64 * NW, TJ = 8 / NW;
+  constexpr float IW = 1.f / kH2WScale;
+  __shared__ __attribute__((aligned(16))) float lds[BT * FP + BT * FEP];
+  __shared__ float wm[2][8];   // per-wave maxima over the real rows, by layer parity (see fused_fb_h2_kernel)
+  float* X = lds;
+  float* E = lds + BT * FP;   // adjoint of g_e of the tile (re-enters at the skip connection), unscaled
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = wave_id();
+  const int64_t row0 = (int64_t)blockIdx.x * BT;
+  const int n0 = wave * 32 * TJ;
+  const long long left = g.M - row0;
+  const int rows_ok = left >= BT ? BT : (int)(left < 0 ? 0 : left);
+  constexpr bool LATE = TJ == 2;
+
+  float unscale;
+  {
+    float m = 0.f;
+    for (int idx = tid; idx < BT * g.Ep; idx += NT) {
+      const int r = idx / g.Ep, c = idx - r * g.Ep;
+      const float v = g.geb[(row0 + r) * g.Ep + c];
+      X[r * FP + c] = v;
+      if (c < FEP) E[r * FEP + c] = v;
+      if (r < rows_ok) m = fmaxf(m, fabsf(v));
+    }
+    m = wave_max(m);
+    if (lane == 0) wm[1][wave] = m;
+    __syncthreads();
+    float s, inv;
+    tile_scale<NW>(wm[1], s, inv);
+    for (int idx = tid; idx < BT * g.Ep; idx += NT) {   // every thread rescales the elements it wrote
+      const int r = idx / g.Ep, c = idx - r * g.Ep;
+      X[r * FP + c] *= s;
+    }
+    __syncthreads();
+    unscale = inv * IW;
+  }
+
+  v16f acc[TI][TJ];
+  AuxTile<TI, TJ> aD, aG;
+  X3Mma<TI, TJ, 2> mm;
+  if constexpr (!LATE) mm.request(g.w3 + 2 * g.w_off[0], g.Kp[0], n0, lane);
+  for (int l = 0; l < g.nh; ++l) {
+    if constexpr (LATE) {
+      mm.request(g.w3 + 2 * g.w_off[l], g.Kp[l], n0, lane);
+      mm.run(X, g.w3 + 2 * g.w_off[l], g.Kp[l], n0, lane, acc, nullptr, 0, 0);   // gzb = u_l W_l^T
+    } else {
+      mm.run(X, g.w3 + 2 * g.w_off[l], g.Kp[l], n0, lane, acc, l + 1 < g.nh ? g.w3 + 2 * g.w_off[l + 1] : nullptr, FH, n0, [&]() {
+        prefetch_tile<TI, TJ>(g.D[l], row0, n0, lane, aD);
+        prefetch_tile<TI, TJ>(g.gz[l], row0, n0, lane, aG);
+      });
+    }
+    const int lane_e = opaque_lane(lane);
+    const int h = lane_e >> 5;
+    if constexpr (LATE) {
+      prefetch_tile<TI, TJ>(g.D[l], row0, n0, lane_e, aD);
+      prefetch_tile<TI, TJ>(g.gz[l], row0, n0, lane_e, aG);
+    }
+    const int n_real = g.n_real[l];
+    const bool pe_tail = (l + 1 == g.skip);
+    const int par = l & 1;
+    const BufRsrc rzR = tile_rsrc(g.zR[l] + (size_t)row0 * FH, BT * FH * 4);
+    if (l + 1 == g.nh && g.ucol != nullptr) {   // last layer: column sums of u_nh instead of the matrix (see fused_ra_kernel)
+      float cs[TJ];
+#pragma unroll
+      for (int tj = 0; tj < TJ; ++tj) cs[tj] = 0.f;
+      for_each_acc<TI, TJ>(n0, lane_e, [&](int tj, int ti, int r, int col, int rowc, int row) {
+        const float v = acc[ti][tj][r] * unscale;
+        const float un = col < n_real ? v * aD.v[ti][tj][r] : 0.f;
+        const float zr = col < n_real ? ((v - un) * aG.v[ti][tj][r]) * 100.f : 0.f;
+        bstore(rzR, (unsigned)(4 * h * FH + col) * 4u, rowc * FH * 4, zr);
+        cs[tj] += (row0 + row < g.M) ? un : 0.f;
+      });
+#pragma unroll
+      for (int tj = 0; tj < TJ; ++tj) {
+        const float tot = cs[tj] + __shfl_xor(cs[tj], 32, 64);
+        if (lane_e < 32) g.ucol[(size_t)blockIdx.x * FH + n0 + tj * 32 + lane_e] = tot;
+      }
+      break;
+    }
+    // phase 1 (registers and HBM only): u_{l+1} and zR_l, the maxima of u_{l+1}
+    const BufRsrc ru = tile_rsrc(g.u[l + 1] + (size_t)row0 * FH, BT * FH * 4);
+    for_each_acc_split<TI, TJ>(
+        n0, lane_e, n_real,
+        [&](int tj, int ti, int r, int col, int rowc, int row) {
+          const unsigned voff = (unsigned)(4 * h * FH + col) * 4u;
+          const unsigned soff = rowc * FH * 4;
+          const float v = acc[ti][tj][r] * unscale;
+          const float un = v * aD.v[ti][tj][r];
+          const float zr = ((v - un) * aG.v[ti][tj][r]) * 100.f;   // 100 v gz (1 - D)
+          bstore(rzR, voff, soff, zr);
+          bstore(ru, voff, soff, un);
+          acc[ti][tj][r] = un;
+        },
+        [&](int tj, int ti, int r, int col, int rowc, int row) {
+          const unsigned voff = (unsigned)(4 * h * FH + col) * 4u;
+          const unsigned soff = rowc * FH * 4;
+          const float v = acc[ti][tj][r] * unscale;
+          float zr, un;
+          if (col < n_real) {
+            un = v * aD.v[ti][tj][r];
+            zr = ((v - un) * aG.v[ti][tj][r]) * 100.f;
+          } else {
+            zr = 0.f;
+            un = (pe_tail && col < n_real + g.pe) ? E[row * FEP + (col - n_real)] : 0.f;
+          }
+          bstore(rzR, voff, soff, zr);
+          bstore(ru, voff, soff, un);
+          acc[ti][tj][r] = un;
+        });
+    {
+      const float mr = wave_max(acc_absmax<TI, TJ>(acc, lane_e, rows_ok));
+      if (lane_e == 0) wm[par][wave] = mr;
+    }
+    lds_barrier();   // every wave has finished reading the tile; the maxima are visible
+    float s, inv;
+    const float tmax = tile_scale<NW>(wm[par], s, inv);
+    if (tid == 0 && g.amax != nullptr) amax_tile_commit(g.amax + AMAX_U + l + 1, tmax);
+    if (l + 1 == g.nh) break;   // (only without ucol: nothing follows)
+    // phase 2: the tile for the next product, scaled by this layer's own maximum
+    for_each_acc<TI, TJ>(n0, lane_e, [&](int tj, int ti, int r, int col, int rowc, int row) {
+      X[row * FP + col] = acc[ti][tj][r] * s;
+    });
+    lds_barrier();
+    unscale = inv * IW;
+  }
+}
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_fb_h2_kernel(FusedBwdArgs g) {
+  constexpr int TI = 2, BT = 64, NT = 64 * NW, TJ = 8 / NW;
+  constexpr float IW = 1.f / kH2WScale;
+  __shared__ __attribute__((aligned(16))) float lds[BT * FP];
+  __shared__ float wm[2][8];   // per-wave maxima over the real rows, by layer parity (padding rows hold workspace garbage:
+                               // they may overflow the scaled tile — their products are never read)
+  float* X = lds;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = wave_id();
+  const int64_t row0 = (int64_t)blockIdx.x * BT;
+  const int n0 = wave * 32 * TJ;
+  const long long left = g.M - row0;
+  const int rows_ok = left >= BT ? BT : (int)(left < 0 ? 0 : left);
+
+  v16f acc[TI][TJ];
+  AuxTile<TI, TJ> aD, aZ;
+  X3Mma<TI, TJ, 2> mm;
+  constexpr bool LATE = TJ == 2;   // 64 x 64-output waves: operand tiles requested after the matrix loop
+  if constexpr (!LATE) {
+    if (g.fbar != nullptr) mm.request(g.w3 + 2 * g.wfT_off, FH, n0, lane);
+    else if (g.nh > 1) mm.request(g.w3 + 2 * g.wT_off[g.nh - 1], FH, n0, lane);
+    prefetch_tile<TI, TJ>(g.D[g.nh - 1], row0, n0, lane, aD);
+    prefetch_tile<TI, TJ>(g.zR[g.nh - 1], row0, n0, lane, aZ);
+  }
+  for (int ti_ = 0; ti_ < TI; ++ti_) for (int tj_ = 0; tj_ < TJ; ++tj_) for (int r_ = 0; r_ < 16; ++r_) acc[ti_][tj_][r_] = 0.f;
+  float unscale = 1.f;   // accumulator -> ab (true units)
+  if (g.fbar != nullptr) {   // ab_{nh-1} = fbar W_feat (+ the sdf-head term below)
+    const float* fb = g.fbar + (size_t)row0 * g.ld_fbar;
+    float m = 0.f;
+    for (int idx = tid; idx < BT * FH / 4; idx += NT) {
+      const int r = idx >> 6, c4 = idx & 63;
+      const vf4 v = *reinterpret_cast<const vf4*>(fb + (size_t)r * g.ld_fbar + c4 * 4);
+      *reinterpret_cast<vf4*>(X + r * FP + c4 * 4) = v;
+      if (r < rows_ok) m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    m = wave_max(m);
+    if (lane == 0) wm[1][wave] = m;
+    __syncthreads();
+    float s, inv;
+    tile_scale<NW>(wm[1], s, inv);
+    for (int idx = tid; idx < BT * FH / 4; idx += NT) {   // every thread rescales the elements it wrote
+      const int r = idx >> 6, c4 = idx & 63;
+      vf4* q = reinterpret_cast<vf4*>(X + r * FP + c4 * 4);
+      *q = *q * s;
+    }
+    __syncthreads();
+    if constexpr (LATE) mm.request(g.w3 + 2 * g.wfT_off, FH, n0, lane);
+    mm.run(X, g.w3 + 2 * g.wfT_off, FH, n0, lane, acc, (!LATE && g.nh > 1) ? g.w3 + 2 * g.wT_off[g.nh - 1] : nullptr, FH, n0);
+    unscale = inv * IW;
+  }
+  if constexpr (LATE) {
+    prefetch_tile<TI, TJ>(g.D[g.nh - 1], row0, n0, lane, aD);
+    prefetch_tile<TI, TJ>(g.zR[g.nh - 1], row0, n0, lane, aZ);
+  }
+  for (int l = g.nh - 1; l >= 0; --l) {
+    // phase 1 (registers and HBM only): zb_l = ab_l * D_l + zR_l, its maxima
+    const int lane_e = opaque_lane(lane);
+    const int h = lane_e >> 5;
+    const int n_real = g.n_real[l];
+    const bool head = (l == g.nh - 1);
+    const int par = l & 1;
+    const BufRsrc rzb = tile_rsrc(g.zb[l] + (size_t)row0 * FH, BT * FH * 4);
+    if (head) {   // + sbar / scale * w_sdf  (the sdf head's contribution to ab_{nh-1}); once per launch
+      for_each_acc<TI, TJ>(n0, lane_e, [&](int tj, int ti, int r, int col, int rowc, int row) {
+        acc[ti][tj][r] = fmaf(g.sbar[row0 + row] * g.inv_scale, g.packed[g.wsdf_off + col], acc[ti][tj][r] * unscale);
+      });
+      unscale = 1.f;
+    }
+    for_each_acc_split<TI, TJ>(
+        n0, lane_e, n_real,
+        [&](int tj, int ti, int r, int col, int rowc, int row) {
+          const float zb = fmaf(acc[ti][tj][r] * unscale, aD.v[ti][tj][r], aZ.v[ti][tj][r]);
+          bstore(rzb, (unsigned)(4 * h * FH + col) * 4u, rowc * FH * 4, zb);
+          acc[ti][tj][r] = zb;
+        },
+        [&](int tj, int ti, int r, int col, int rowc, int row) {
+          const float zb = col < n_real ? fmaf(acc[ti][tj][r] * unscale, aD.v[ti][tj][r], aZ.v[ti][tj][r]) : 0.f;
+          bstore(rzb, (unsigned)(4 * h * FH + col) * 4u, rowc * FH * 4, zb);
+          acc[ti][tj][r] = zb;
+        });
+    {
+      const float mr = wave_max(acc_absmax<TI, TJ>(acc, lane_e, rows_ok));
+      if (lane_e == 0) wm[par][wave] = mr;
+    }
+    lds_barrier();   // every wave has finished reading the tile; the maxima are visible
+    float s, inv;
+    const float tmax = tile_scale<NW>(wm[par], s, inv);
+    if (tid == 0 && g.amax != nullptr) amax_tile_commit(g.amax + AMAX_ZB + l, tmax);
+    if (l == 0) break;
+    // phase 2: the tile for the next product, scaled by this layer's own maximum
+    for_each_acc<TI, TJ>(n0, lane_e, [&](int tj, int ti, int r, int col, int rowc, int row) {
+      X[row * FP + col] = acc[ti][tj][r] * s;
+    });
+    lds_barrier();
+    if constexpr (LATE) {
+      mm.request(g.w3 + 2 * g.wT_off[l], FH, n0, lane);
+      mm.run(X, g.w3 + 2 * g.wT_off[l], FH, n0, lane, acc, nullptr, 0, 0);   // ab_{l-1} = zb_l W_l
+      prefetch_tile<TI, TJ>(g.D[l - 1], row0, n0, opaque_lane(lane), aD);
+      prefetch_tile<TI, TJ>(g.zR[l - 1], row0, n0, opaque_lane(lane), aZ);
+    } else {
+      mm.run(X, g.w3 + 2 * g.wT_off[l], FH, n0, lane, acc, l > 1 ? g.w3 + 2 * g.wT_off[l - 1] : nullptr, FH, n0, [&]() {
+        prefetch_tile<TI, TJ>(g.D[l - 1], row0, n0, lane, aD);
+        prefetch_tile<TI, TJ>(g.zR[l - 1], row0, n0, lane, aZ);
+      });
+    }
+    unscale = inv * IW;
   }
 }
 
@@ -461,6 +755,7 @@ static void fill_args(const Layout& L, const float* packed, PointBufs& pb, Fused
   g.nrm = pb.nrm;
   g.geb = pb.geb;
   g.sbar = pb.sbar;
+  g.amax = is_x2h(L) ? pb.amax : nullptr;
 }
 
 // Variant of the three sweeps: tile height TI (32 / 64 points) x waves per workgroup NW (4: 64 columns per wave;
@@ -529,7 +824,15 @@ int fused_ra(const Layout& L, const float* packed, PointBufs& pb, hipStream_t s,
     *u_tiles = (int)(pb.Mp / (32 * ti));
   }
   const dim3 grid((unsigned)(pb.Mp / (32 * ti))), block(64 * nw);
-  if (is_x3(L)) {
+  // RA stays on the six bf16 terms: it reads D_l, gz_l and writes zR_l, u_{l+1} — 2.1 GB per 65,536 points, 0.42 ms at
+  // 5 TB/s against 0.45 ms measured: the matrix time hides under the state traffic, and the x2h form (fused_ra_h2_kernel,
+  // kept for RNB_VARIANT_X2H with RNB_VARIANT_REG_TILE as the A/B switch), whose two-phase epilogue stores later, measured
+  // 0.505 (8 waves) / 0.545 ms (4 waves, 24 spilled registers) against 0.475 (profiles/r04_ab_experiments.txt).
+  if (is_x2h(L) && ti == 2 && (L.variant & RNB_VARIANT_REG_TILE)) {
+    g.w3 = x2h_mirror(L, packed);
+    if (nw == 8) hipLaunchKernelGGL((fused_ra_h2_kernel<8>), grid, block, 0, s, g);
+    else hipLaunchKernelGGL((fused_ra_h2_kernel<4>), grid, block, 0, s, g);
+  } else if (is_x3(L)) {
     if (ti == 2 && nw == 8) hipLaunchKernelGGL((fused_ra_kernel<2, 8, true>), grid, block, 0, s, g);
     else if (ti == 2) hipLaunchKernelGGL((fused_ra_kernel<2, 4, true>), grid, block, 0, s, g);
     else if (nw == 8) hipLaunchKernelGGL((fused_ra_kernel<1, 8, true>), grid, block, 0, s, g);
@@ -550,7 +853,11 @@ int fused_fb(const Layout& L, const float* packed, PointBufs& pb, bool with_colo
   ProfScope prof(hidden_flops(L, pb.M, 1) + (with_color ? 2.0 * (double)pb.M * L.F * L.H : 0.0), s, "FB_sweep");
   const int ti = bwd_ti(L, is_x3(L) ? 2 : 1), nw = bwd_nw(L, is_x3(L) ? 4 : 8);
   const dim3 grid((unsigned)(pb.Mp / (32 * ti))), block(64 * nw);
-  if (is_x3(L)) {
+  if (is_x2h(L) && ti == 2) {   // three fp16 terms, per-tile scales (64-point tiles only: the in-place form)
+    g.w3 = x2h_mirror(L, packed);
+    if (nw == 8) hipLaunchKernelGGL((fused_fb_h2_kernel<8>), grid, block, 0, s, g);
+    else hipLaunchKernelGGL((fused_fb_h2_kernel<4>), grid, block, 0, s, g);
+  } else if (is_x3(L)) {
     if (ti == 2 && nw == 8) hipLaunchKernelGGL((fused_fb_kernel<2, 8, true>), grid, block, 0, s, g);
     else if (ti == 2) hipLaunchKernelGGL((fused_fb_kernel<2, 4, true>), grid, block, 0, s, g);
     else if (nw == 8) hipLaunchKernelGGL((fused_fb_kernel<1, 8, true>), grid, block, 0, s, g);

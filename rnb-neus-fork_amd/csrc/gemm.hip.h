@@ -288,6 +288,10 @@ struct DwPair {
   int ldx;
   const float* Y;
   int ldy;
+  // x2h form of the 256-row kernel (gemm_dw_x3_kernel<., 2>): which operand is the loss adjoint (0: X, 1: Y; the other one
+  // is saved forward state of known range) and where its producer left max |.| over the real rows (float bits)
+  int adj = 0;
+  const unsigned* amax = nullptr;
 };
 
 template <bool GUARD, int KT>
@@ -347,6 +351,48 @@ __device__ inline void x3_split8(const vf4& x0, const vf4& x1, vu4x& hi, vu4x& m
     lo[p] = x3_pack2(sa, sb);
   }
 }
+// ---- maxima of adjoint tensors (scales of the x2h weight-gradient jobs) --------------------------------------------
+// A producer of an adjoint tensor leaves max |.| over the REAL rows (padding rows hold workspace garbage) in a slot of
+// PointBufs::amax as float bits (non-negative floats order like unsigned integers): one atomic per wave.
+__device__ inline void amax_commit(unsigned* slot, float m, int lane) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  // the slot only grows: a wave whose maximum is not above what is already there sends no atomic (thousands of same-address
+  // atomics arriving together serialise in the L2: 35 us at the end of a 60 us kernel when every wave sent one)
+  if (lane == 0 && slot != nullptr) {
+    const unsigned b = __builtin_bit_cast(unsigned, m);
+    if (b > __atomic_load_n(slot, __ATOMIC_RELAXED)) atomicMax(slot, b);
+  }
+}
+// max |acc| over the accumulator rows below `rows_ok` (relative to the wave's first row) of a (32 TI) x (32 TJ) block
+template <int TI, int TJ>
+__device__ inline float acc_absmax(const v16f (&acc)[TI][TJ], int lane, int rows_ok) {
+  float m0 = 0.f, m1 = 0.f;
+  if (rows_ok >= 32 * TI) {
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          m0 = fmaxf(m0, fabsf(acc[ti][tj][r]));
+          m1 = fmaxf(m1, fabsf(acc[ti][tj][r + 1]));
+        }
+  } else {
+    const int h = lane >> 5;
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          m0 = fmaxf(m0, row < rows_ok ? fabsf(acc[ti][tj][r]) : 0.f);
+        }
+  }
+  return fmaxf(m0, m1);
+}
+
 // ---- "x2h": the same idea on the fp16 matrix pipe with TWO planes and THREE terms ----------------------------------
 // xs = x * S (S a power of two: exact), hi = fp16(xs), lo = fp16(xs - hi): two 11-bit roundings, |xs - hi - lo| <= 2^-22 |xs|
 // (rms 2^-23.6: about four times the rounding noise of storing x in fp32 at all) as long as lo is a normal fp16 number
@@ -963,9 +1009,11 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_x3_kernel(const float* __res
 // NP = 2: the fp16 three-term form (x2h; forward layers: the inputs are activations of known range): W3 is then the
 // fp16 mirror (weights times kH2WScale), the rows are scaled by kH2ActScale as they are staged and the accumulators
 // rescaled before the epilogue.
+// amax != nullptr: max |acc| over the rows below m_real is left there (an upper bound of the epilogue's masked outputs)
 template <int TJ, class Epi, int NP = 3>
 __global__ __launch_bounds__(512, 1) void gemm_rows_x3m_kernel(const float* __restrict__ A, int lda,
-                                                               const x3raw* __restrict__ W3, int N, int K, Epi epi) {
+                                                               const x3raw* __restrict__ W3, int N, int K, Epi epi,
+                                                               unsigned* amax = nullptr, long long m_real = 0) {
   constexpr int ROWS = 128;
   constexpr int PLB = ROWS * XP;              // bytes of one plane
   constexpr int BUFB = NP * PLB;              // one staging buffer (three planes: 18,432 B)
@@ -1064,6 +1112,28 @@ __global__ __launch_bounds__(512, 1) void gemm_rows_x3m_kernel(const float* __re
     step(ks + 1, b1);
   }
   __syncthreads();   // the staging buffers become the epilogue strips
+  if (amax != nullptr) {   // (workgroup-uniform)  the eight waves' maxima meet in LDS: one atomic per workgroup
+    __shared__ float wmx[8];
+    const long long left = m_real - m_blk;
+    float m = 0.f;
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj) {
+      if (!on[tj]) continue;
+      v16f t[4][1];
+#pragma unroll
+      for (int ti = 0; ti < 4; ++ti) t[ti][0] = acc[ti][tj];
+      m = fmaxf(m, acc_absmax<4, 1>(t, lane, left >= ROWS ? ROWS : (int)(left < 0 ? 0 : left)));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if (lane == 0) wmx[wave] = m;
+    __syncthreads();
+    if (tid == 0) {
+      for (int w = 1; w < 8; ++w) m = fmaxf(m, wmx[w]);
+      const unsigned b = __builtin_bit_cast(unsigned, m);
+      if (b > __atomic_load_n(amax, __ATOMIC_RELAXED)) atomicMax(amax, b);
+    }
+  }
   float* strip = reinterpret_cast<float*>(smem + wave * STRIP);
 #pragma unroll
   for (int tj = 0; tj < TJ; ++tj) {
@@ -1092,6 +1162,16 @@ constexpr int kX3Half = 4 * 68 * 16;            // one point half of one plane: 
 constexpr int kX3Plane = 2 * kX3Half;
 constexpr int kX3OpBytes = 3 * kX3Plane;        // one operand of one chunk: 25.5 KB
 constexpr int kX3BufBytes = 2 * kX3OpBytes;     // both operands
+// NP planes per operand (3: bf16 hi / mid / lo, six terms; 2: fp16 hi / lo, three terms — "x2h")
+template <int NP> constexpr int dw_op_bytes() { return NP * kX3Plane; }
+template <int NP> constexpr int dw_buf_bytes() { return 2 * NP * kX3Plane; }
+// the power-of-two scale of the adjoint operand of an x2h job: its maximum (float bits `mbits`) goes to [2^13, 2^14)
+__device__ inline void x2h_dyn_scale(unsigned mbits, float& s, float& inv_s) {
+  int ef = (int)(mbits >> 23);                        // biased exponent of the maximum (0: all zero)
+  ef = ef < 24 ? 24 : (ef > 250 ? 250 : ef);          // both factors stay normal numbers
+  s = __builtin_bit_cast(float, (unsigned)(267 - ef) << 23);        // 2^(13 - e)
+  inv_s = __builtin_bit_cast(float, (unsigned)(ef - 13) << 23);     // 2^(e - 13)
+}
 
 // (buffer loads: the lane's column offset in one VGPR, the wave-uniform row offset in the scalar operand)
 __device__ inline void dw_x3_load(BufRsrc rs, unsigned voff, int ld, int row0, vf4 (&x)[4]) {
@@ -1100,96 +1180,107 @@ __device__ inline void dw_x3_load(BufRsrc rs, unsigned voff, int ld, int row0, v
     x[p] = __builtin_bit_cast(vf4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (unsigned)(row0 + p) * (unsigned)ld * 4u, RNB_AUX_LD));   // read once
 }
 // 4 columns x 4 points of one thread -> 12 half units at w (+ 68 * 16 per column, + kX3Plane per plane)
-__device__ inline void dw_x3_split(const vf4 (&x)[4], vu2x (&hi)[4], vu2x (&mid)[4], vu2x (&lo)[4]) {
-#pragma unroll
-  for (int j = 0; j < 4; ++j) x3_split4(vf4{x[0][j], x[1][j], x[2][j], x[3][j]}, hi[j], mid[j], lo[j]);
+// one column (four points) -> its NP plane units; sc: the operand's scale (x2h only)
+template <int NP>
+__device__ inline void dw_xn_split_col(const vf4& col, float sc, vu2x (&pl)[NP]) {
+  if constexpr (NP == 3) x3_split4(col, pl[0], pl[1], pl[2]);
+  else x2h_split4(col * sc, pl[0], pl[1]);
 }
-__device__ inline void dw_x3_store(char* w, const vu2x (&hi)[4], const vu2x (&mid)[4], const vu2x (&lo)[4]) {
+template <int NP>
+__device__ inline void dw_x3_split(const vf4 (&x)[4], float sc, vu2x (&pl)[4][NP]) {
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    *reinterpret_cast<vu2x*>(w + j * 68 * 16) = hi[j];
-    *reinterpret_cast<vu2x*>(w + j * 68 * 16 + kX3Plane) = mid[j];
-    *reinterpret_cast<vu2x*>(w + j * 68 * 16 + 2 * kX3Plane) = lo[j];
-  }
+  for (int j = 0; j < 4; ++j) dw_xn_split_col<NP>(vf4{x[0][j], x[1][j], x[2][j], x[3][j]}, sc, pl[j]);
+}
+template <int NP>
+__device__ inline void dw_x3_store(char* w, const vu2x (&pl)[4][NP]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int q = 0; q < NP; ++q) *reinterpret_cast<vu2x*>(w + j * 68 * 16 + q * kX3Plane) = pl[j][q];
+}
+// the NT terms of one (ti, tj) block, small ones first
+template <int NP>
+__device__ inline v16f dw_xn_mfma(const vu4x (&a)[NP], const vu4x (&b)[NP], v16f c, int t) {
+  constexpr int PA[6] = {NP == 3 ? 2 : 1, 0, NP == 3 ? 1 : 0, 1, 0, 0};
+  constexpr int PB[6] = {0, NP == 3 ? 2 : 1, NP == 3 ? 1 : 0, 0, 1, 0};
+  if constexpr (NP == 3)
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(x3bf8, a[PA[t]]), __builtin_bit_cast(x3bf8, b[PB[t]]), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(x2h8, a[PA[t]]), __builtin_bit_cast(x2h8, b[PB[t]]), c, 0, 0, 0);
 }
 // One chunk of one wave: the 48 MFMAs on the fragments at fx / fy (one column tile of Y at a time, the next tile's
 // fragments requested before the current tile's MFMAs), and — in the MFMA gaps, three vector instructions behind each
 // MFMA — the split of the raw rows `x` of a later chunk, written to `w` at the end.
-__device__ inline void dw_x3_chunk(const char* fx, const char* fy, v16f (&acc)[2][4], const vf4 (&x)[4], char* w) {
-  vu4x a[2][3], b[2][3];
+template <int NP>
+__device__ inline void dw_x3_chunk(const char* fx, const char* fy, v16f (&acc)[2][4], const vf4 (&x)[4], float sc, char* w) {
+  constexpr int NT = NP == 3 ? 6 : 3;
+  vu4x a[2][NP], b[2][NP];
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) a[t][pl] = *reinterpret_cast<const vu4x*>(fx + pl * kX3Plane + t * 128);
+    for (int pl = 0; pl < NP; ++pl) a[t][pl] = *reinterpret_cast<const vu4x*>(fx + pl * kX3Plane + t * 128);
 #pragma unroll
-  for (int pl = 0; pl < 3; ++pl) b[0][pl] = *reinterpret_cast<const vu4x*>(fy + pl * kX3Plane);
+  for (int pl = 0; pl < NP; ++pl) b[0][pl] = *reinterpret_cast<const vu4x*>(fy + pl * kX3Plane);
 #pragma unroll
   for (int tj = 0; tj < 4; ++tj) {
     if (tj + 1 < 4) {
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) b[(tj + 1) & 1][pl] = *reinterpret_cast<const vu4x*>(fy + pl * kX3Plane + (tj + 1) * 128);
+      for (int pl = 0; pl < NP; ++pl) b[(tj + 1) & 1][pl] = *reinterpret_cast<const vu4x*>(fy + pl * kX3Plane + (tj + 1) * 128);
     }
-    constexpr int PA[6] = {2, 0, 1, 1, 0, 0};   // small terms first (x3_mfma)
-    constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-    for (int t = 0; t < 6; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int ti = 0; ti < 2; ++ti)
-        acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(x3bf8, a[ti][PA[t]]),
-                                                              __builtin_bit_cast(x3bf8, b[tj & 1][PB[t]]), acc[ti][tj], 0, 0, 0);
+      for (int ti = 0; ti < 2; ++ti) acc[ti][tj] = dw_xn_mfma<NP>(a[ti], b[tj & 1], acc[ti][tj], t);
     {   // column tj of this thread's 4 x 4 raw block: split and stored while tile tj multiplies
-      vu2x hi, mid, lo;
-      x3_split4(vf4{x[0][tj], x[1][tj], x[2][tj], x[3][tj]}, hi, mid, lo);
-      *reinterpret_cast<vu2x*>(w + tj * 68 * 16) = hi;
-      *reinterpret_cast<vu2x*>(w + tj * 68 * 16 + kX3Plane) = mid;
-      *reinterpret_cast<vu2x*>(w + tj * 68 * 16 + 2 * kX3Plane) = lo;
+      vu2x pl[NP];
+      dw_xn_split_col<NP>(vf4{x[0][tj], x[1][tj], x[2][tj], x[3][tj]}, sc, pl);
+#pragma unroll
+      for (int q = 0; q < NP; ++q) *reinterpret_cast<vu2x*>(w + tj * 68 * 16 + q * kX3Plane) = pl[q];
     }
   }
-  // schedule of the region: per column tile its fragment reads (of the NEXT tile), its 12 MFMAs with the vector work of
-  // one raw column between them, then that column's three stores
-  __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);   // a and b[0]
+  // schedule of the region: per column tile its fragment reads (of the NEXT tile), its 2 NT MFMAs with the vector work of
+  // one raw column between them, then that column's stores
+  __builtin_amdgcn_sched_group_barrier(0x100, 3 * NP, 0);   // a and b[0]
 #pragma unroll
   for (int tj = 0; tj < 4; ++tj) {
-    if (tj + 1 < 4) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+    if (tj + 1 < 4) __builtin_amdgcn_sched_group_barrier(0x100, NP, 0);
 #pragma unroll
-    for (int m = 0; m < 12; ++m) {
+    for (int m = 0; m < 2 * NT; ++m) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
     }
-    __builtin_amdgcn_sched_group_barrier(0x200, 3, 0);
+    __builtin_amdgcn_sched_group_barrier(0x200, NP, 0);
   }
   __builtin_amdgcn_sched_barrier(0);
 }
 // The same for a NARROW job (Y operand of 64 columns: the PE-input layer, the tail of the albedo net's 320-wide first
 // layer): wave (wm, wn) owns rows 64 wm .. + 64, columns 32 wn .. + 32 — 12 MFMAs per chunk; the staging split of the
 // thread's whole 4 x 4 raw block rides between them (st_on: lanes that stage nothing skip the stores).
-__device__ inline void dw_x3_chunk_narrow(const char* fx, const char* fy, v16f (&acc)[2][1], const vf4 (&x)[4], char* w,
+template <int NP>
+__device__ inline void dw_x3_chunk_narrow(const char* fx, const char* fy, v16f (&acc)[2][1], const vf4 (&x)[4], float sc, char* w,
                                           bool st_on) {
-  vu4x a[2][3], b[3];
+  constexpr int NT = NP == 3 ? 6 : 3;
+  vu4x a[2][NP], b[NP];
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) a[t][pl] = *reinterpret_cast<const vu4x*>(fx + pl * kX3Plane + t * 128);
+    for (int pl = 0; pl < NP; ++pl) a[t][pl] = *reinterpret_cast<const vu4x*>(fx + pl * kX3Plane + t * 128);
 #pragma unroll
-  for (int pl = 0; pl < 3; ++pl) b[pl] = *reinterpret_cast<const vu4x*>(fy + pl * kX3Plane);
-  constexpr int PA[6] = {2, 0, 1, 1, 0, 0};   // small terms first (x3_mfma)
-  constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+  for (int pl = 0; pl < NP; ++pl) b[pl] = *reinterpret_cast<const vu4x*>(fy + pl * kX3Plane);
 #pragma unroll
-  for (int t = 0; t < 6; ++t)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int ti = 0; ti < 2; ++ti)
-      acc[ti][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(x3bf8, a[ti][PA[t]]),
-                                                           __builtin_bit_cast(x3bf8, b[PB[t]]), acc[ti][0], 0, 0, 0);
-  vu2x hi[4], mid[4], lo[4];
-  dw_x3_split(x, hi, mid, lo);
-  __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);
+    for (int ti = 0; ti < 2; ++ti) acc[ti][0] = dw_xn_mfma<NP>(a[ti], b, acc[ti][0], t);
+  vu2x pl[4][NP];
+  dw_x3_split<NP>(x, sc, pl);
+  __builtin_amdgcn_sched_group_barrier(0x100, 3 * NP, 0);
 #pragma unroll
-  for (int m = 0; m < 12; ++m) {
+  for (int m = 0; m < 2 * NT; ++m) {
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
     __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
   }
   __builtin_amdgcn_sched_barrier(0);
-  if (st_on) dw_x3_store(w, hi, mid, lo);
+  if (st_on) dw_x3_store<NP>(w, pl);
 }
 __device__ inline void dw_x3_colsum(const vf4 (&x)[4], bool on, double (&bs)[4]) {
   if (!on) return;
@@ -1199,8 +1290,9 @@ __device__ inline void dw_x3_colsum(const vf4 (&x)[4], bool on, double (&bs)[4])
 
 // DUMMY == 1 (tools/dwx3_bench only): wave 0 sums the clocks it spends waiting at the barrier / issuing a chunk's
 // reads, MFMAs, split and stores / issuing the next loads, and leaves them in J.db (as uint64[8] per workgroup)
-template <int DUMMY, bool NARROW>
+template <int DUMMY, bool NARROW, int NP = 3>
 __device__ inline void dw_x3_body(const DwGroup& g, const DwJob& J, int split, char* lds) {
+  constexpr int kOp = dw_op_bytes<NP>(), kBuf = dw_buf_bytes<NP>();
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = wave_id();
   const int wm = wave >> 1, wn = wave & 1;
@@ -1213,12 +1305,12 @@ __device__ inline void dw_x3_body(const DwGroup& g, const DwJob& J, int split, c
   // staging role of this thread: columns 4 cg .. + 4, points 4 pq .. + 4 of operand sop
   const int cg = lane, pq = wave & 3, sop = wave >> 2;
   const bool st_on = !(narrow && sop == 1 && cg >= 16);   // a narrow Y row is 16 column groups
-  char* const swr = lds + sop * kX3OpBytes + (pq >> 1) * kX3Half + cg * 16 + (pq & 1) * 8;   // + buffer, column, plane
+  char* const swr = lds + sop * kOp + (pq >> 1) * kX3Half + cg * 16 + (pq & 1) * 8;   // + buffer, column, plane
   // fragment addresses of this lane: column 64 wm (128 wn) + 32 t + i of the operand, point half h
   const int i = lane & 31, h = lane >> 5;
   const int ui = (i & 3) * 68 + (i >> 2);
   const char* const fx = lds + h * kX3Half + (ui + 16 * wm) * 16;
-  const char* const fy = lds + kX3OpBytes + h * kX3Half + (ui + (narrow ? 8 : 32) * wn) * 16;
+  const char* const fy = lds + kOp + h * kX3Half + (ui + (narrow ? 8 : 32) * wn) * 16;
   constexpr int NTJ = NARROW ? 1 : 4;
   v16f acc[2][NTJ];
 #pragma unroll
@@ -1228,12 +1320,23 @@ __device__ inline void dw_x3_body(const DwGroup& g, const DwJob& J, int split, c
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[ti][tj][r] = 0.f;
   double bs[4] = {0.0, 0.0, 0.0, 0.0};
+  // x2h: one scale for the adjoint operands of all pairs of the job (they share the accumulators), from the larger of
+  // their recorded maxima; the state operands (activations, Jacobian rows, network inputs) carry kH2ActScale
+  [[maybe_unused]] float s_adj = 1.f, unscale = 1.f;
+  if constexpr (NP == 2) {
+    unsigned mb = J.p1.amax ? *J.p1.amax : 0u;
+    if (J.npairs > 1 && J.p2.amax) mb = max(mb, *J.p2.amax);
+    float inv;
+    x2h_dyn_scale(mb, s_adj, inv);
+    unscale = inv * (1.f / kH2ActScale);
+  }
   [[maybe_unused]] unsigned long long t_bar = 0, t_chunk = 0, t_load = 0, t_all = 0;
   [[maybe_unused]] const unsigned long long t_begin = DUMMY == 1 ? __builtin_amdgcn_s_memtime() : 0;
   [[maybe_unused]] const unsigned long long r_begin = DUMMY == 1 ? __builtin_amdgcn_s_memrealtime() : 0;
   for (int pi = 0; pi < J.npairs; ++pi) {
     const DwPair p = pi == 0 ? J.p1 : J.p2;
     const int ld = sop == 0 ? p.ldx : p.ldy;
+    [[maybe_unused]] const float sc = NP == 2 ? (sop == p.adj ? s_adj : kH2ActScale) : 1.f;   // this thread's operand
     // resource based at this split's first row: 32-bit offsets stay inside the split whatever the total point count
     const BufRsrc src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>((sop == 0 ? p.X : p.Y) + (size_t)m_begin * ld), 0,
                                                           0xfffffffc, 0x00020000);
@@ -1246,9 +1349,9 @@ __device__ inline void dw_x3_body(const DwGroup& g, const DwJob& J, int split, c
     dw_x3_load(src, voff, ld, r0 + min(1, last) * kX3Chunk, x1);
     __builtin_amdgcn_s_barrier();   // every wave is done with the buffers of the previous pair
     {
-      vu2x hi[4], mid[4], lo[4];
-      dw_x3_split(x0, hi, mid, lo);
-      if (st_on) dw_x3_store(swr, hi, mid, lo);
+      vu2x pl[4][NP];
+      dw_x3_split<NP>(x0, sc, pl);
+      if (st_on) dw_x3_store<NP>(swr, pl);
       dw_x3_colsum(x0, do_bias, bs);
     }
     dw_x3_load(src, voff, ld, r0 + min(2, last) * kX3Chunk, x0);
@@ -1258,8 +1361,8 @@ __device__ inline void dw_x3_body(const DwGroup& g, const DwJob& J, int split, c
       [[maybe_unused]] const unsigned long long s0 = DUMMY == 1 ? __builtin_amdgcn_s_memtime() : 0;
       __builtin_amdgcn_s_barrier();
       [[maybe_unused]] const unsigned long long s1 = DUMMY == 1 ? __builtin_amdgcn_s_memtime() : 0;
-      if constexpr (narrow) dw_x3_chunk_narrow(fx, fy, acc, x1, swr + kX3BufBytes, st_on);
-      else dw_x3_chunk(fx, fy, acc, x1, swr + kX3BufBytes);
+      if constexpr (narrow) dw_x3_chunk_narrow<NP>(fx, fy, acc, x1, sc, swr + kBuf, st_on);
+      else dw_x3_chunk<NP>(fx, fy, acc, x1, sc, swr + kBuf);
       dw_x3_colsum(x1, do_bias, bs);   // (nchunks even: chunk c + 1 always exists)
       [[maybe_unused]] const unsigned long long s2 = DUMMY == 1 ? __builtin_amdgcn_s_memtime() : 0;
       dw_x3_load(src, voff, ld, r0 + min(c + 3, last) * kX3Chunk, x1);
@@ -1271,8 +1374,8 @@ __device__ inline void dw_x3_body(const DwGroup& g, const DwJob& J, int split, c
       // nobody reads); x0 <- chunk c + 4
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      if constexpr (narrow) dw_x3_chunk_narrow(fx + kX3BufBytes, fy + kX3BufBytes, acc, x0, swr, st_on);
-      else dw_x3_chunk(fx + kX3BufBytes, fy + kX3BufBytes, acc, x0, swr);
+      if constexpr (narrow) dw_x3_chunk_narrow<NP>(fx + kBuf, fy + kBuf, acc, x0, sc, swr, st_on);
+      else dw_x3_chunk<NP>(fx + kBuf, fy + kBuf, acc, x0, sc, swr);
       dw_x3_colsum(x0, do_bias && c + 2 < nchunks, bs);
       dw_x3_load(src, voff, ld, r0 + min(c + 4, last) * kX3Chunk, x0);
     }
@@ -1289,8 +1392,9 @@ __device__ inline void dw_x3_body(const DwGroup& g, const DwJob& J, int split, c
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = wm * 64 + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (pdst) __builtin_nontemporal_store(acc[ti][tj][r], pdst + (size_t)row * Kj + col);
-        else atomicAdd(J.dW + (size_t)row * lddw + col, acc[ti][tj][r]);
+        const float v = NP == 2 ? acc[ti][tj][r] * unscale : acc[ti][tj][r];
+        if (pdst) __builtin_nontemporal_store(v, pdst + (size_t)row * Kj + col);
+        else atomicAdd(J.dW + (size_t)row * lddw + col, v);
       }
   }
   if constexpr (DUMMY == 1) {
@@ -1318,9 +1422,9 @@ __device__ inline void dw_x3_body(const DwGroup& g, const DwJob& J, int split, c
 }
 
 
-template <int DUMMY>
+template <int DUMMY, int NP = 3>
 __global__ __launch_bounds__(512, 1) void gemm_dw_x3_kernel(const DwGroup g) {
-  __shared__ __attribute__((aligned(16))) char lds[2 * kX3BufBytes];   // 102 KB
+  __shared__ __attribute__((aligned(16))) char lds[2 * dw_buf_bytes<NP>() > 8192 ? 2 * dw_buf_bytes<NP>() : 8192];   // 102 KB (NP = 2: 68 KB)
   int ji = 0, begin = 0;
   for (int q = 0; q + 1 < g.njobs; ++q)
     if ((int)blockIdx.x >= g.job[q].block_end) { ji = q + 1; begin = g.job[q].block_end; }
@@ -1328,8 +1432,8 @@ __global__ __launch_bounds__(512, 1) void gemm_dw_x3_kernel(const DwGroup g) {
   const int split = (int)blockIdx.x - begin;
   if (split >= J.splits) return;
   // two bodies, one per job width (workgroup-uniform): separate accumulator sets, separate register allocation
-  if (J.K < 256) dw_x3_body<DUMMY, true>(g, J, split, lds);
-  else dw_x3_body<DUMMY, false>(g, J, split, lds);
+  if (J.K < 256) dw_x3_body<DUMMY, true, NP>(g, J, split, lds);
+  else dw_x3_body<DUMMY, false, NP>(g, J, split, lds);
 }
 
 // ---- activation helpers ----------------------------------------------------------------------------

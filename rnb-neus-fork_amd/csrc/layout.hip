@@ -168,6 +168,7 @@ void carve_points(const Layout& L, Carver& c, int64_t M, int mode, PointBufs* pb
       pb->fbar_k8 = c.take<uint16_t>(Mp * L.Hp);
     }
     pb->geb = c.take<float>(Mp * L.Ep);
+    pb->amax = c.take<unsigned>(AMAX_SLOTS);
     pb->sbar = c.take<float>(Mp);
     pb->nbar = c.take<float>(Mp * 4);
     pb->albbar = c.take<float>(Mp * 4);

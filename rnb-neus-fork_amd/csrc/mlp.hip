@@ -217,7 +217,7 @@ __global__ __launch_bounds__(512) void color_out_bwd_kernel(const float* __restr
                                                             const float* __restrict__ Wo, int ldwo, int Co,
                                                             int squeeze, int64_t M, int rows_per_blk,
                                                             float* __restrict__ zc, float* __restrict__ dWo,
-                                                            float* __restrict__ dbo) {
+                                                            float* __restrict__ dbo, unsigned* __restrict__ amax) {
   __shared__ float red[64][4][33];
   __shared__ float redb[64][4];
   const int tid = threadIdx.x, cg = tid & 7, ph = tid >> 3;
@@ -226,6 +226,7 @@ __global__ __launch_bounds__(512) void color_out_bwd_kernel(const float* __restr
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_blk;
   const int64_t r1 = min(M, r0 + rows_per_blk);
   float w[4][4], dw[4][4], db[4] = {0.f, 0.f, 0.f, 0.f};
+  float zmax = 0.f;   // max |zc| written by this thread (rows < M only: the loop stops at r1)
 #pragma unroll
   for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -252,9 +253,11 @@ __global__ __launch_bounds__(512) void color_out_bwd_kernel(const float* __restr
 #pragma unroll
       for (int c = 0; c < 4; ++c) { t = fmaf(zo[c], w[c][j], t); dw[c][j] = fmaf(zo[c], av[j], dw[c][j]); }
       z[j] = (k0 + j < Hc && av[j] > 0.f) ? t : 0.f;
+      zmax = fmaxf(zmax, fabsf(z[j]));
     }
     *reinterpret_cast<vf4*>(zc + row * Hcp + k0) = z;
   }
+  amax_commit(amax, zmax, tid & 63);
 #pragma unroll
   for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -284,7 +287,8 @@ __global__ __launch_bounds__(64) void nbar_geb_kernel(const float* __restrict__ 
                                                       const float* __restrict__ nbar_in,
                                                       const float* __restrict__ cinb, int Cinp, int blk_off,
                                                       int pen_off, int multires_view, int with_color, int multires,
-                                                      int Ep, int64_t M, int64_t Mp, float* __restrict__ geb) {
+                                                      int Ep, int64_t M, int64_t Mp, float* __restrict__ geb,
+                                                      unsigned* __restrict__ amax) {
   extern __shared__ float tile[];
   const int lane = threadIdx.x;
   const int64_t r0 = (int64_t)blockIdx.x * 64, row = r0 + lane;
@@ -331,6 +335,11 @@ __global__ __launch_bounds__(64) void nbar_geb_kernel(const float* __restrict__ 
     f *= 2.f;
   }
   for (; c < Ep; ++c) o[c] = 0.f;
+  if (amax != nullptr) {   // max |geb| (rows >= M carry nb = 0): the scale of layer 0's weight-gradient job (x2h)
+    float m = 0.f;
+    for (int q = 0; q < Ep; ++q) m = fmaxf(m, fabsf(o[q]));
+    amax_commit(amax, m, lane);
+  }
   __builtin_amdgcn_wave_barrier();
   tile_store64(geb, Ep, r0, 0, Ep, tile, lane);
 }
@@ -616,7 +625,8 @@ static inline double mm_flops(int64_t M, const Lin& ln) { return 2.0 * (double)M
 // x3: the product as six bf16 MFMA terms (RNB_VARIANT_X3; k-contiguous weights, N >= 256, K % 16 == 0)
 template <bool B_KMAJOR, class Epi>
 static int launch_rows(const float* A, int lda, const float* W, int ldw, int64_t Mp, int N, int K, const Epi& epi,
-                       double flops, hipStream_t s, bool x3 = false, const x3raw* W3 = nullptr, const x3raw* Wh2 = nullptr) {
+                       double flops, hipStream_t s, bool x3 = false, const x3raw* W3 = nullptr, const x3raw* Wh2 = nullptr,
+                       unsigned* amax = nullptr, int64_t m_real = 0) {
   ProfScope prof(flops, s, Wh2 ? "layer_gemm(forward)" : "layer_gemm");
   if constexpr (!B_KMAJOR) {
     // Wh2: this matrix in the fp16 mirror (x2h; forward layers only)
@@ -628,8 +638,8 @@ static int launch_rows(const float* A, int lda, const float* W, int ldw, int64_t
     }
     // W3: this matrix in the split mirror (x3_pack_weights): the weights are then read as ready-made fragments
     if (x3 && W3 != nullptr && N % 32 == 0 && N <= 512 && K % 32 == 0 && Mp % 128 == 0) {
-      if (N <= 256) hipLaunchKernelGGL((gemm_rows_x3m_kernel<1, Epi>), dim3((unsigned)(Mp / 128)), dim3(512), 0, s, A, lda, W3, N, K, epi);
-      else hipLaunchKernelGGL((gemm_rows_x3m_kernel<2, Epi>), dim3((unsigned)(Mp / 128)), dim3(512), 0, s, A, lda, W3, N, K, epi);
+      if (N <= 256) hipLaunchKernelGGL((gemm_rows_x3m_kernel<1, Epi>), dim3((unsigned)(Mp / 128)), dim3(512), 0, s, A, lda, W3, N, K, epi, amax, (long long)m_real);
+      else hipLaunchKernelGGL((gemm_rows_x3m_kernel<2, Epi>), dim3((unsigned)(Mp / 128)), dim3(512), 0, s, A, lda, W3, N, K, epi, amax, (long long)m_real);
       RNB_CHECK_LAUNCH();
       return RNB_OK;
     }
@@ -720,6 +730,7 @@ struct DwBatch {
   bool lds_path;      // RNB_VARIANT_DW_LDS: staged-through-LDS kernels (A/B switch)
   bool no_staged = true;    // RNB_VARIANT_DW_STAGED clears it: 256 x 256 jobs through the LDS-DMA staged kernel
   bool x3 = false;          // RNB_VARIANT_X3: 256 x 256 jobs through gemm_dw_x3_kernel (same split plan and slabs)
+  bool h2 = false;          // RNB_VARIANT_X2H: ... as three fp16 terms, the adjoint operands scaled by their recorded maxima
   float* part;        // RNB_VARIANT_DETERMINISTIC: bump allocator over the zeroed partial-slab workspace (or nullptr)
   int64_t part_left;
   float* slab;        // slabs of the staged 256 x 256 kernel (always; the tail of the same workspace)
@@ -772,7 +783,8 @@ struct DwBatch {
     }
     {
       ProfScope prof(flops[3], s, "dW(x3: 256x256 + narrow jobs + reduce)");
-      if (x3) hipLaunchKernelGGL(gemm_dw_x3_kernel<0>, dim3((unsigned)end), dim3(512), 0, s, g);
+      if (x3 && h2) hipLaunchKernelGGL((gemm_dw_x3_kernel<0, 2>), dim3((unsigned)end), dim3(512), 0, s, g);
+      else if (x3) hipLaunchKernelGGL((gemm_dw_x3_kernel<0, 3>), dim3((unsigned)end), dim3(512), 0, s, g);
       else hipLaunchKernelGGL(gemm_dw_staged_kernel<0>, dim3((unsigned)end), dim3(1024), 0, s, g);
       RNB_CHECK_LAUNCH();
       hipLaunchKernelGGL(dw_reduce_kernel<0>, dim3(256, g.njobs), dim3(256), 0, s, g);
@@ -1048,6 +1060,10 @@ int sweep_backward(const Layout& L, const float* packed, PointBufs& pb, bool wit
              pb.dw_part + det_floats, staged_floats);
   dw.x3 = is_x3(L);
   dw.no_staged = (L.variant & RNB_VARIANT_DW_STAGED) == 0 && !dw.x3;
+  // x2h weight gradients: every adjoint tensor's producer (fused sweeps, albedo backward) records its maximum
+  const bool h2 = is_x2h(L) && fused && !is_bf16(L) && pb.amax != nullptr;
+  dw.h2 = h2;
+  if (h2) RNB_CHECK_HIP(hipMemsetAsync(pb.amax, 0, AMAX_SLOTS * sizeof(unsigned), s));
   const bool color_bf16 = is_bf16(L) && with_color && bf16_color_supported(L) && pb.cin8 != nullptr;
   // ---- C': albedo network backward ---------------------------------------------------------------
   if (color_bf16) {
@@ -1059,23 +1075,24 @@ int sweep_backward(const Layout& L, const float* packed, PointBufs& pb, bool wit
     rows_per_blk = (rows_per_blk + 63) / 64 * 64;
     hipLaunchKernelGGL(color_out_bwd_kernel, dim3(blocks_for(M, rows_per_blk), chunks), dim3(512), 0, s, pb.albbar, pb.alb,
                        pb.ac[L.nc - 1], L.Hcp, L.Hc, packed + L.colo.w_off, L.colo.Kp, L.Co, L.squeeze, M,
-                       rows_per_blk, pb.zc[L.nc - 1], packed_grad + L.colo.w_off, packed_grad + L.colo.b_off);
+                       rows_per_blk, pb.zc[L.nc - 1], packed_grad + L.colo.w_off, packed_grad + L.colo.b_off,
+                       h2 ? pb.amax + AMAX_ZC + (L.nc - 1) : (unsigned*)nullptr);
     RNB_CHECK_LAUNCH();
     for (int l = L.nc - 1; l >= 0; --l) {
       const Lin& ln = L.col[l];
       const float* in = l == 0 ? pb.cin : pb.ac[l - 1];
       const int ldin = l == 0 ? L.Cinp : L.Hcp;
-      DwPair p{pb.zc[l], L.Hcp, in, ldin};
+      DwPair p{pb.zc[l], L.Hcp, in, ldin, 0, h2 ? pb.amax + AMAX_ZC + l : nullptr};
       RNB_TRY(dw.add(p, p, 1, ln.Np, ln.Kp, packed_grad + ln.w_off, ln.Kp, packed_grad + ln.b_off, 0, mm_flops(M, ln)));
       if (l > 0) {
         EpiReluMask epi{pb.ac[l - 1], pb.zc[l - 1], L.Hcp, L.col[l - 1].N};
         // zc_{l-1} = (zc_l W_l) * relu': k-contiguous product against the transposed copy W_l^T [Kp x Np]
         RNB_TRY((launch_rows<false, EpiReluMask>(pb.zc[l], L.Hcp, packed + ln.wT_off, ln.Np, Mp, ln.Kp, ln.Np, epi, mm_flops(M, ln), s, is_x3(L),
-                                                 x3_mirror(L, packed, ln.wT_off))));
+                                                 x3_mirror(L, packed, ln.wT_off), nullptr, h2 ? pb.amax + AMAX_ZC + (l - 1) : nullptr, M)));
       } else {
         EpiStore epi{pb.cinb, L.Cinp};
         RNB_TRY((launch_rows<false, EpiStore>(pb.zc[0], L.Hcp, packed + ln.wT_off, ln.Np, Mp, ln.Kp, ln.Np, epi, mm_flops(M, ln), s, is_x3(L),
-                                              x3_mirror(L, packed, ln.wT_off))));
+                                              x3_mirror(L, packed, ln.wT_off), nullptr, h2 ? pb.amax + AMAX_CINB : nullptr, M)));
       }
     }
   }
@@ -1084,7 +1101,7 @@ int sweep_backward(const Layout& L, const float* packed, PointBufs& pb, bool wit
     const int wt = (with_color && L.Cinp - L.F > L.Ep) ? L.Cinp - L.F : L.Ep;
     hipLaunchKernelGGL(nbar_geb_kernel, dim3(blocks_for(Mp, 64)), dim3(64), (size_t)64 * (wt + 1) * sizeof(float), s,
                        pb.x, pb.nrm, pb.nbar, pb.cinb, L.Cinp, L.F, L.F + L.pev, L.multires_view, with_color ? 1 : 0,
-                       L.multires, L.Ep, M, Mp, pb.geb);
+                       L.multires, L.Ep, M, Mp, pb.geb, h2 ? pb.amax + AMAX_U : (unsigned*)nullptr);
   }
   RNB_CHECK_LAUNCH();
   if (is_bf16(L)) {
@@ -1130,7 +1147,7 @@ int sweep_backward(const Layout& L, const float* packed, PointBufs& pb, bool wit
                                         with_color ? mm_flops(M, L.feat) : 0.0, s)));
     }
     if (with_color) {
-      DwPair p{pb.cinb, L.Cinp, pb.a[L.nh - 1], L.Hp};
+      DwPair p{pb.cinb, L.Cinp, pb.a[L.nh - 1], L.Hp, 0, h2 ? pb.amax + AMAX_CINB : nullptr};
       RNB_TRY(dw.add(p, p, 1, L.feat.Np, L.feat.Kp, packed_grad + L.feat.w_off, L.feat.Kp,
                      packed_grad + L.feat.b_off, 0, mm_flops(M, L.feat)));
     }
@@ -1141,8 +1158,8 @@ int sweep_backward(const Layout& L, const float* packed, PointBufs& pb, bool wit
     const float* in = l == 0 ? pb.e : pb.a[l - 1];
     const int ldin = l == 0 ? L.Ep : L.Hp;
     const float* uin = l == 0 ? pb.geb : pb.u[l];
-    DwPair p1{pb.gz[l], L.Hp, uin, ldin};
-    DwPair p2{pb.zb[l], L.Hp, in, ldin};
+    DwPair p1{pb.gz[l], L.Hp, uin, ldin, 1, h2 ? pb.amax + AMAX_U + l : nullptr};
+    DwPair p2{pb.zb[l], L.Hp, in, ldin, 0, h2 ? pb.amax + AMAX_ZB + l : nullptr};
     RNB_TRY(dw.add(p1, p2, 2, ln.Np, ln.Kp, packed_grad + ln.w_off, ln.Kp, packed_grad + ln.b_off, 1,
                    2.0 * mm_flops(M, ln)));
     if (l > 0 && !fused) {

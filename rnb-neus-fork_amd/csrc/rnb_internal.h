@@ -149,10 +149,13 @@ struct PointBufs {
   void* ac8[RNB_MAX_LIN];   //   hidden activations as bf16 K8 [Mp,256]
   void* zc8[RNB_MAX_LIN];   //   pre-activation adjoints as bf16 K8 [Mp,256]
   void* fbar_k8;            // RNB_VARIANT_BF16: feature part of cinb as bf16 K8 [Mp,256] (written by the FB sweep)
+  unsigned* amax;           // [AMAX_SLOTS] max |.| of the adjoint tensors (float bits; zeroed at the start of a backward)
   float* dw_part;           // partial slabs of the split-K weight-gradient GEMMs: [deterministic variant | staged kernel]
   int64_t dw_part_floats;
 };
 
+// slots of PointBufs::amax: zb_l, u_l (u_0 = geb), zc_l, cinb
+enum { AMAX_ZB = 0, AMAX_U = RNB_MAX_LIN, AMAX_ZC = 2 * RNB_MAX_LIN + 1, AMAX_CINB = 3 * RNB_MAX_LIN + 1, AMAX_SLOTS = 3 * RNB_MAX_LIN + 2 };
 enum PointMode { PM_SDF_ONLY = 0, PM_WITH_NORMAL = 1, PM_WITH_COLOR = 2, PM_WITH_BACKWARD = 4 };
 void carve_points(const Layout& L, Carver& c, int64_t M, int mode, PointBufs* pb);
 
