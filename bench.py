@@ -66,10 +66,22 @@ HBM_BOUND_TBS = 4.0    # a class that moves more than this (PMC bytes / event ti
                        # spec, ~2/3 of what a plain copy reaches (6.3 TB/s)
 
 
-def kernel_classes(lib, steps, peak_tflops, traffic=None):
+# matrix terms per fp32 product of every kernel class under the default arithmetic (RNB_VARIANT_X3 + X2H): three fp16 terms
+# except the RA sweep, which keeps the six bf16 terms (state-traffic bound: DESIGN 4)
+X2H_TERMS = {"F_sweep(save)": 3, "F_sweep(forward_only)": 3, "R_sweep": 3, "FB_sweep": 3,
+             "dW(x3: 256x256 + narrow jobs + reduce)": 3, "layer_gemm(forward)": 3, "RA_sweep": 6, "layer_gemm": 3}
+
+
+def class_peak(tag, default_peak, terms):
+    """MFMA ceiling of one kernel class in algorithmic fp32 TFLOP/s: the dense 16-bit peak over its terms per product."""
+    return BF16_MFMA_PEAK_TFLOPS / terms[tag] if terms and tag in terms else default_peak
+
+
+def kernel_classes(lib, steps, peak_tflops, traffic=None, terms=None):
     """Per kernel class of the last rnb_profile_collect (HIP events on the launch stream): ms per step, launches per step,
-    algorithmic TFLOP/s and its fraction of `peak_tflops`; with the stored PMC traffic of the same workload also the
-    HBM rate of the class and the roof that bounds it (`bound`: "hbm" above HBM_BOUND_TBS, else "mfma"); sorted by time."""
+    algorithmic TFLOP/s and its fraction of the class's MFMA ceiling (`peak_tflops`, or 2500 / terms[class]); with the
+    stored PMC traffic of the same workload also the HBM rate of the class and the roof that bounds it (`bound`: "hbm"
+    above HBM_BOUND_TBS, else "mfma"); sorted by time."""
     need = lib.rnb_profile_report(None, 0)
     buf = C.create_string_buffer(int(need) + 16)
     lib.rnb_profile_report(buf, len(buf))
@@ -80,8 +92,12 @@ def kernel_classes(lib, steps, peak_tflops, traffic=None):
         if ms <= 0:
             continue
         tf = fl / (ms * 1e-3) / 1e12
+        pk = class_peak(tag, peak_tflops, terms)
         d = {"kernel_class": tag, "ms_per_step": round(ms / steps, 4), "launches_per_step": n / steps,
-             "tflops": round(tf, 2), "frac": round(tf / peak_tflops, 4)}
+             "tflops": round(tf, 2), "frac": round(tf / pk, 4), "flop_per_step": fl / steps}
+        if terms:
+            d["terms"] = terms.get(tag)
+            d["peak"] = round(pk, 1)
         key = CLASS_KERNELS.get(tag)
         if traffic and key:
             b = sum((2.0 * v["fetch_size_raw_kb_per_launch"] + v["write_size_kb_per_launch"]) * 1024.0 * v["launches_per_step"]
@@ -545,10 +561,23 @@ def measure_train(args, ctx, with_cpu=True):
                 # --f32-mfma: v_mfma_f32_32x32x2_f32 against the fp32 MFMA peak.  `achieved` counts ALGORITHMIC fp32
                 # FLOPs (2 M N K of the real layer shapes), never the six terms.
                 x3 = not args.f32_mfma
+                x2h = x3 and args.x2h is not False
+                terms = X2H_TERMS if x2h else None
                 peak = BF16_MFMA_PEAK_TFLOPS / 6.0 if x3 else FP32_MFMA_PEAK_TFLOPS
+                by = kernel_classes(lib, args.steps, peak, tr, terms)
+                if x2h and by:
+                    # mixed arithmetic: the ceiling of the family is the rate at which its classes would finish if each ran
+                    # at its own MFMA peak (flop-weighted harmonic mean): frac = ideal matrix time / measured time
+                    ideal_ms = sum(k["flop_per_step"] / (class_peak(k["kernel_class"], peak, terms) * 1e12) * 1e3 for k in by)
+                    peak = sum(k["flop_per_step"] for k in by) / (ideal_ms * 1e-3) / 1e12
+                for k in by:
+                    k.pop("flop_per_step", None)
                 roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
                         "frac": round(ach / peak, 4),
-                        "peak_basis": ("2500 TFLOP/s dense bf16 MFMA / 6 bf16 terms per fp32 product (x3 arithmetic)" if x3
+                        "peak_basis": ("2500 TFLOP/s dense 16-bit MFMA / terms per fp32 product, per kernel class (x2h: three "
+                                       "fp16 terms: 833.3; RA sweep: six bf16 terms: 416.7), combined as "
+                                       "the flop-weighted harmonic mean: frac = ideal matrix time / measured time" if x2h else
+                                       "2500 TFLOP/s dense bf16 MFMA / 6 bf16 terms per fp32 product (x3 arithmetic)" if x3
                                        else "157.3 TFLOP/s dense fp32 MFMA"),
                         "frac_of_fp32_mfma_peak": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
                         "traffic": round(tr["hbm_bytes_per_launch"]) if tr else None,
@@ -557,14 +586,16 @@ def measure_train(args, ctx, with_cpu=True):
                         "traffic_detail": ({"hbm_bytes_per_step": round(tr["hbm_bytes_per_step"]),
                                             "launches_per_step": tr["launches_per_step"],
                                             "source": "profiles/" + traffic_file} if tr else None),
-                        "kernel": ("x3 MFMA family: fused_forward/reverse/ra/fb_kernel<.., true>, gemm_dw_x3_kernel, "
+                        "kernel": ("split-operand MFMA family: fused_forward/reverse_kernel<.., true, true>, fused_fb_h2_kernel, "
+                                   "gemm_dw_x3_kernel<0, 2>, gemm_rows_x3m_kernel<.., 2> (three fp16 terms); fused_ra_kernel<.., true> "
+                                   "(six bf16 terms)" if x2h else
+                                   "x3 MFMA family: fused_forward/reverse/ra/fb_kernel<.., true>, gemm_dw_x3_kernel, "
                                    "gemm_rows_x3_kernel<*> (+ gemm_dw_direct_kernel<64> for the K = 64 / 320 gradients)" if x3 else
                                    "fp32-MFMA family: fused_forward/reverse/ra/fb_kernel, gemm_dw_direct_kernel, "
                                    "gemm_rows_kernel<*>"),
                         "step_frac": round(step_tf / peak, 4),
                         "step_frac_of_fp32_mfma_peak": round(step_tf / FP32_MFMA_PEAK_TFLOPS, 4)}
                 roof.update(common)
-                by = kernel_classes(lib, args.steps, peak, tr)
                 if by:
                     roof["dominant_kernel"] = by[0]     # the class with the largest share of the step
                     roof["by_kernel_class"] = by
@@ -611,7 +642,11 @@ def measure_train(args, ctx, with_cpu=True):
             "arithmetic": ("bf16 operands, fp32 accumulate (v_mfma_f32_32x32x16_bf16); masters, gradients, epilogues fp32" if bf16 else
                            ("fp32 MFMA (v_mfma_f32_32x32x2_f32)" if args.f32_mfma else
                             "x3: every fp32 operand as 3 bf16 terms (hi + mid + lo = x exactly), 6 of the 9 cross terms per product "
-                            "on v_mfma_f32_32x32x16_bf16, fp32 accumulate; dropped terms < 2^-26 |ab|")),
+                            "on v_mfma_f32_32x32x16_bf16, fp32 accumulate; dropped terms < 2^-26 |ab|" if args.x2h is False else
+                            "x2h: fp32 operands as 2 fp16 terms after a power-of-two scale (fixed for weights / activations / "
+                            "Jacobian rows, taken from the data for loss adjoints), 3 of the 4 cross terms per product on "
+                            "v_mfma_f32_32x32x16_f16, fp32 accumulate; operand representation <= 2^-22 (rms 2^-23.6); the RA sweep "
+                            "keeps x3 (3 bf16 terms per operand, 6 cross terms)")),
             "build_id": bid,
             "rccl_ranks": world if backend == "nccl" else (1 if world == 1 else 0),
             # the flat gradient buffer is all-reduced after the backward sweeps have finished (renderer.py: one all_reduce on
@@ -662,6 +697,7 @@ ALSO_LEGS = (
     ("config 3: wmask_rnb_noalbedo.conf (normal-only loss path)", dict(no_albedo=True)),
     ("config 5 (1-GPU leg): bf16 sweeps, 256 samples per ray", dict(dtype="bf16", samples=256)),
     ("NeuSRenderer.render, forward only (no_grad)", dict(mode="render")),
+    ("A/B: six bf16 terms in every product (RNB_VARIANT_NO_X2H: the round-3 arithmetic)", dict(x2h=False)),
     ("A/B: native fp32 MFMA arithmetic (RNB_VARIANT_F32_MFMA)", dict(f32_mfma=True)),
 )
 
@@ -673,7 +709,8 @@ def run_train(args):
     world, rank = ctx[0], ctx[1]
     line = measure_train(args, ctx, with_cpu=False)
     plain = (world == 1 and args.mode == "train" and not args.no_also and not args.device_rays and not args.no_albedo
-             and args.dtype == "f32" and not args.f32_mfma and not args.warmup_mode and args.rays == 512 and args.samples == 128)
+             and args.dtype == "f32" and not args.f32_mfma and args.x2h is None and not args.warmup_mode and args.rays == 512
+             and args.samples == 128)
     if plain:
         also = []
         for name, kw in ALSO_LEGS:

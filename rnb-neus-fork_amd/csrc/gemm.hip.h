@@ -422,6 +422,13 @@ __device__ inline float x2h_resid_hi(float x, unsigned h) {
   asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(x), "v"(h));
   return r;
 }
+// the power-of-two scale of the adjoint operand of an x2h job: its maximum (float bits `mbits`) goes to [2^13, 2^14)
+__device__ inline void x2h_dyn_scale(unsigned mbits, float& s, float& inv_s) {
+  int ef = (int)(mbits >> 23);                        // biased exponent of the maximum (0: all zero)
+  ef = ef < 24 ? 24 : (ef > 250 ? 250 : ef);          // both factors stay normal numbers
+  s = __builtin_bit_cast(float, (unsigned)(267 - ef) << 23);        // 2^(13 - e)
+  inv_s = __builtin_bit_cast(float, (unsigned)(ef - 13) << 23);     // 2^(e - 13)
+}
 // 8 consecutive k of one row (already scaled) -> hi / lo operand registers: 4 instructions per pair
 __device__ inline void x2h_split8(const vf4& x0, const vf4& x1, vu4x& hi, vu4x& lo) {
   const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
@@ -1013,7 +1020,8 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_x3_kernel(const float* __res
 template <int TJ, class Epi, int NP = 3>
 __global__ __launch_bounds__(512, 1) void gemm_rows_x3m_kernel(const float* __restrict__ A, int lda,
                                                                const x3raw* __restrict__ W3, int N, int K, Epi epi,
-                                                               unsigned* amax = nullptr, long long m_real = 0) {
+                                                               unsigned* amax = nullptr, long long m_real = 0,
+                                                               const unsigned* in_amax = nullptr) {
   constexpr int ROWS = 128;
   constexpr int PLB = ROWS * XP;              // bytes of one plane
   constexpr int BUFB = NP * PLB;              // one staging buffer (three planes: 18,432 B)
@@ -1048,6 +1056,12 @@ __global__ __launch_bounds__(512, 1) void gemm_rows_x3m_kernel(const float* __re
   auto load_a = [&](int ks) {
     return __builtin_bit_cast(vf4, __builtin_amdgcn_raw_buffer_load_b128(rsA, aoff, (unsigned)ks * 64u, RNB_AUX_LD));
   };
+  // NP == 2: scale of the rows: fixed for forward activations; for a loss adjoint (backward layers) from the maximum its
+  // producer recorded (in_amax), like the weight-gradient jobs
+  [[maybe_unused]] float sa = kH2ActScale, isa = 1.f / kH2ActScale;
+  if constexpr (NP == 2) {
+    if (in_amax != nullptr) x2h_dyn_scale(*in_amax, sa, isa);
+  }
   auto stage = [&](const vf4& x, int buf) {
     char* w = swr + buf * BUFB;
     if constexpr (NP == 3) {
@@ -1058,7 +1072,7 @@ __global__ __launch_bounds__(512, 1) void gemm_rows_x3m_kernel(const float* __re
       *reinterpret_cast<vu2x*>(w + 2 * PLB) = lo;
     } else {
       vu2x hi, lo;
-      x2h_split4(x * kH2ActScale, hi, lo);
+      x2h_split4(x * sa, hi, lo);
       *reinterpret_cast<vu2x*>(w) = hi;
       *reinterpret_cast<vu2x*>(w + PLB) = lo;
     }
@@ -1124,6 +1138,7 @@ __global__ __launch_bounds__(512, 1) void gemm_rows_x3m_kernel(const float* __re
       for (int ti = 0; ti < 4; ++ti) t[ti][0] = acc[ti][tj];
       m = fmaxf(m, acc_absmax<4, 1>(t, lane, left >= ROWS ? ROWS : (int)(left < 0 ? 0 : left)));
     }
+    if constexpr (NP == 2) m *= isa * (1.f / kH2WScale);   // (the accumulators are still scaled)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     if (lane == 0) wmx[wave] = m;
@@ -1140,7 +1155,7 @@ __global__ __launch_bounds__(512, 1) void gemm_rows_x3m_kernel(const float* __re
     if (!on[tj]) continue;
     v16f t[4][1];
 #pragma unroll
-    for (int ti = 0; ti < 4; ++ti) t[ti][0] = NP == 3 ? acc[ti][tj] : acc[ti][tj] * (1.f / (kH2ActScale * kH2WScale));
+    for (int ti = 0; ti < 4; ++ti) t[ti][0] = NP == 3 ? acc[ti][tj] : acc[ti][tj] * (isa * (1.f / kH2WScale));
     run_epilogue<1, Epi, 4>(t, strip, m_blk, nt[tj] * 32, lane, 1u, epi);
   }
 }
@@ -1165,13 +1180,6 @@ constexpr int kX3BufBytes = 2 * kX3OpBytes;     // both operands
 // NP planes per operand (3: bf16 hi / mid / lo, six terms; 2: fp16 hi / lo, three terms — "x2h")
 template <int NP> constexpr int dw_op_bytes() { return NP * kX3Plane; }
 template <int NP> constexpr int dw_buf_bytes() { return 2 * NP * kX3Plane; }
-// the power-of-two scale of the adjoint operand of an x2h job: its maximum (float bits `mbits`) goes to [2^13, 2^14)
-__device__ inline void x2h_dyn_scale(unsigned mbits, float& s, float& inv_s) {
-  int ef = (int)(mbits >> 23);                        // biased exponent of the maximum (0: all zero)
-  ef = ef < 24 ? 24 : (ef > 250 ? 250 : ef);          // both factors stay normal numbers
-  s = __builtin_bit_cast(float, (unsigned)(267 - ef) << 23);        // 2^(13 - e)
-  inv_s = __builtin_bit_cast(float, (unsigned)(ef - 13) << 23);     // 2^(e - 13)
-}
 
 // (buffer loads: the lane's column offset in one VGPR, the wave-uniform row offset in the scalar operand)
 __device__ inline void dw_x3_load(BufRsrc rs, unsigned voff, int ld, int row0, vf4 (&x)[4]) {

@@ -257,7 +257,12 @@ __global__ __launch_bounds__(512) void color_out_bwd_kernel(const float* __restr
     }
     *reinterpret_cast<vf4*>(zc + row * Hcp + k0) = z;
   }
-  amax_commit(amax, zmax, tid & 63);
+  __shared__ float zm[8];
+  if (amax != nullptr) {   // (uniform)  wave maxima meet in LDS behind the barrier below: one atomic per workgroup
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) zmax = fmaxf(zmax, __shfl_xor(zmax, o, 64));
+    if ((tid & 63) == 0) zm[tid >> 6] = zmax;
+  }
 #pragma unroll
   for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -267,6 +272,12 @@ __global__ __launch_bounds__(512) void color_out_bwd_kernel(const float* __restr
     for (int c = 0; c < 4; ++c) redb[ph][c] = db[c];
   }
   __syncthreads();
+  if (amax != nullptr && tid == 511) {
+    float m = zm[0];
+    for (int w = 1; w < 8; ++w) m = fmaxf(m, zm[w]);
+    const unsigned b = __builtin_bit_cast(unsigned, m);
+    if (b > __atomic_load_n(amax, __ATOMIC_RELAXED)) atomicMax(amax, b);
+  }
   if (tid < 128) {            // (c, column) pairs of this chunk
     const int c = tid >> 5, col = tid & 31;
     float t = 0.f;
@@ -321,6 +332,7 @@ __global__ __launch_bounds__(64) void nbar_geb_kernel(const float* __restrict__ 
   }
   float* o = tile + lane * (Ep + 1);
   o[0] = nb[0]; o[1] = nb[1]; o[2] = nb[2];
+  float gm = fmaxf(fmaxf(fabsf(nb[0]), fabsf(nb[1])), fabsf(nb[2]));   // max |geb| of this row (rows >= M carry nb = 0)
   int c = 3;
   float f = 1.f;
   for (int k = 0; k < multires; ++k) {
@@ -328,18 +340,16 @@ __global__ __launch_bounds__(64) void nbar_geb_kernel(const float* __restrict__ 
     for (int d = 0; d < 3; ++d) {
       float s, co;
       sincosf(x4[row * 4 + d] * f, &s, &co);
-      o[c + d] = f * co * nb[d];
-      o[c + 3 + d] = -f * s * nb[d];
+      const float v0 = f * co * nb[d], v1 = -f * s * nb[d];
+      o[c + d] = v0;
+      o[c + 3 + d] = v1;
+      gm = fmaxf(gm, fmaxf(fabsf(v0), fabsf(v1)));
     }
     c += 6;
     f *= 2.f;
   }
   for (; c < Ep; ++c) o[c] = 0.f;
-  if (amax != nullptr) {   // max |geb| (rows >= M carry nb = 0): the scale of layer 0's weight-gradient job (x2h)
-    float m = 0.f;
-    for (int q = 0; q < Ep; ++q) m = fmaxf(m, fabsf(o[q]));
-    amax_commit(amax, m, lane);
-  }
+  if (amax != nullptr) amax_commit(amax, gm, lane);   // the scale of layer 0's weight-gradient job (x2h)
   __builtin_amdgcn_wave_barrier();
   tile_store64(geb, Ep, r0, 0, Ep, tile, lane);
 }
@@ -626,13 +636,13 @@ static inline double mm_flops(int64_t M, const Lin& ln) { return 2.0 * (double)M
 template <bool B_KMAJOR, class Epi>
 static int launch_rows(const float* A, int lda, const float* W, int ldw, int64_t Mp, int N, int K, const Epi& epi,
                        double flops, hipStream_t s, bool x3 = false, const x3raw* W3 = nullptr, const x3raw* Wh2 = nullptr,
-                       unsigned* amax = nullptr, int64_t m_real = 0) {
-  ProfScope prof(flops, s, Wh2 ? "layer_gemm(forward)" : "layer_gemm");
+                       unsigned* amax = nullptr, int64_t m_real = 0, const unsigned* in_amax = nullptr) {
+  ProfScope prof(flops, s, (Wh2 && !in_amax) ? "layer_gemm(forward)" : "layer_gemm");
   if constexpr (!B_KMAJOR) {
     // Wh2: this matrix in the fp16 mirror (x2h; forward layers only)
     if (x3 && Wh2 != nullptr && N % 32 == 0 && N <= 512 && K % 32 == 0 && Mp % 128 == 0) {
-      if (N <= 256) hipLaunchKernelGGL((gemm_rows_x3m_kernel<1, Epi, 2>), dim3((unsigned)(Mp / 128)), dim3(512), 0, s, A, lda, Wh2, N, K, epi);
-      else hipLaunchKernelGGL((gemm_rows_x3m_kernel<2, Epi, 2>), dim3((unsigned)(Mp / 128)), dim3(512), 0, s, A, lda, Wh2, N, K, epi);
+      if (N <= 256) hipLaunchKernelGGL((gemm_rows_x3m_kernel<1, Epi, 2>), dim3((unsigned)(Mp / 128)), dim3(512), 0, s, A, lda, Wh2, N, K, epi, amax, (long long)m_real, in_amax);
+      else hipLaunchKernelGGL((gemm_rows_x3m_kernel<2, Epi, 2>), dim3((unsigned)(Mp / 128)), dim3(512), 0, s, A, lda, Wh2, N, K, epi, amax, (long long)m_real, in_amax);
       RNB_CHECK_LAUNCH();
       return RNB_OK;
     }
@@ -1088,11 +1098,13 @@ int sweep_backward(const Layout& L, const float* packed, PointBufs& pb, bool wit
         EpiReluMask epi{pb.ac[l - 1], pb.zc[l - 1], L.Hcp, L.col[l - 1].N};
         // zc_{l-1} = (zc_l W_l) * relu': k-contiguous product against the transposed copy W_l^T [Kp x Np]
         RNB_TRY((launch_rows<false, EpiReluMask>(pb.zc[l], L.Hcp, packed + ln.wT_off, ln.Np, Mp, ln.Kp, ln.Np, epi, mm_flops(M, ln), s, is_x3(L),
-                                                 x3_mirror(L, packed, ln.wT_off), nullptr, h2 ? pb.amax + AMAX_ZC + (l - 1) : nullptr, M)));
+                                                 x3_mirror(L, packed, ln.wT_off), h2 ? x2h_mirror(L, packed) + 2 * ln.wT_off : nullptr,
+                                                 h2 ? pb.amax + AMAX_ZC + (l - 1) : nullptr, M, h2 ? pb.amax + AMAX_ZC + l : nullptr)));
       } else {
         EpiStore epi{pb.cinb, L.Cinp};
         RNB_TRY((launch_rows<false, EpiStore>(pb.zc[0], L.Hcp, packed + ln.wT_off, ln.Np, Mp, ln.Kp, ln.Np, epi, mm_flops(M, ln), s, is_x3(L),
-                                              x3_mirror(L, packed, ln.wT_off), nullptr, h2 ? pb.amax + AMAX_CINB : nullptr, M)));
+                                              x3_mirror(L, packed, ln.wT_off), h2 ? x2h_mirror(L, packed) + 2 * ln.wT_off : nullptr,
+                                              h2 ? pb.amax + AMAX_CINB : nullptr, M, h2 ? pb.amax + AMAX_ZC + 0 : nullptr)));
       }
     }
   }

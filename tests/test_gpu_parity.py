@@ -696,7 +696,10 @@ def test_fused_and_generic_paths_agree(R):
                     ("deterministic", dict(deterministic=True)), ("x3", dict(x3=True)),
                     ("fwd_ti2_nw8", dict(fwd_ti=2, fwd_nw=8)), ("f32_mfma", dict(f32_mfma=True)), ("f32_mfma_ti2", dict(f32_mfma=True, bwd_ti=2, bwd_nw=4)),
                     ("x3_ti1_nw4", dict(x3=True, bwd_ti=1, bwd_nw=4, fwd_ti=1, fwd_nw=4)),
-                    ("x3_ti2_nw8", dict(x3=True, bwd_ti=2, bwd_nw=8, fwd_ti=2))):
+                    ("x3_ti2_nw8", dict(x3=True, bwd_ti=2, bwd_nw=8, fwd_ti=2)),
+                    ("no_x2h", dict(x2h=False)), ("no_x2h_det", dict(x2h=False, deterministic=True)),
+                    ("x2h_ti1", dict(x2h=True, bwd_ti=1, bwd_nw=4, fwd_ti=1, fwd_nw=4)),
+                    ("x2h_ra_h2", dict(x2h=True, reg_tile=True))):
         ren.set_variant(**kw)
         for q in params:
             q.grad = None
@@ -717,6 +720,65 @@ def test_fused_and_generic_paths_agree(R):
         for a_, c_ in zip(res["fused"]["g"], res[other]["g"]):
             rel = float((a_ - c_).norm() / c_.norm().clamp_min(1e-12))
             assert rel < 2e-4, f"{other}: gradient rel-L2 {rel:.2e}"
+
+
+def test_gradients_scale_exactly_with_the_loss(R):
+    """The x2h weight-gradient kernel and FB sweep scale their adjoint operands by powers of two taken from the data (the
+    recorded maxima), so multiplying the loss by 2^k must multiply every gradient by exactly 2^k — no overflow at 2^+40
+    (adjoints ~1e8: far outside fp16 without the scales), no loss of bits at 2^-40.  Deterministic variant (ordered
+    reductions): the comparison is bit for bit."""
+    mc = O.ModelConf()
+    torch.manual_seed(5)
+    p = O.init_params(mc)
+    with torch.no_grad():
+        p["dev.variance"].fill_(0.3)
+    sdf, devn, col, ren = R.build_from_named_params(mc, p, _dev())
+    ren.set_variant(deterministic=True)
+    b = {k: v.to(_dev()) for k, v in O.synthetic_batch(128, seed=8, step=3).items()}
+    params = list(sdf.parameters()) + list(devn.parameters()) + list(col.parameters())
+    grads = {}
+    z = None
+    for k in (0, 40, -40):
+        for q in params:
+            q.grad = None
+        out = ren.render_rnb(b["rays_o"], b["rays_d"], b["near"], b["far"], b["lights_dir"], cos_anneal_ratio=1.0,
+                             t_rand=b["t_rand"], z_vals=z)
+        z = ren.last_z_vals
+        (O.rnb_loss(out, b["true_rgb"], b["mask"])[0] * (2.0 ** k)).backward()
+        grads[k] = [q.grad.clone() for q in params]
+        assert all(bool(torch.isfinite(x).all()) for x in grads[k]), k
+    ren.set_variant()
+    assert any(float(x.abs().max()) > 0 for x in grads[0])
+    for k in (40, -40):
+        for a_, c_ in zip(grads[0], grads[k]):
+            assert torch.equal(a_, c_ * (2.0 ** -k)), f"loss x 2^{k}"
+
+
+def test_x2h_operand_range_is_loud(R):
+    """The fp16 three-term products carry fixed scales for weights (|w| < 255) and activations (|a| < 1023).  A weight beyond
+    that range must give non-finite outputs (never finite wrong ones); RNB_VARIANT_NO_X2H (six bf16 terms) still evaluates
+    it.  Forward-only SDF queries on the full-size network."""
+    mc = O.ModelConf()
+    torch.manual_seed(6)
+    p = O.init_params(mc)
+    sdf, devn, col, ren = R.build_from_named_params(mc, p, _dev())
+    pts = (torch.rand(4096, 3, generator=torch.Generator().manual_seed(2)) * 2 - 1).to(_dev())
+    with torch.no_grad():
+        base = sdf.sdf(pts)
+        assert bool(torch.isfinite(base).all())
+        sdf.lin3.weight_g[7] = 1.0e4            # one row of layer 3 with |w| up to 1e4 max|v| / ||v|| (~ 1500)
+        big = float((sdf.lin3.weight_g[7] * sdf.lin3.weight_v[7].abs().max() / sdf.lin3.weight_v[7].norm()))
+        assert big > 300.0
+        out_h2 = sdf.sdf(pts)
+        assert not bool(torch.isfinite(out_h2).all()), "a weight beyond the fp16 range must not pass silently"
+        ren.set_variant(x2h=False)
+        packed = ren._pack(False)
+        out_x3 = R.runtime.sdf_forward(ren.desc, packed, pts, False)
+        assert bool(torch.isfinite(out_x3).all())
+        ref = O.sdf_forward({k: v.detach().cpu() for k, v in
+                             {**{("sdf." + n): q for n, q in sdf.named_parameters()}}.items()}, mc.sdf, pts.cpu())[:, :1]
+        torch.testing.assert_close(out_x3.cpu(), ref, rtol=1e-3, atol=1e-3)
+    ren.set_variant()
 
 
 def test_deterministic_variant_is_bit_reproducible(R):
