@@ -98,13 +98,16 @@ typedef struct rnb_model_desc {
  *   RNB_VARIANT_LDS_TILE      with 32 points each and the weights through an LDS-DMA ring + vector waves for the
  *                             epilogues), LDS_TILE = the 64-point LDS-tile kernels (fused.hip / fused_bwd.hip).  Neither
  *                             bit: the measured default per sweep and batch size.  A/B switches.
- *   RNB_VARIANT_X2H /         (with X3; ON by default, NO_X2H switches it off) the FORWARD-type sweeps (SDF forward and
- *   RNB_VARIANT_NO_X2H        its saved-state form, sampling passes, grid queries, the normal's reverse sweep) take every fp32
- *                             product as THREE fp16 matrix terms (x = hi + lo in fp16 after a power-of-two scale) instead of
- *                             six bf16 ones: half the matrix time, operands represented to 2^-22 (rms 2^-23.6; the measured SDF error
- *                             is below the six-term scheme's), but a bounded operand
- *                             range: |weight| < 255, |activation| < 1023 (beyond: inf / NaN outputs, never silently wrong
- *                             ones).  The backward sweeps keep the bf16 scheme (adjoints have no a-priori range). */
+ *   RNB_VARIANT_X2H /         (with X3; ON by default, NO_X2H switches it off) every fp32 product of the fused path except the
+ *   RNB_VARIANT_NO_X2H        RA sweep's is taken as THREE fp16 matrix terms (x = hi + lo in fp16 after a power-of-two scale)
+ *                             instead of six bf16 ones: half the matrix time; operands represented to 2^-22 (rms 2^-23.6;
+ *                             the measured SDF error against fp64 is below the six-term scheme's).  Scales:
+ *                             FIXED for operands of known range — weights 2^8 (|w| < 255), activations, network inputs and
+ *                             the Jacobian rows of the normal's reverse sweep 2^6 (|a| < 1023): beyond that range outputs are
+ *                             inf / NaN, never silently wrong; TAKEN FROM THE DATA for loss adjoints (weight gradients,
+ *                             FB sweep, albedo backward): their producers record max |.|, so any loss scale works (a loss
+ *                             times 2^k gives gradients times 2^k bit for bit, tested at k = +-40).  The RA sweep is bound by
+ *                             its saved-state traffic and keeps the six bf16 terms. */
 enum {
   RNB_VARIANT_BF16 = 1,
   RNB_VARIANT_DETERMINISTIC = 2,
