@@ -266,13 +266,26 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TI == 2) ? 1 : 2) void fused_r
   const int64_t row0 = (int64_t)blockIdx.x * BT;
   const int n0 = wave * 32 * TJ;
 
+  float gm = 0.f;   // max |geb| of the tile (its padding rows are written as zeros by nbar_geb_kernel: no mask)
   for (int idx = tid; idx < BT * g.Ep; idx += NT) {
     const int r = idx / g.Ep, c = idx - r * g.Ep;
     const float v = g.geb[(row0 + r) * g.Ep + c];
     X[r * FP + c] = v;
     if (c < FEP) E[r * FEP + c] = v;
+    gm = fmaxf(gm, fabsf(v));
+  }
+  if (g.amax != nullptr) {   // u_0 = geb: the scale of layer 0's weight-gradient job (x2h); one conditional atomic per tile
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) gm = fmaxf(gm, __shfl_xor(gm, o, 64));
+    if (lane == 0) wmx[1][wave] = gm;
   }
   __syncthreads();
+  if (g.amax != nullptr && tid == 0) {
+    float m = wmx[1][0];
+    for (int w = 1; w < NW; ++w) m = fmaxf(m, wmx[1][w]);
+    const unsigned bq = __builtin_bit_cast(unsigned, m);
+    if (bq > __atomic_load_n(g.amax + AMAX_U, __ATOMIC_RELAXED)) atomicMax(g.amax + AMAX_U, bq);
+  }
 
   v16f acc[TI][TJ];
   AuxTile<TI, TJ> aD, aG;
@@ -516,7 +529,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_ra_h2_kernel(F
     if (lane == 0) wm[1][wave] = m;
     __syncthreads();
     float s, inv;
-    tile_scale<NW>(wm[1], s, inv);
+    const float gmax = tile_scale<NW>(wm[1], s, inv);
+    if (tid == 0 && g.amax != nullptr) amax_tile_commit(g.amax + AMAX_U, gmax);   // u_0 = geb
     for (int idx = tid; idx < BT * g.Ep; idx += NT) {   // every thread rescales the elements it wrote
       const int r = idx / g.Ep, c = idx - r * g.Ep;
       X[r * FP + c] *= s;

@@ -1113,7 +1113,7 @@ int sweep_backward(const Layout& L, const float* packed, PointBufs& pb, bool wit
     const int wt = (with_color && L.Cinp - L.F > L.Ep) ? L.Cinp - L.F : L.Ep;
     hipLaunchKernelGGL(nbar_geb_kernel, dim3(blocks_for(Mp, 64)), dim3(64), (size_t)64 * (wt + 1) * sizeof(float), s,
                        pb.x, pb.nrm, pb.nbar, pb.cinb, L.Cinp, L.F, L.F + L.pev, L.multires_view, with_color ? 1 : 0,
-                       L.multires, L.Ep, M, Mp, pb.geb, h2 ? pb.amax + AMAX_U : (unsigned*)nullptr);
+                       L.multires, L.Ep, M, Mp, pb.geb, (unsigned*)nullptr);   // (max |geb|: recorded by the RA sweep as it loads the tile)
   }
   RNB_CHECK_LAUNCH();
   if (is_bf16(L)) {

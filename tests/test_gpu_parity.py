@@ -747,6 +747,13 @@ def test_gradients_scale_exactly_with_the_loss(R):
         (O.rnb_loss(out, b["true_rgb"], b["mask"])[0] * (2.0 ** k)).backward()
         grads[k] = [q.grad.clone() for q in params]
         assert all(bool(torch.isfinite(x).all()) for x in grads[k]), k
+    # an all-zero adjoint (recorded maxima 0: the scale falls back to its clamp) gives exactly zero gradients, not NaN
+    for q in params:
+        q.grad = None
+    out = ren.render_rnb(b["rays_o"], b["rays_d"], b["near"], b["far"], b["lights_dir"], cos_anneal_ratio=1.0,
+                         t_rand=b["t_rand"], z_vals=z)
+    (O.rnb_loss(out, b["true_rgb"], b["mask"])[0] * 0.0).backward()
+    assert all(bool((q.grad == 0).all()) for q in params)
     ren.set_variant()
     assert any(float(x.abs().max()) > 0 for x in grads[0])
     for k in (40, -40):
