@@ -393,6 +393,27 @@ class NeuSRenderer:
                 u = slab[:res]
         return u.cpu().numpy() if to_host else u
 
+    def x2h_range_report(self):
+        """The default arithmetic (RNB_VARIANT_X2H, include/rnbneus.h) carries fixed power-of-two scales for operands of known
+        range: |effective weight| < 255.  (|activation| < 1023 depends on the inputs; a violation of either shows as
+        non-finite outputs.)  This helper — plain torch, off the hot path, one device-to-host copy — reports the largest
+        |g v / ||v||| over every layer of both networks, so that a model can be checked once after loading a checkpoint:
+        `{"max_abs_weight": m, "layer": name, "limit": 255.0, "ok": m < 255}`.  When `ok` is False, select the six-term
+        arithmetic with `set_variant(x2h=False)`."""
+        worst, where = 0.0, None
+        with torch.no_grad():
+            for prefix, net in (("sdf", self.sdf_network), ("color", self.color_network)):
+                for i, lin in enumerate(net.lins()):
+                    if hasattr(lin, "weight_g"):
+                        v = lin.weight_v.detach().double()
+                        w = lin.weight_g.detach().double().reshape(-1, 1) * v / v.norm(dim=1, keepdim=True)
+                    else:
+                        w = lin.weight.detach().double()
+                    m = float(w.abs().max())
+                    if m > worst or where is None:
+                        worst, where = m, f"{prefix}.lin{i}"
+        return {"max_abs_weight": worst, "layer": where, "limit": 255.0, "ok": bool(worst < 255.0)}
+
     def extract_geometry(self, bound_min, bound_max, resolution, threshold=0.0, backend=None):
         """models/renderer.py:1219-1224 / :27-36: SDF grid + marching cubes + rescaling to the bounding box; returns
         numpy `(vertices [V,3] float64, triangles [T,3])` as the reference does.

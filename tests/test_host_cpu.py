@@ -325,3 +325,22 @@ def test_cpu_tensors_are_rejected_by_the_train_helpers():
     with pytest.raises(RuntimeError, match="GPU"):
         R.DeviceRays(torch.zeros(1, 1, 2, 2, 3), None, torch.zeros(1, 2, 2, 1), None, None, torch.eye(4)[None],
                      torch.eye(4)[None], "cpu")
+
+
+def test_x2h_range_report_flags_weights_beyond_the_fp16_scale():
+    """NeuSRenderer.x2h_range_report (host-side torch): the geometric init is far inside the operand range of the default
+    arithmetic; a weight row scaled to 1e4 is reported with its layer."""
+    torch.manual_seed(0)
+    sdf = R.SDFNetwork(d_out=257, d_in=3, d_hidden=256, n_layers=8, skip_in=[4], multires=6, bias=0.5, scale=1.0,
+                       geometric_init=True, weight_norm=True)
+    dev = R.SingleVarianceNetwork(0.3)
+    col = R.RenderingNetwork(d_feature=256, mode="no_view_dir", d_in=6, d_out=3, d_hidden=256, n_layers=2,
+                             weight_norm=True, multires_view=4, squeeze_out=True)
+    ren = R.NeuSRenderer(None, sdf, dev, col, n_samples=64, n_importance=64, n_outside=0, up_sample_steps=4, perturb=1.0)
+    rep = ren.x2h_range_report()
+    assert rep["ok"] and rep["max_abs_weight"] < 2.0 and rep["limit"] == 255.0
+    with torch.no_grad():
+        sdf.lin3.weight_g[7] = 1.0e4
+    rep = ren.x2h_range_report()
+    assert not rep["ok"] and rep["layer"] == "sdf.lin3" and rep["max_abs_weight"] > 255.0
+
