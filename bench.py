@@ -58,10 +58,10 @@ def measured_traffic(name, n_gpus, rays, samples, build_id):
 
 
 # kernel class tag (rnb_profile_report) -> substring of the kernel names whose PMC traffic belongs to it
-CLASS_KERNELS = {"RA_sweep": "fused_ra_kernel", "FB_sweep": "fused_fb_kernel", "R_sweep": "fused_reverse_kernel",
+CLASS_KERNELS = {"RA_sweep": "fused_ra_kernel", "FB_sweep": "fused_fb_", "R_sweep": "fused_reverse_kernel",
                  "F_sweep(save)": "fused_forward_kernel<2, true", "dW(x3: 256x256 + narrow jobs + reduce)": "gemm_dw_x3_kernel",
                  "dW(all)": "bf_dw_kernel", "dW(other)": "gemm_dw_direct_kernel", "layer_gemm": ("EpiReluMask", "EpiStore"),
-                 "layer_gemm(forward)": "EpiRelu>"}
+                 "layer_gemm(forward)": "EpiRelu,"}
 HBM_BOUND_TBS = 4.0    # a class that moves more than this (PMC bytes / event time) is labelled hbm-bound: half of the 8 TB/s
                        # spec, ~2/3 of what a plain copy reaches (6.3 TB/s)
 
