@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <type_traits>
 #include <vector>
 
 #include "../rnb-neus-fork_amd/csrc/gemm.hip.h"
@@ -56,28 +57,34 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
-  for (int it = 0; it < 3; ++it) hipLaunchKernelGGL(gemm_dw_x3_kernel<0>, dim3(end), dim3(512), 0, 0, g);
-  CK(hipEventRecord(e0));
-  const int iters = 20;
-  for (int it = 0; it < iters; ++it) hipLaunchKernelGGL(gemm_dw_x3_kernel<0>, dim3(end), dim3(512), 0, 0, g);
-  CK(hipEventRecord(e1));
-  CK(hipDeviceSynchronize());
-  float ms;
-  CK(hipEventElapsedTime(&ms, e0, e1));
-  ms /= iters;
-  const double mfma_cycles_per_simd = 2.0 * njobs * (double)M / 16 * 8 * 48 * 32 / 1024;   // pairs x chunks x waves x MFMAs x 32 clk
-  printf("gemm_dw_x3_kernel: %d points, %d jobs x 2 pairs: %.1f us;  matrix pipe %.0f %% at 2.4 GHz;  operands %.2f TB/s\n", M, njobs,
-         ms * 1e3, 100.0 * mfma_cycles_per_simd / (ms * 1e-3 * 2.4e9), 2.0 * njobs * 2.0 * M * 1024 / (ms * 1e-3) / 1e12);
-  hipLaunchKernelGGL(gemm_dw_x3_kernel<1>, dim3(end), dim3(512), 0, 0, g);
-  CK(hipDeviceSynchronize());
-  std::vector<unsigned long long> st(256 * 8);
-  CK(hipMemcpy(st.data(), stamps, st.size() * 8, hipMemcpyDeviceToHost));
-  double a[5] = {0, 0, 0, 0, 0};
-  for (int b = 0; b < end; ++b)
-    for (int k = 0; k < 5; ++k) a[k] += (double)st[8 * b + k] / end;
-  const double nch = 2.0 * rows / 16;   // chunk iterations per workgroup (both pairs)
-  printf("stamped (s_memtime = shader clocks): per chunk  barrier wait %.0f  chunk issue %.0f  load issue %.0f  | whole kernel %.0f clocks"
-         " = %.1f us of s_memrealtime => %.2f GHz (matrix work per chunk and SIMD: 3072)\n", a[0] / nch * 2, a[1] / nch * 2,
-         a[2] / nch * 2, a[3], a[4] / 100.0, a[3] / (a[4] / 100.0) / 1e3);
+  auto run = [&](auto np_tag) {
+    constexpr int NP = decltype(np_tag)::value;
+    for (int it = 0; it < 3; ++it) hipLaunchKernelGGL((gemm_dw_x3_kernel<0, NP>), dim3(end), dim3(512), 0, 0, g);
+    CK(hipEventRecord(e0));
+    const int iters = 20;
+    for (int it = 0; it < iters; ++it) hipLaunchKernelGGL((gemm_dw_x3_kernel<0, NP>), dim3(end), dim3(512), 0, 0, g);
+    CK(hipEventRecord(e1));
+    CK(hipDeviceSynchronize());
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    ms /= iters;
+    const int terms = NP == 3 ? 6 : 3;
+    const double mfma_cycles_per_simd = 2.0 * njobs * (double)M / 16 * 8 * (8 * terms) * 32 / 1024;   // pairs x chunks x waves x MFMAs x 32 clk
+    printf("gemm_dw_x3_kernel<0, %d>: %d points, %d jobs x 2 pairs: %.1f us;  matrix pipe %.0f %% at 2.4 GHz;  operands %.2f TB/s\n", NP, M,
+           njobs, ms * 1e3, 100.0 * mfma_cycles_per_simd / (ms * 1e-3 * 2.4e9), 2.0 * njobs * 2.0 * M * 1024 / (ms * 1e-3) / 1e12);
+    hipLaunchKernelGGL((gemm_dw_x3_kernel<1, NP>), dim3(end), dim3(512), 0, 0, g);
+    CK(hipDeviceSynchronize());
+    std::vector<unsigned long long> st(256 * 8);
+    CK(hipMemcpy(st.data(), stamps, st.size() * 8, hipMemcpyDeviceToHost));
+    double a[5] = {0, 0, 0, 0, 0};
+    for (int b = 0; b < end; ++b)
+      for (int k = 0; k < 5; ++k) a[k] += (double)st[8 * b + k] / end;
+    const double nch = 2.0 * rows / 16;   // chunk iterations per workgroup (both pairs)
+    printf("  stamped (s_memtime = shader clocks): per chunk  barrier wait %.0f  chunk issue %.0f  load issue %.0f  | whole kernel %.0f clocks"
+           " = %.1f us of s_memrealtime => %.2f GHz (matrix work per chunk and SIMD: %d)\n", a[0] / nch * 2, a[1] / nch * 2,
+           a[2] / nch * 2, a[3], a[4] / 100.0, a[3] / (a[4] / 100.0) / 1e3, 2 * 8 * terms * 32);
+  };
+  run(std::integral_constant<int, 3>());
+  run(std::integral_constant<int, 2>());   // x2h: three fp16 terms (no recorded maxima here: the clamp scale; timing only)
   return 0;
 }
