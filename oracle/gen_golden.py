@@ -495,6 +495,28 @@ def b512_case():
           f"d loss / d variance {float(dev.variance.grad):.3e}")
 
 
+def flags_case():
+    """Full-size (256-wide) networks — the shapes the fused HIP kernels take — under the flags the other full-size fixtures
+    leave at their defaults: `cos_anneal_ratio` in {0.3, 0.0, 0.5}, `perturb_overwrite = 0` and `render`
+    WITHOUT a background colour.  Same sharpened state as full_main_sharp (read back from its .npz), B = 32."""
+    mc = O.ModelConf()
+    sdf, dev, col, ren = build_reference(mc, seed=0)
+    load_fixture_state("full_main_sharp", sdf, dev, col)
+    B = 32
+    b = O.synthetic_batch(B, seed=17, step=6, warmup=False)
+    run_case("full_main_cos03", mc, sdf, dev, col, ren, b, api="render_rnb", cos_anneal_ratio=0.3,
+             weights_from="full_main_sharp", grad_stride=7)
+    # (batch seeds 20 / 26: picked among seeds 18..29 as the first ones on which the scene has a surface (weight_sum mean
+    # > 0.4) and the fp32 reference resolves d loss / d variance — on seed 18 that gradient is 5e-3 from the reference's own
+    # fp64 run with cos_anneal_ratio = 0, which tests/golden_util.py refuses as a parity target)
+    b = O.synthetic_batch(B, seed=20, step=9, warmup=True)
+    run_case("full_warmup_cos0_noperturb", mc, sdf, dev, col, ren, b, api="render_rnb_warmup", cos_anneal_ratio=0.0,
+             perturb_overwrite=0, weights_from="full_main_sharp", grad_stride=7)
+    b = O.synthetic_batch(B, seed=26, step=15, warmup=False)
+    run_case("full_render_nobg_cos05", mc, sdf, dev, col, ren, b, api="render", cos_anneal_ratio=0.5,
+             weights_from="full_main_sharp", grad_stride=7)
+
+
 def grid_case():
     """The SDF grid of validate_mesh from the REFERENCE's own `extract_fields` (models/renderer.py:10-25, called with
     query_func = -sdf_network.sdf as at :1219-1224): tiny networks (seed 0 state of tiny_warmup_geo), asymmetric bounds,
@@ -638,13 +660,15 @@ def main():
              weights_from="full_main_sharp", grad_stride=7)
     # ---- (iii) BASELINE config 2 at its real shape (B = 512) on the same sharpened state ---------
     b512_case()
+    # ---- (iv) the non-default flags on the full-size networks ----------------------------------------
+    flags_case()
 
 
-if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] in ("raygen", "checkpoint", "convergence", "b512", "grid"):
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] in ("raygen", "checkpoint", "convergence", "b512", "grid", "flags"):
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     {"raygen": raygen_case, "checkpoint": checkpoint_case, "convergence": convergence_case,
-     "b512": b512_case, "grid": grid_case}[sys.argv[1]]()
+     "b512": b512_case, "grid": grid_case, "flags": flags_case}[sys.argv[1]]()
     sys.exit(0)
 
 if __name__ == "__main__":
