@@ -57,9 +57,23 @@ def measured_traffic(name, n_gpus, rays, samples, build_id):
     return t, None
 
 
+def measured_mfma_busy(build_id, name="sq_counters.json"):
+    """Matrix-pipe busy fraction per kernel (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs)) from the stored
+    rocprofv3 PMC pass (tools/sq_summary.py writes profiles/sq_counters.json with the library's build id); quoted only for
+    the build it was collected on.  Returns {kernel name: {...}} or None."""
+    try:
+        with open(os.path.join(PROFILES, name)) as f:
+            t = json.load(f)
+    except Exception:
+        return None
+    if t.get("build_id") != build_id:
+        return None
+    return t.get("per_kernel")
+
+
 # kernel class tag (rnb_profile_report) -> substring of the kernel names whose PMC traffic belongs to it
 CLASS_KERNELS = {"RA_sweep": "fused_ra_kernel", "FB_sweep": "fused_fb_", "R_sweep": "fused_reverse_kernel",
-                 "F_sweep(save)": "fused_forward_kernel<2, true", "dW(x3: 256x256 + narrow jobs + reduce)": "gemm_dw_x3_kernel",
+                 "F_sweep(save)": "fused_forward_kernel<2, true", "dW(x3: 256x256 + narrow jobs)": "gemm_dw_x3_kernel",
                  "dW(all)": "bf_dw_kernel", "dW(other)": "gemm_dw_direct_kernel", "layer_gemm": ("EpiReluMask", "EpiStore"),
                  "layer_gemm(forward)": "EpiRelu,"}
 HBM_BOUND_TBS = 4.0    # a class that moves more than this (PMC bytes / event time) is labelled hbm-bound: half of the 8 TB/s
@@ -69,7 +83,7 @@ HBM_BOUND_TBS = 4.0    # a class that moves more than this (PMC bytes / event ti
 # matrix terms per fp32 product of every kernel class under the default arithmetic (RNB_VARIANT_X3 + X2H): three fp16 terms
 # except the RA sweep, which keeps the six bf16 terms (state-traffic bound: DESIGN 4)
 X2H_TERMS = {"F_sweep(save)": 3, "F_sweep(forward_only)": 3, "R_sweep": 3, "FB_sweep": 3,
-             "dW(x3: 256x256 + narrow jobs + reduce)": 3, "layer_gemm(forward)": 3, "RA_sweep": 6, "layer_gemm": 3}
+             "dW(x3: 256x256 + narrow jobs)": 3, "layer_gemm(forward)": 3, "RA_sweep": 6, "layer_gemm": 3}
 
 
 def class_peak(tag, default_peak, terms):
@@ -137,7 +151,8 @@ def parse():
     ap.add_argument("--warmup-mode", action="store_true", help="render_rnb_warmup instead of render_rnb")
     ap.add_argument("--no-albedo", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-steps", type=int, default=10, help="timed steps of the CPU baseline (median reported; BASELINE.md 3)")
+    ap.add_argument("--cpu-warmup", type=int, default=3, help="untimed warm-up steps of the CPU baseline")
     ap.add_argument("--no-gemm-events", action="store_true")
     ap.add_argument("--deterministic", action="store_true", help="ordered reductions instead of fp32 atomics")
     ap.add_argument("--x3", action="store_true", help="request RNB_VARIANT_X3 explicitly (it is the default for the 256-wide shape)")
@@ -213,7 +228,7 @@ def cpu_threads():
     return int(os.environ.get("RNB_CPU_THREADS", min(avail, 16)))
 
 
-def cpu_baseline(rays, samples, steps, warmup_mode, no_albedo):
+def cpu_baseline(rays, samples, steps, warmup_mode, no_albedo, warm=3):
     """The oracle (a PyTorch-CPU restatement with the reference's op structure: two fine SDF forwards,
     autograd double backward, Adam) timed on this box's host cores on a bounded sample.  The oracle computes in
     fp32 whatever --dtype says: the reference has no reduced-precision path."""
@@ -229,7 +244,7 @@ def cpu_baseline(rays, samples, steps, warmup_mode, no_albedo):
     names = O.param_order(mc, no_albedo)
     opt = torch.optim.Adam([p[k] for k in names], lr=5e-4)
     times = []
-    for it in range(steps + 1):
+    for it in range(steps + warm):
         b = O.synthetic_batch(rays, seed=0, step=it, warmup=warmup_mode)
         t0 = time.perf_counter()
         out = O.render_rnb(p, mc, b["rays_o"], b["rays_d"], b["near"], b["far"], b["lights_dir"],
@@ -240,17 +255,17 @@ def cpu_baseline(rays, samples, steps, warmup_mode, no_albedo):
         opt.step()
         dt = time.perf_counter() - t0
         print(f"[bench] cpu baseline step {it}: {dt:.2f} s", file=sys.stderr, flush=True)
-        if it > 0:
+        if it >= warm:
             times.append(dt)
     times.sort()
     med = times[len(times) // 2]
     return {"value": rays / med, "unit": "rays/s", "cores": threads, "kind": "port",
-            "sample": f"{steps} timed steps (+1 warm-up) of {rays} rays x ({samples // 2}+{samples // 2}) samples, "
+            "sample": f"median of {steps} timed steps (after {warm} warm-up steps) of {rays} rays x ({samples // 2}+{samples // 2}) samples, "
                       f"full train step (render_rnb + loss + backward + Adam) with oracle/rnb_oracle.py, torch "
                       f"{torch.__version__} CPU fp32, {threads} threads; median {med:.3f} s/step"}
 
 
-def cpu_baseline_render(rays, samples, steps):
+def cpu_baseline_render(rays, samples, steps, warm=3):
     """CPU leg of --mode render: the oracle's `render` (sampling + fine pass with the autograd normal, as the reference
     computes it even for a forward-only image, exp_runner.py:389-472)."""
     import torch
@@ -261,18 +276,18 @@ def cpu_baseline_render(rays, samples, steps):
     torch.manual_seed(0)
     p = O.init_params(mc)
     times = []
-    for it in range(steps + 1):
+    for it in range(steps + warm):
         b = O.synthetic_batch(rays, seed=0, step=it)
         t0 = time.perf_counter()
         O.render(p, mc, b["rays_o"], b["rays_d"], b["near"], b["far"], t_rand=b["t_rand"], cos_anneal_ratio=1.0)
         dt = time.perf_counter() - t0
         print(f"[bench] cpu baseline render {it}: {dt:.2f} s", file=sys.stderr, flush=True)
-        if it > 0:
+        if it >= warm:
             times.append(dt)
     times.sort()
     med = times[len(times) // 2]
     return {"value": rays / med, "unit": "rays/s", "cores": threads, "kind": "port",
-            "sample": f"{steps} timed calls (+1 warm-up) of oracle/rnb_oracle.py::render on {rays} rays x ({samples // 2}+"
+            "sample": f"median of {steps} timed calls (after {warm} warm-up calls) of oracle/rnb_oracle.py::render on {rays} rays x ({samples // 2}+"
                       f"{samples // 2}) samples, torch {torch.__version__} CPU fp32, {threads} threads; median {med:.3f} s"}
 
 
@@ -456,6 +471,7 @@ def measure_train(args, ctx, with_cpu=True):
             gb = sum(t.numel() * 4 for t in (capture.images, capture.light_directions, capture.masks)) / 1e9
             print(f"[bench] synthetic capture {V} x {Hh} x {Ww} resident in HBM: {gb:.2f} GB", file=sys.stderr, flush=True)
     use_capture = [capture is not None]
+    last_out = [None]      # the dict of the last render (sizes only: SURVEY 8(d)'s algorithmic bytes)
 
     def step(i):
         if forward_only:
@@ -464,6 +480,7 @@ def measure_train(args, ctx, with_cpu=True):
             b = batches[i % n_batches]
             with torch.no_grad():
                 out = ren.render(b["rays_o"], b["rays_d"], b["near"], b["far"], cos_anneal_ratio=1.0, t_rand=b["t_rand"])
+            last_out[0] = out
             return out["color_fine"].sum()
         if use_capture[0]:
             # exp_runner.py:174-220 on the device: pixel draw, ray / target / per-pixel light gather, near / far — one
@@ -475,6 +492,7 @@ def measure_train(args, ctx, with_cpu=True):
         fn = ren.render_rnb_warmup if args.warmup_mode else ren.render_rnb
         out = fn(b["rays_o"], b["rays_d"], b["near"], b["far"], b["lights_dir"], cos_anneal_ratio=1.0,
                  no_albedo=args.no_albedo, t_rand=b["t_rand"])
+        last_out[0] = out
         if args.torch_train_ops:
             loss, _ = torch_rnb_loss(out, b["true_rgb"], b["mask"])
         else:
@@ -499,6 +517,8 @@ def measure_train(args, ctx, with_cpu=True):
     barrier()
     if use_events:
         lib.rnb_profile_enable(1)
+    if world > 1:
+        P.time_collectives(True)     # event pairs around the step's all-reduces (normalisers + flat gradient buffer)
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(args.steps):
@@ -510,6 +530,10 @@ def measure_train(args, ctx, with_cpu=True):
     if use_events:
         R.native.check(lib.rnb_profile_collect(C.byref(gemm_ms), C.byref(gemm_n), C.byref(gemm_fl)))
         lib.rnb_profile_enable(0)
+    coll_ms, coll_n = (0.0, 0)
+    if world > 1:
+        coll_ms, coll_n = P.collective_ms()
+        P.time_collectives(False)
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     median_ms = per_step[len(per_step) // 2]
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -556,73 +580,99 @@ def measure_train(args, ctx, with_cpu=True):
                       "gemm_ms_per_step": round(gemm_ms.value / args.steps, 3),
                       "step_algorithmic_tflops": round(step_tf, 3)}
             if not bf16:
-                # dtype f32.  Default arithmetic ("x3"): every fp32 product as six v_mfma_f32_32x32x16_bf16 terms on
-                # three-way split operands, so the matrix-pipe ceiling of an fp32 FLOP is the dense bf16 peak / 6;
-                # --f32-mfma: v_mfma_f32_32x32x2_f32 against the fp32 MFMA peak.  `achieved` counts ALGORITHMIC fp32
-                # FLOPs (2 M N K of the real layer shapes), never the six terms.
+                # dtype f32.  SURVEY 8(d): the path is MFMA-bound (~7 MB of algorithmic HBM traffic per 530-GFLOP step), so
+                # `roofline` is the MATRIX roof of the dominant kernel class: algorithmic fp32 FLOPs (2 M N K of the real layer
+                # shapes, never the split terms) / its device time (HIP events on the launch stream) / (dense peak of the MFMA
+                # dtype it issues / terms per fp32 product).  The family, the whole step and the design's saved-state HBM
+                # figure are kept beside it (`family`, `step`, `hbm_state`).
                 x3 = not args.f32_mfma
                 x2h = x3 and args.x2h is not False
                 terms = X2H_TERMS if x2h else None
-                peak = BF16_MFMA_PEAK_TFLOPS / 6.0 if x3 else FP32_MFMA_PEAK_TFLOPS
-                by = kernel_classes(lib, args.steps, peak, tr, terms)
+                base_peak = BF16_MFMA_PEAK_TFLOPS / 6.0 if x3 else FP32_MFMA_PEAK_TFLOPS
+                by = kernel_classes(lib, args.steps, base_peak, tr, terms)
+                fam_peak = base_peak
                 if x2h and by:
                     # mixed arithmetic: the ceiling of the family is the rate at which its classes would finish if each ran
                     # at its own MFMA peak (flop-weighted harmonic mean): frac = ideal matrix time / measured time
-                    ideal_ms = sum(k["flop_per_step"] / (class_peak(k["kernel_class"], peak, terms) * 1e12) * 1e3 for k in by)
-                    peak = sum(k["flop_per_step"] for k in by) / (ideal_ms * 1e-3) / 1e12
-                for k in by:
-                    k.pop("flop_per_step", None)
-                roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
-                        "frac": round(ach / peak, 4),
-                        "peak_basis": ("2500 TFLOP/s dense 16-bit MFMA / terms per fp32 product, per kernel class (x2h: three "
-                                       "fp16 terms: 833.3; RA sweep: six bf16 terms: 416.7), combined as "
-                                       "the flop-weighted harmonic mean: frac = ideal matrix time / measured time" if x2h else
-                                       "2500 TFLOP/s dense bf16 MFMA / 6 bf16 terms per fp32 product (x3 arithmetic)" if x3
-                                       else "157.3 TFLOP/s dense fp32 MFMA"),
-                        "frac_of_fp32_mfma_peak": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
-                        "traffic": round(tr["hbm_bytes_per_launch"]) if tr else None,
-                        "traffic_unit": "HBM bytes per launch",
+                    ideal_ms = sum(k["flop_per_step"] / (class_peak(k["kernel_class"], base_peak, terms) * 1e12) * 1e3 for k in by)
+                    fam_peak = sum(k["flop_per_step"] for k in by) / (ideal_ms * 1e-3) / 1e12
+                dom = by[0] if by else None
+                busy = measured_mfma_busy(bid)
+                dom_kernel = CLASS_KERNELS.get(dom["kernel_class"]) if dom else None
+                dom_terms = (terms or {}).get(dom["kernel_class"]) if dom else None
+                dom_terms = dom_terms or (6 if x3 else 1)
+                dom_peak = class_peak(dom["kernel_class"], base_peak, terms) if dom else fam_peak
+                dom_busy = None
+                if busy and dom_kernel:
+                    keys = dom_kernel if isinstance(dom_kernel, tuple) else (dom_kernel,)
+                    hits = [v for k, v in busy.items() if any(kk in k for kk in keys)]
+                    if hits:
+                        dom_busy = round(max(h["mfma_busy"] for h in hits), 4)
+                roof = {"bound": "mfma",
+                        "achieved": dom["tflops"] if dom else round(ach, 3), "peak": round(dom_peak, 1), "unit": "TFLOP/s",
+                        "frac": round((dom["tflops"] if dom else ach) / dom_peak, 4),
+                        "kernel": (f"{dom['kernel_class']}: " + (" / ".join(dom_kernel) if isinstance(dom_kernel, tuple) else str(dom_kernel))) if dom else None,
+                        "terms": dom_terms,
+                        "mfma_dtype": ("fp32 (v_mfma_f32_32x32x2_f32)" if not x3 else
+                                       "fp16 (v_mfma_f32_32x32x16_f16)" if dom_terms == 3 else "bf16 (v_mfma_f32_32x32x16_bf16)"),
+                        "peak_basis": (f"{BF16_MFMA_PEAK_TFLOPS:.0f} TFLOP/s dense 16-bit MFMA / {dom_terms} matrix terms per fp32 product"
+                                       if x3 else "157.3 TFLOP/s dense fp32 MFMA"),
+                        "frac_of_fp32_mfma_peak": round((dom["tflops"] if dom else ach) / FP32_MFMA_PEAK_TFLOPS, 4),
+                        "avg_launch_us": round(1e3 * dom["ms_per_step"] / dom["launches_per_step"], 2) if dom else None,
+                        "flop_per_launch": round(dom["flop_per_step"] / dom["launches_per_step"], 1) if dom else None,
+                        "launches_per_step": dom["launches_per_step"] if dom else None,
+                        "mfma_busy_pmc": dom_busy,
+                        "mfma_busy_note": (None if dom_busy is not None else
+                                           "no SQ_VALU_MFMA_BUSY_CYCLES pass of this build under profiles/sq_counters.json"),
+                        "traffic": (round(dom["hbm_gb_per_step"] * 1e9 / dom["launches_per_step"]) if dom and "hbm_gb_per_step" in dom else None),
+                        "traffic_unit": "HBM bytes per launch of this kernel (PMC: 2 x FETCH_SIZE + WRITE_SIZE)",
                         "traffic_note": tr_note,
-                        "traffic_detail": ({"hbm_bytes_per_step": round(tr["hbm_bytes_per_step"]),
-                                            "launches_per_step": tr["launches_per_step"],
-                                            "source": "profiles/" + traffic_file} if tr else None),
-                        "kernel": ("split-operand MFMA family: fused_forward/reverse_kernel<.., true, true>, fused_fb_h2_kernel, "
-                                   "gemm_dw_x3_kernel<0, 2>, gemm_rows_x3m_kernel<.., 2> (three fp16 terms); fused_ra_kernel<.., true> "
-                                   "(six bf16 terms)" if x2h else
-                                   "x3 MFMA family: fused_forward/reverse/ra/fb_kernel<.., true>, gemm_dw_x3_kernel, "
-                                   "gemm_rows_x3_kernel<*> (+ gemm_dw_direct_kernel<64> for the K = 64 / 320 gradients)" if x3 else
-                                   "fp32-MFMA family: fused_forward/reverse/ra/fb_kernel, gemm_dw_direct_kernel, "
-                                   "gemm_rows_kernel<*>"),
-                        "step_frac": round(step_tf / peak, 4),
-                        "step_frac_of_fp32_mfma_peak": round(step_tf / FP32_MFMA_PEAK_TFLOPS, 4)}
-                roof.update(common)
+                        "family": {"kernels": ("split-operand MFMA family: fused_forward/reverse_kernel<.., true, true>, fused_fb_h2_kernel, "
+                                               "gemm_dw_x3_kernel<0, 2>, color_fwd/bwd_h2_kernel (three fp16 terms); fused_ra_kernel<.., true> "
+                                               "(six bf16 terms)" if x2h else
+                                               "x3 MFMA family: fused_forward/reverse/ra/fb_kernel<.., true>, gemm_dw_x3_kernel, "
+                                               "gemm_rows_x3m_kernel<*>" if x3 else
+                                               "fp32-MFMA family: fused_forward/reverse/ra/fb_kernel, gemm_dw_direct_kernel, gemm_rows_kernel<*>"),
+                                   "achieved": round(ach, 3), "peak": round(fam_peak, 1), "unit": "TFLOP/s",
+                                   "frac": round(ach / fam_peak, 4),
+                                   "peak_basis": ("2500 / terms per kernel class (three fp16 terms: 833.3; RA sweep, six bf16 terms: 416.7), "
+                                                  "flop-weighted harmonic mean: frac = ideal matrix time / measured time" if x2h else
+                                                  "2500 / 6 bf16 terms per fp32 product" if x3 else "157.3 TFLOP/s dense fp32 MFMA"),
+                                   "frac_of_fp32_mfma_peak": round(ach / FP32_MFMA_PEAK_TFLOPS, 4)},
+                        "step": {"algorithmic_flop": tf.value, "algorithmic_tflops": round(step_tf, 3),
+                                 "frac": round(step_tf / fam_peak, 4),
+                                 "frac_of_fp32_mfma_peak": round(step_tf / FP32_MFMA_PEAK_TFLOPS, 4)}}
+                roof["family"].update(common)
                 if by:
-                    roof["dominant_kernel"] = by[0]     # the class with the largest share of the step
                     roof["by_kernel_class"] = by
-                    if any(k.get("bound") == "hbm" for k in by):
-                        roof["bound_note"] = ("family label `bound` = the roof of the dominant class; classes marked "
-                                              "bound: hbm in by_kernel_class move > 4 TB/s and are co-bound by HBM")
-                if x2h and not forward_only:
-                    # With three fp16 terms the matrix time has dropped below the time the fp32 saved state needs on HBM
-                    # (15 matrices of [points x 256] fp32 per hidden layer): whichever of the two roofs the family
-                    # sits closer to is the bound; the other one is kept beside it.
+                # SURVEY 8(d)'s algorithmic HBM bytes: what a fully fused step must move — the ray inputs, the returned tensors,
+                # one read of the weights and one write of their gradients — against what the PMC counters saw
+                try:
+                    io = sum(v.numel() * v.element_size() for v in batches[0].values() if torch.is_tensor(v))
+                    io += sum(v.numel() * v.element_size() for v in last_out[0].values() if torch.is_tensor(v)) if last_out[0] else 0
+                    io += 2 * sum(q.numel() * 4 for q in params)
+                    roof["algorithmic_bytes_per_step"] = io
+                    roof["algorithmic_bytes_basis"] = ("SURVEY 8(d): ray inputs + returned tensors + one read of the trained leaves "
+                                                       "+ one write of their gradients")
+                    if tr:
+                        roof["traffic_bytes_per_step"] = round(tr["hbm_bytes_per_step"])
+                        roof["traffic_ratio"] = round(tr["hbm_bytes_per_step"] / io, 1)
+                        roof["traffic_source"] = "profiles/" + traffic_file
+                except Exception as e:      # (never let bookkeeping kill the line)
+                    roof["algorithmic_bytes_note"] = repr(e)
+                if x3 and not forward_only:
+                    # the DESIGN's own floor: the fp32 per-point saved state written once and read once per consumer between
+                    # the launches of the unfused decomposition (not SURVEY 8(d)'s algorithmic bytes)
                     try:
                         ab = C.c_double()
                         R.native.check(lib.rnb_algorithmic_bytes(C.byref(ren.desc), B, flags, C.byref(ab)))
                         gbs = ab.value * args.steps / (gemm_ms.value * 1e-3) / 1e9
+                        roof["hbm_state"] = {"design_state_bytes_per_step": ab.value, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+                                             "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                                             "basis": ("rnb_algorithmic_bytes: every saved-state matrix of the design written once and "
+                                                       "read once per consumer / device time of the MFMA-family launches")}
                     except Exception:
-                        ab, gbs = None, None
-                    if gbs and gbs / HBM_PEAK_GBS > roof["frac"]:
-                        mf = {k: roof[k] for k in ("achieved", "peak", "unit", "frac", "peak_basis", "frac_of_fp32_mfma_peak",
-                                                   "step_frac", "step_frac_of_fp32_mfma_peak")}
-                        for k in mf:
-                            roof.pop(k, None)
-                        roof.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                     "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_step": ab.value,
-                                     "bound_basis": ("algorithmic bytes of the per-point saved state (rnb_algorithmic_bytes: every "
-                                                     "state matrix written once and read once per consumer) / device time of the "
-                                                     "MFMA-family launches; the matrix roof of the same launches is under `mfma`"),
-                                     "mfma": mf})
+                        pass
             else:
                 # bf16 sweeps: 1/16 of the fp32 matrix time, so the per-point saved state decides: the bound is HBM.
                 # achieved = algorithmic bytes of the MFMA-family launches (each saved-state matrix written once and
@@ -645,13 +695,17 @@ def measure_train(args, ctx, with_cpu=True):
                         "mfma_tflops": round(ach, 2), "mfma_frac_of_bf16_peak": round(ach / BF16_MFMA_PEAK_TFLOPS, 4),
                         "step_frac_of_bf16_peak": round(step_tf / BF16_MFMA_PEAK_TFLOPS, 4)}
                 roof.update(common)
+                if tr:   # the same rate on the bytes the PMC counters saw (independent of the design's own byte count)
+                    pg = tr["hbm_bytes_per_step"] * args.steps / (gemm_ms.value * 1e-3) / 1e9
+                    roof["pmc"] = {"hbm_bytes_per_step": round(tr["hbm_bytes_per_step"]), "achieved": round(pg, 1), "unit": "GB/s",
+                                   "frac": round(pg / HBM_PEAK_GBS, 4), "source": "profiles/" + traffic_file}
                 by = kernel_classes(lib, args.steps, BF16_MFMA_PEAK_TFLOPS, tr)
                 if by:
                     roof["by_kernel_class"] = by
         cpu = None
         if world == 1 and not args.no_cpu_baseline and with_cpu:
-            cpu = (cpu_baseline_render(B, S, args.cpu_steps) if forward_only else
-                   cpu_baseline(B, S, args.cpu_steps, args.warmup_mode, args.no_albedo))
+            cpu = (cpu_baseline_render(B, S, args.cpu_steps, args.cpu_warmup) if forward_only else
+                   cpu_baseline(B, S, args.cpu_steps, args.warmup_mode, args.no_albedo, args.cpu_warmup))
         line = {
             "metric": (f"forward-only rays/sec (NeuSRenderer.render, no_grad) at {B} rays x {S} samples/ray" if forward_only
                        else f"training rays/sec at {B} rays x {S} samples/ray"),
@@ -673,6 +727,10 @@ def measure_train(args, ctx, with_cpu=True):
             # the flat gradient buffer is all-reduced after the backward sweeps have finished (renderer.py: one all_reduce on
             # the compute stream): nothing overlaps it — 2.7 MB, latency-bound on xGMI
             "grad_allreduce_overlap": (False if world > 1 else None),
+            # device time of rank 0's collectives per step (HIP events on the compute stream around each all-reduce: the 4-float
+            # normalisers in the loss + the flat gradient buffer in the backward), so an N > 1 line decomposes itself
+            "allreduce_ms_per_step": (round(coll_ms / args.steps, 4) if world > 1 else None),
+            "allreduces_per_step": (coll_n / args.steps if world > 1 else None),
             "config": {"workload": "DiLiGenT-MV-shaped synthetic rays, wmask_rnb.conf networks (8x256 SDF MLP + "
                                    "2x256 albedo MLP), train_rnb step "
                                    f"({'render_rnb_warmup' if args.warmup_mode else 'render_rnb'}), "
@@ -683,6 +741,9 @@ def measure_train(args, ctx, with_cpu=True):
                        "dp_loss": ("exact large-batch (one 4-float all-reduce of the normalisers + SUM of gradients)" if (world > 1 and exact_dp)
                                    else ("DDP mean of per-rank losses" if world > 1 else "single process")),
                        "backend": backend, "deterministic": bool(args.deterministic),
+                       # the products behind `dtype` (kept here too: the driver's parsed record keeps `config`)
+                       "arithmetic": ("bf16" if bf16 else "fp32_mfma" if args.f32_mfma else "x3" if args.x2h is False else "x2h"),
+                       "operand_bits": (8 if bf16 else 24 if (args.f32_mfma or args.x2h is False) else 22),
                        "train_ops": ("torch ops loss + torch.optim.Adam(fused)" if args.torch_train_ops
                                      else "rnb_loss_rnb + rnb_adam_step (one launch each)")},
             "roofline": roof,
@@ -718,6 +779,8 @@ ALSO_LEGS = (
     ("config 3: wmask_rnb_noalbedo.conf (normal-only loss path)", dict(no_albedo=True)),
     ("config 5 (1-GPU leg): bf16 sweeps, 256 samples per ray", dict(dtype="bf16", samples=256)),
     ("NeuSRenderer.render, forward only (no_grad)", dict(mode="render")),
+    ("deterministic reductions (RNB_VARIANT_DETERMINISTIC: ordered slab sums instead of fp32 atomics, bit-reproducible)",
+     dict(deterministic=True)),
     ("A/B: six bf16 terms in every product (RNB_VARIANT_NO_X2H: the round-3 arithmetic)", dict(x2h=False)),
     ("A/B: native fp32 MFMA arithmetic (RNB_VARIANT_F32_MFMA)", dict(f32_mfma=True)),
 )
@@ -746,15 +809,18 @@ def run_train(args):
                          "config": {"workload": l["config"]["workload"], "no_albedo": l["config"]["no_albedo"],
                                     "samples_per_ray": l["config"]["samples_per_ray"]},
                          "roofline": {"bound": r.get("bound"), "frac": r.get("frac"), "achieved": r.get("achieved"),
-                                      "peak": r.get("peak"), "unit": r.get("unit"), "step_frac": r.get("step_frac")}})
+                                      "peak": r.get("peak"), "unit": r.get("unit"), "kernel": r.get("kernel"),
+                                      "family_frac": (r.get("family") or {}).get("frac"),
+                                      "step_frac": (r.get("step") or {}).get("frac", r.get("step_frac")),
+                                      "pmc": r.get("pmc")}})
             print(f"[bench] also: {name}: {l['value']:.0f} {l['unit']}, {l['ms_per_step']} ms/step", file=sys.stderr, flush=True)
         line["also"] = also
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             forward_only = args.mode == "render"
             B = args.rays if args.scaling == "weak" else args.global_rays // world
-            cpu = (cpu_baseline_render(B, args.samples, args.cpu_steps) if forward_only else
-                   cpu_baseline(B, args.samples, args.cpu_steps, args.warmup_mode, args.no_albedo))
+            cpu = (cpu_baseline_render(B, args.samples, args.cpu_steps, args.cpu_warmup) if forward_only else
+                   cpu_baseline(B, args.samples, args.cpu_steps, args.warmup_mode, args.no_albedo, args.cpu_warmup))
             line["cpu_baseline"] = cpu
             line["gpu_over_cpu"] = round(line["value"] / cpu["value"], 1)
         emit(line)

@@ -72,6 +72,7 @@ static int points_setup(const rnb_model_desc* desc, int64_t n, void* ws, size_t 
   Carver c(ws, ws_bytes);
   carve_points(*L, c, n, kPointsMode, pb);
   if (!c.ok) RNB_FAIL(RNB_E_WORKSPACE, "workspace too small: need %zu bytes, have %zu", c.off, ws_bytes);
+  pb->smax = nullptr;   // (state maxima are kept for a render's backward only: nothing zeroes them here)
   return RNB_OK;
 }
 
@@ -473,7 +474,7 @@ RNB_API int rnb_render_fwd(const rnb_model_desc* desc, const float* packed, cons
   const int mode = render_mode_of(a->flags, L);
   const bool use_color = (mode & PM_WITH_COLOR) != 0;
   RNB_TRY(launch_fine_points(a->rays_o, a->rays_d, a->z_vals, a->B, a->S, 2.0f / (float)desc->n_samples, rb.pts,
-                             rb.dists, s));
+                             rb.dists, rb.pb.smax, s));
   const bool color_bf16 = is_bf16(L) && use_color && bf16_color_supported(L);
   if (color_bf16) {   // the feature head writes bf16 K8 straight into the albedo net's input
     RNB_TRY(bf16_forward(L, packed, rb.pts, a->B * a->S, rb.pb, true, true, s, nullptr, true));

@@ -23,8 +23,10 @@ __device__ inline float inv_s_from_variance(const float* variance, bool* inside_
 // pts[b,j] = o + d * (z + dists/2),  dists[b,j] = z[j+1]-z[j] (last: sample_dist)
 __global__ void fine_points_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                                    const float* __restrict__ z, int64_t B, int S, float sample_dist,
-                                   float* __restrict__ pts, float* __restrict__ dists) {
+                                   float* __restrict__ pts, float* __restrict__ dists, unsigned* __restrict__ smax) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // first kernel of a render forward: the maxima of the saved state (PointBufs::smax) start from zero
+  if (smax != nullptr && i < SMAX_SLOTS) smax[i] = 0u;
   if (i >= B * S) return;
   const int64_t b = i / S;
   const int j = (int)(i - b * S);
@@ -366,10 +368,11 @@ __global__ __launch_bounds__(256) void variance_grad_kernel(const float* __restr
 }
 
 int launch_fine_points(const float* rays_o, const float* rays_d, const float* z, int64_t B, int S, float sample_dist,
-                       float* pts, float* dists, hipStream_t s) {
+                       float* pts, float* dists, unsigned* smax_to_zero, hipStream_t s) {
   const int64_t tot = B * S;
+  static_assert(SMAX_SLOTS <= 256, "one workgroup zeroes the slots");
   hipLaunchKernelGGL(fine_points_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, rays_o, rays_d, z, B, S,
-                     sample_dist, pts, dists);
+                     sample_dist, pts, dists, smax_to_zero);
   RNB_CHECK_LAUNCH();
   return RNB_OK;
 }

@@ -29,9 +29,7 @@ namespace rnb {
 template <int TI, bool SAVE, int NW = 4, bool X3 = false, bool H2 = false>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_forward_kernel(FusedFwdArgs g) {
   static_assert(!H2 || X3, "x2h is a form of the split-operand path");
-  constexpr float SA = H2 ? kH2ActScale : 1.f;                         // scale of the activations in LDS
-  constexpr float ISA = 1.f / SA;
-  constexpr float INV = H2 ? 1.f / (kH2ActScale * kH2WScale) : 1.f;    // accumulator -> pre-activation
+  constexpr float SA = H2 ? kH2ActScale : 1.f;                         // what a writer multiplies by (see kH2ActLimit)
   constexpr int WP = H2 ? 2 : 3;                                       // planes of the weight mirror
   constexpr int FT = 32 * TI;
   constexpr int NT = 64 * NW;     // threads
@@ -41,6 +39,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_forward_kernel
   // workgroups per CU)
   constexpr int NBUF = TI == 1 ? 2 : 1;
   __shared__ __attribute__((aligned(16))) float lds[NBUF * FT * FP + FT * FEP];
+  __shared__ float wmx[2][8];     // x2h: the waves' maxima of the values just written, by layer parity
   float* X = lds;
   float* Y = lds + (NBUF - 1) * FT * FP;
   float* E = lds + NBUF * FT * FP;
@@ -48,6 +47,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_forward_kernel
   const int wave = wave_id();
   const int64_t row0 = (int64_t)blockIdx.x * FT;
   const int n0 = wave * 32 * TJ;
+  // x2h: the tile in LDS holds its values times `sa` (a power of two, per tile and layer; isa = 1 / sa)
+  [[maybe_unused]] float sa = SA, isa = 1.f / SA;
 
   // ---- positional encoding of the tile: X[:, 0:Ep] = [x, sin(2^k x), cos(2^k x)], zero padded -------
   {
@@ -93,12 +94,29 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_forward_kernel
         er[c] = s; er[c + 3] = co;
       }
     }
+    if constexpr (H2) {   // the only unbounded entries of the encoding are the coordinates themselves
+      const float m = wave_max(fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fabsf(x[2])));
+      if (lane == 0) wmx[1][wave] = m;
+    }
   }
   __syncthreads();
+  if constexpr (H2) {
+    const float tm = fmaxf(tile_max<NW>(wmx[1]), 1.f);
+    if (SAVE && g.smax != nullptr && tid == 0) amax_tile_commit(g.smax + SMAX_E, tm);
+    if (tm >= kH2ActLimit) {   // (workgroup-uniform) coordinates beyond 256: this tile carries a smaller scale
+      x2h_dyn_scale(__builtin_bit_cast(unsigned, tm), sa, isa);
+      const float f = sa * (1.f / SA);
+      for (int idx = tid; idx < FT * g.Ep; idx += NT) {
+        const int r = idx / g.Ep, c = idx - r * g.Ep;
+        X[r * FP + c] *= f;
+      }
+      __syncthreads();
+    }
+  }
   if (SAVE) {   // e is an operand of the backward (dW of layer 0) and of the R sweep: FT x Ep floats
     for (int idx = tid; idx < FT * g.Ep; idx += NT) {
       const int r = idx / g.Ep, c = idx - r * g.Ep;
-      g.e[(row0 + r) * g.Ep + c] = X[r * FP + c] * ISA;
+      g.e[(row0 + r) * g.Ep + c] = X[r * FP + c] * isa;
     }
   }
 
@@ -107,6 +125,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_forward_kernel
   [[maybe_unused]] X3Mma<TI, TJ, WP> mm;
   if constexpr (X3) mm.request(g.w3 + WP * g.w_off[0], g.Kp[0], n0, lane);
   for (int l = 0; l < g.nh; ++l) {
+    // x2h: accumulator -> pre-activation: 1 / (scale of the tile x scale of this layer's matrix in the mirror)
+    [[maybe_unused]] const float inv = H2 ? isa * g.h2tab->iws[l] : 1.f;
     if constexpr (X3) {   // the next product's first weight steps are requested before this layer's epilogue
       const x3raw* wn = l + 1 < g.nh ? g.w3 + WP * g.w_off[l + 1] : (g.with_feat ? g.w3 + WP * g.wf_off : nullptr);
       mm.run(X, g.w3 + WP * g.w_off[l], g.Kp[l], n0, lane, acc, wn, FH, n0);
@@ -122,6 +142,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_forward_kernel
     const int n_real = g.n_real[l];
     const bool pe_tail = (l + 1 == g.skip);
     const bool last = (l + 1 == g.nh);
+    [[maybe_unused]] float am = 0.f;   // x2h: max |.| of what this thread writes to the tile
 #pragma unroll
     for (int tj = 0; tj < TJ; ++tj) {
       const int col = n0 + tj * 32 + cl;
@@ -137,7 +158,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_forward_kernel
           const int rowc = ti * 32 + (r & 3) + 8 * (r >> 2);   // compile-time part of the row
           const int row = rowc + 4 * h;
           vf2 a, D;
-          const vf2 z = H2 ? vf2{__builtin_fmaf(acc[ti][tj][r], INV, bc), __builtin_fmaf(acc[ti][tj][r + 1], INV, bc)}
+          const vf2 z = H2 ? vf2{__builtin_fmaf(acc[ti][tj][r], inv, bc), __builtin_fmaf(acc[ti][tj][r + 1], inv, bc)}
                            : vf2{acc[ti][tj][r] + bc, acc[ti][tj][r + 1] + bc};
           if constexpr (SAVE) softplus_aD_sel<X3 && RNB_X3_SCALAR_EPI>(z, a, D);
           else a = softplus_a_sel<X3 && RNB_X3_SCALAR_EPI>(z);
@@ -148,6 +169,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_forward_kernel
           }
           Y[row * FP + col] = a.x * SA;
           Y[(row + 1) * FP + col] = a.y * SA;
+          if constexpr (H2) am = fmaxf(am, fmaxf(fabsf(a.x), fabsf(a.y)));   // (one v_max3_f32 per pair)
           if (SAVE) {
             bstore(ra, voff, rowc * FH * 4, a.x);
             bstore(ra, voff, (rowc + 1) * FH * 4, a.y);
@@ -161,7 +183,28 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_forward_kernel
         }
       }
     }
+    if constexpr (H2) {
+      am = wave_max(am);
+      if (lane == 0) wmx[l & 1][wave] = am;
+    }
     lds_barrier();   // the new activations are visible to every wave
+    if constexpr (H2) {
+      const float tm = tile_max<NW>(wmx[l & 1]);
+      if (SAVE && g.smax != nullptr && tid == 0) amax_tile_commit(g.smax + SMAX_A + l, tm);
+      sa = SA;
+      isa = 1.f / SA;
+      if (tm >= kH2ActLimit) {   // (workgroup-uniform; never taken by a network whose activations stay below 256)
+        x2h_dyn_scale(__builtin_bit_cast(unsigned, tm), sa, isa);
+        const float f = sa * (1.f / SA);
+#pragma unroll
+        for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+          for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Y[(ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * FP + n0 + tj * 32 + cl] *= f;
+        lds_barrier();
+      }
+    }
     if constexpr (NBUF == 2) { float* t = X; X = Y; Y = t; }
   }
 
@@ -180,7 +223,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_forward_kernel
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
       if (lane == 0) {
-        const float v = (H2 ? __builtin_fmaf(s, ISA, bs) : s + bs) / g.scale;
+        const float v = (H2 ? __builtin_fmaf(s, isa, bs) : s + bs) / g.scale;
         if (!g.grid.on) g.sdf[row0 + row] = v;
         else if (row0 + row < g.M) g.sdf[row0 + row] = v * g.grid.out_scale;   // the volume has exactly M entries
       }
@@ -188,6 +231,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_forward_kernel
   }
   // ---- feature head: rows 1.. of the output layer, written into the albedo network's input ------------
   if (g.with_feat) {
+    [[maybe_unused]] const float inv = H2 ? isa * g.h2tab->iws[g.nh] : 1.f;
     if constexpr (X3) mm.run(X, g.w3 + WP * g.wf_off, FH, n0, lane, acc, nullptr, 0, 0);   // (requested by the last hidden layer)
     else layer_mma_nt<TI, NoHook, TJ>(X, g.packed + g.wf_off, FH, n0, lane, acc);
     const float* bias = g.packed + g.bf_off;
@@ -204,7 +248,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_forward_kernel
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int rowc = ti * 32 + (r & 3) + 8 * (r >> 2);
-            bstore(rc, voff, rowc * rowb, H2 ? __builtin_fmaf(acc[ti][tj][r], INV, bc) : acc[ti][tj][r] + bc);
+            bstore(rc, voff, rowc * rowb, H2 ? __builtin_fmaf(acc[ti][tj][r], inv, bc) : acc[ti][tj][r] + bc);
           }
         }
       }
@@ -214,13 +258,16 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_forward_kernel
 
 // ---- RNB_VARIANT_X3: the split weight mirror ----------------------------------------------------------------
 constexpr int kMaxX3 = 4 * RNB_MAX_LIN + 2;
-struct X3Entry { long long off; int N, K, unit_begin, tperm; };
+// id: slot of the matrix in the x2h scale table (H2Tab; W and W^T share it), or -1; tr: this entry is the transposed copy
+struct X3Entry { long long off; int N, K, unit_begin, tperm, id, tr; };
 struct X3Table { int n, total_units; X3Entry e[kMaxX3]; };
 // one thread per 16-byte unit of one plane-triple: W[32 nt + c][16 ks + 8 h .. +8] -> hi, mid, lo.
 // tperm (the SDF network's matrices): the lane's 8 k of a step are 16 ks + 4 h + {0..3, 8..11} instead — the order in
 // which the accumulator of a TRANSPOSED product (sweep_mv.hip: mv_kfeat) hands its features to the next layer; the
 // LDS-tile kernels read their activation rows in the same order (x3_read_a), so one mirror serves both families.
-__global__ void x3_pack_kernel(const float* __restrict__ src, X3Table t, x3raw* __restrict__ dst) {
+// tab != nullptr (x2h): the maximum |w| of every matrix is left in tab->wmax[id] on the way (float bits, zeroed by
+// wn_fwd_kernel; W entries only: W^T holds the same values) — x2h_pack_kernel, which follows, takes the matrix's scale from it.
+__global__ void x3_pack_kernel(const float* __restrict__ src, X3Table t, x3raw* __restrict__ dst, H2Tab* __restrict__ tab) {
   const int u = blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= t.total_units) return;
   int ei = 0;
@@ -232,15 +279,31 @@ __global__ void x3_pack_kernel(const float* __restrict__ src, X3Table t, x3raw* 
   const int nt = frag / nks, ks = frag - nt * nks;
   const int c = lane & 31, h = lane >> 5;
   const float* sp = src + en.off + (size_t)(nt * 32 + c) * en.K + ks * 16 + h * (en.tperm ? 4 : 8);
+  const vf4 x0 = *reinterpret_cast<const vf4*>(sp), x1 = *reinterpret_cast<const vf4*>(sp + (en.tperm ? 8 : 4));
   vu4x hi, mid, lo;
-  x3_split8(*reinterpret_cast<const vf4*>(sp), *reinterpret_cast<const vf4*>(sp + (en.tperm ? 8 : 4)), hi, mid, lo);
+  x3_split8(x0, x1, hi, mid, lo);
   x3raw* dp = dst + 3 * en.off + ((size_t)frag * 3 * 64 + lane) * 8;
   *reinterpret_cast<vu4x*>(dp) = hi;
   *reinterpret_cast<vu4x*>(dp + 512) = mid;
   *reinterpret_cast<vu4x*>(dp + 1024) = lo;
+  if (tab != nullptr && en.id >= 0 && !en.tr) {   // (wave-uniform: an entry's units are a multiple of 64)
+    float m = fmaxf(fmaxf(fmaxf(fabsf(x0.x), fabsf(x0.y)), fmaxf(fabsf(x0.z), fabsf(x0.w))),
+                    fmaxf(fmaxf(fabsf(x1.x), fabsf(x1.y)), fmaxf(fabsf(x1.z), fabsf(x1.w))));
+    amax_commit(tab->wmax + en.id, m, lane);
+  }
 }
-// the fp16 mirror of the forward-type kernels (x2h): same fragments, two planes, weights times kH2WScale
-__global__ void x2h_pack_kernel(const float* __restrict__ src, X3Table t, x3raw* __restrict__ dst) {
+// the scale of a matrix of the fp16 mirror from the float bits of its max |w|: 2^8 (the round-4 constant: results unchanged)
+// while the maximum is below 64; beyond, the power of two that puts the maximum in [2^13, 2^14) — no finite weight overflows
+// fp16.  (A non-finite maximum keeps 2^8: the mirror then carries the inf / NaN into every product, as fp32 arithmetic would.)
+__device__ inline float x2h_weight_scale(unsigned mbits, float& inv) {
+  float s = kH2WScale;
+  inv = 1.f / kH2WScale;
+  const int ef = (int)(mbits >> 23);
+  if (ef >= 127 + 6 && ef < 255) x2h_dyn_scale(mbits, s, inv);
+  return s;
+}
+// the fp16 mirror of the forward-type kernels (x2h): same fragments, two planes, weights times the matrix's scale
+__global__ void x2h_pack_kernel(const float* __restrict__ src, X3Table t, x3raw* __restrict__ dst, H2Tab* __restrict__ tab) {
   const int u = blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= t.total_units) return;
   int ei = 0;
@@ -251,9 +314,12 @@ __global__ void x2h_pack_kernel(const float* __restrict__ src, X3Table t, x3raw*
   const int nks = en.K >> 4;
   const int nt = frag / nks, ks = frag - nt * nks;
   const int c = lane & 31, h = lane >> 5;
+  float inv;
+  const float sw = x2h_weight_scale(tab->wmax[en.id], inv);
+  if (lu == 0 && !en.tr) { tab->ws[en.id] = sw; tab->iws[en.id] = inv; }   // what the consumers read
   const float* sp = src + en.off + (size_t)(nt * 32 + c) * en.K + ks * 16 + h * (en.tperm ? 4 : 8);
   vu4x hi, lo;
-  x2h_split8(*reinterpret_cast<const vf4*>(sp) * kH2WScale, *reinterpret_cast<const vf4*>(sp + (en.tperm ? 8 : 4)) * kH2WScale, hi, lo);
+  x2h_split8(*reinterpret_cast<const vf4*>(sp) * sw, *reinterpret_cast<const vf4*>(sp + (en.tperm ? 8 : 4)) * sw, hi, lo);
   x3raw* dp = dst + 2 * en.off + ((size_t)frag * 2 * 64 + lane) * 8;
   *reinterpret_cast<vu4x*>(dp) = hi;
   *reinterpret_cast<vu4x*>(dp + 512) = lo;
@@ -263,44 +329,30 @@ int x3_pack_weights(const Layout& L, float* packed, hipStream_t s) {
   X3Table t;
   t.n = 0;
   t.total_units = 0;
-  auto add = [&](long long off, int N, int K, int tperm) {
+  auto add = [&](long long off, int N, int K, int tperm, int id, int tr) {
     if (off < 0 || N <= 0 || K <= 0) return;
     X3Entry& e = t.e[t.n++];
-    e.off = off; e.N = N; e.K = K; e.unit_begin = t.total_units; e.tperm = tperm;
+    e.off = off; e.N = N; e.K = K; e.unit_begin = t.total_units; e.tperm = tperm; e.id = id; e.tr = tr;
     t.total_units += N * K / 8;
   };
   for (int l = 0; l < L.nh; ++l) {
-    add(L.hid[l].w_off, L.hid[l].Np, L.hid[l].Kp, 1);
-    add(L.hid[l].wT_off, L.hid[l].Kp, L.hid[l].Np, 1);
+    add(L.hid[l].w_off, L.hid[l].Np, L.hid[l].Kp, 1, l, 0);
+    add(L.hid[l].wT_off, L.hid[l].Kp, L.hid[l].Np, 1, l, 1);
   }
   if (L.F > 0) {
-    add(L.feat.w_off, L.feat.Np, L.feat.Kp, 1);
-    add(L.feat.wT_off, L.feat.Kp, L.feat.Np, 1);
+    add(L.feat.w_off, L.feat.Np, L.feat.Kp, 1, L.nh, 0);
+    add(L.feat.wT_off, L.feat.Kp, L.feat.Np, 1, L.nh, 1);
   }
-  for (int l = 0; l < L.nc; ++l) {   // the albedo network's hidden layers (gemm_rows_x3m_kernel reads them as fragments)
-    add(L.col[l].w_off, L.col[l].Np, L.col[l].Kp, 0);
-    add(L.col[l].wT_off, L.col[l].Kp, L.col[l].Np, 0);
+  for (int l = 0; l < L.nc; ++l) {   // the albedo network's hidden layers (read as fragments by its kernels)
+    add(L.col[l].w_off, L.col[l].Np, L.col[l].Kp, 0, L.nh + 1 + l, 0);
+    add(L.col[l].wT_off, L.col[l].Kp, L.col[l].Np, 0, L.nh + 1 + l, 1);
   }
-  hipLaunchKernelGGL(x3_pack_kernel, dim3((unsigned)((t.total_units + 255) / 256)), dim3(256), 0, s, packed, t, dst);
+  H2Tab* tab = is_x2h(L) ? h2_tab(L, packed) : nullptr;
+  hipLaunchKernelGGL(x3_pack_kernel, dim3((unsigned)((t.total_units + 255) / 256)), dim3(256), 0, s, packed, t, dst, tab);
   RNB_CHECK_LAUNCH();
-  if (is_x2h(L)) {   // (every matrix by now: the backward sweeps read the fp16 planes too)
-    X3Table th;
-    th.n = 0;
-    th.total_units = 0;
-    for (int q = 0; q < t.n; ++q) {
-      const X3Entry& e = t.e[q];
-      bool fwd = false;
-      for (int l = 0; l < L.nh; ++l) fwd = fwd || e.off == L.hid[l].w_off || e.off == L.hid[l].wT_off;
-      fwd = fwd || (L.F > 0 && (e.off == L.feat.w_off || e.off == L.feat.wT_off));   // (W_feat^T: the FB sweep's first product)
-      for (int l = 0; l < L.nc; ++l) fwd = fwd || e.off == L.col[l].w_off || e.off == L.col[l].wT_off;   // the albedo network
-      if (!fwd) continue;
-      X3Entry& d = th.e[th.n++];
-      d = e;
-      d.unit_begin = th.total_units;
-      th.total_units += e.N * e.K / 8;
-    }
-    hipLaunchKernelGGL(x2h_pack_kernel, dim3((unsigned)((th.total_units + 255) / 256)), dim3(256), 0, s, packed, th,
-                       x2h_mirror(L, packed));
+  if (is_x2h(L)) {   // every matrix once more as two fp16 planes (same table: the scales come from the maxima just taken)
+    hipLaunchKernelGGL(x2h_pack_kernel, dim3((unsigned)((t.total_units + 255) / 256)), dim3(256), 0, s, packed, t,
+                       x2h_mirror(L, packed), tab);
     RNB_CHECK_LAUNCH();
   }
   return RNB_OK;
@@ -354,6 +406,8 @@ int fused_forward(const Layout& L, const float* packed, const float* pts, int64_
   g.x4 = pb.x;
   g.e = pb.e;
   g.gz_last = need_gz_last ? pb.gz[L.nh - 1] : nullptr;
+  g.h2tab = h2 ? h2_tab(L, packed) : nullptr;
+  g.smax = (save && h2) ? pb.smax : nullptr;
   // algorithmic FLOPs of the sweep (real layer shapes), for the optional event instrumentation
   double fl = 0;
   for (int l = 0; l < L.nh; ++l) fl += 2.0 * (double)M * L.hid[l].N * L.hid[l].K;

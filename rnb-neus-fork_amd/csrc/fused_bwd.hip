@@ -45,6 +45,8 @@ struct FusedBwdArgs {
   const float* fbar;    // [Mp,ld_fbar] first 256 columns, or nullptr (FB, no_albedo)
   int ld_fbar;
   unsigned* amax;       // PointBufs::amax (RA: slots AMAX_U + l of the u_l it writes; FB: AMAX_ZB + l), or nullptr
+  const H2Tab* h2tab;   // x2h: scales of the fp16 mirror's matrices (hidden layer l: id l, feature head: id nh)
+  unsigned* smax;       // x2h R sweep of a render forward: PointBufs::smax (slots SMAX_GZ + l grown by the tile maxima), or nullptr
 };
 
 // AuxTile<TI, TJ>: one value per accumulator element of the wave's (32 TI) x (32 TJ) block
@@ -139,8 +141,7 @@ __device__ inline void layer_mma(const float* __restrict__ X, const FusedBwdArgs
 template <int TI, int NW = 4, bool X3 = false, bool H2 = false>
 __global__ __launch_bounds__(64 * NW, (NW == 8 && TI == 2) ? 1 : 2) void fused_reverse_kernel(FusedBwdArgs g) {
   static_assert(!H2 || X3, "x2h is a form of the split-operand path");
-  constexpr float SG = H2 ? kH2ActScale : 1.f;
-  constexpr float INV = H2 ? 1.f / (kH2ActScale * kH2WScale) : 1.f;
+  constexpr float SG = H2 ? kH2ActScale : 1.f;   // what a writer multiplies by; the tile's scale `sg` is per tile and layer (kH2ActLimit)
   constexpr int WP = H2 ? 2 : 3;
   constexpr int BT = 32 * TI;
   constexpr int NT = 64 * NW;   // threads
@@ -149,6 +150,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TI == 2) ? 1 : 2) void fused_r
   [[maybe_unused]] constexpr bool BOTH_IN_LOOP = !(TI == 2 && TJ == 2);
   constexpr int NBUF = TI == 1 ? 2 : 1;
   __shared__ __attribute__((aligned(16))) float lds[NBUF * BT * FP + BT * FEP];
+  __shared__ float wmx[2][8];              // x2h: the waves' maxima of the values just written, by layer parity
   float* X = lds;                          // input of the current layer
   float* Y = lds + (NBUF - 1) * BT * FP;   // output of the current layer (== X when updated in place)
   float* GE = lds + NBUF * BT * FP;        // d sdf / d e of the tile
@@ -156,12 +158,14 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TI == 2) ? 1 : 2) void fused_r
   const int wave = wave_id();
   const int64_t row0 = (int64_t)blockIdx.x * BT;
   const int n0 = wave * 32 * TJ;
+  [[maybe_unused]] float sg = SG, isg = 1.f / SG;   // x2h: the tile holds gz times sg
 
   // seed: gz_{nh-1} = w_sdf * D_{nh-1}  (row 0 of the output layer is d sdf / d a_last)
   {
     const float* Dl = g.D[g.nh - 1] + (size_t)row0 * FH;
     float* gzl = g.gz[g.nh - 1] + (size_t)row0 * FH;
     const float* ws = g.packed + g.wsdf_off;
+    float m = 0.f;
     for (int idx = tid; idx < BT * FH / 4; idx += NT) {
       const int r = idx >> 6, c4 = idx & 63;
       const vf4 d = *reinterpret_cast<const vf4*>(Dl + r * FH + c4 * 4);
@@ -169,10 +173,28 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TI == 2) ? 1 : 2) void fused_r
       const vf4 v = d * w;
       *reinterpret_cast<vf4*>(X + r * FP + c4 * 4) = v * SG;
       *reinterpret_cast<vf4*>(gzl + r * FH + c4 * 4) = v;
+      if constexpr (H2) m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
     }
     for (int idx = tid; idx < BT * FEP; idx += NT) GE[idx] = 0.f;
+    if constexpr (H2) {
+      m = wave_max(m);
+      if (lane == 0) wmx[g.nh & 1][wave] = m;
+    }
   }
   __syncthreads();
+  if constexpr (H2) {
+    const float tm = tile_max<NW>(wmx[g.nh & 1]);
+    if (g.smax != nullptr && tid == 0) amax_tile_commit(g.smax + SMAX_GZ + g.nh - 1, tm);
+    if (tm >= kH2ActLimit) {   // (workgroup-uniform)
+      x2h_dyn_scale(__builtin_bit_cast(unsigned, tm), sg, isg);
+      const float f = sg * (1.f / SG);
+      for (int idx = tid; idx < BT * FH / 4; idx += NT) {
+        vf4* q = reinterpret_cast<vf4*>(X + (idx >> 6) * FP + (idx & 63) * 4);
+        *q = *q * f;
+      }
+      __syncthreads();
+    }
+  }
 
   v16f acc[TI][TJ];
   AuxTile<TI, TJ> aD;
@@ -181,6 +203,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TI == 2) ? 1 : 2) void fused_r
     if (g.nh > 1 || n0 < 64) mm.request(g.w3 + WP * g.wT_off[g.nh - 1], FH, n0, lane);
   }
   for (int l = g.nh - 1; l >= 1; --l) {
+    // x2h: accumulator -> g: 1 / (scale of the tile x scale of this layer's matrix in the mirror)
+    [[maybe_unused]] const float INV = H2 ? isg * g.h2tab->iws[l] : 1.f;
     const long long nxt = (l > 1 || n0 < 64) ? g.wT_off[l - 1] : -1;   // layer 0's product: the waves of columns 0..63
     // x3, 64 x 64-output waves: the operand tile is requested AFTER the matrix loop, into the registers the loop's
     // fragments leave behind; the other workgroup of the CU multiplies while it travels
@@ -194,12 +218,14 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TI == 2) ? 1 : 2) void fused_r
     const bool is_skip = (l == g.skip);
     const int ksplit = is_skip ? FH - g.pe : FH;   // columns that belong to layer l-1's output
     const BufRsrc rg = tile_rsrc(g.gz[l - 1] + (size_t)row0 * FH, BT * FH * 4);
+    [[maybe_unused]] float gm[2] = {0.f, 0.f};   // x2h: max |gz_{l-1}| of this thread
     for_each_acc_split<TI, TJ>(
         n0, lane_e, ksplit,
         [&](int tj, int ti, int r, int col, int rowc, int row) {
           const float gzv = acc[ti][tj][r] * INV * aD.v[ti][tj][r];
           Y[row * FP + col] = gzv * SG;
           bstore(rg, (unsigned)(4 * h * FH + col) * 4u, rowc * FH * 4, gzv);
+          if constexpr (H2) gm[r & 1] = fmaxf(gm[r & 1], fabsf(gzv));
         },
         [&](int tj, int ti, int r, int col, int rowc, int row) {
           const float v = acc[ti][tj][r] * INV;
@@ -212,12 +238,30 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TI == 2) ? 1 : 2) void fused_r
           }
           Y[row * FP + col] = gzv * SG;
           bstore(rg, (unsigned)(4 * h * FH + col) * 4u, rowc * FH * 4, gzv);
+          if constexpr (H2) gm[r & 1] = fmaxf(gm[r & 1], fabsf(gzv));
         });
+    if constexpr (H2) {
+      const float m = wave_max(fmaxf(gm[0], gm[1]));
+      if (lane_e == 0) wmx[l & 1][wave] = m;
+    }
     lds_barrier();
+    if constexpr (H2) {
+      const float tm = tile_max<NW>(wmx[l & 1]);
+      if (g.smax != nullptr && tid == 0) amax_tile_commit(g.smax + SMAX_GZ + l - 1, tm);
+      sg = SG;
+      isg = 1.f / SG;
+      if (tm >= kH2ActLimit) {   // (workgroup-uniform; a Jacobian row beyond 256: this tile carries a smaller scale)
+        x2h_dyn_scale(__builtin_bit_cast(unsigned, tm), sg, isg);
+        const float f = sg * (1.f / SG);
+        for_each_acc<TI, TJ>(n0, lane_e, [&](int tj, int ti, int r, int col, int rowc, int row) { Y[row * FP + col] *= f; });
+        lds_barrier();
+      }
+    }
     if constexpr (NBUF == 2) { float* t = X; X = Y; Y = t; }
   }
   // layer 0: g_e += gz_0 W_0 (Ep = 64 columns: the waves that own columns 0..63)
   if (n0 < 64) {
+    [[maybe_unused]] const float INV = H2 ? isg * g.h2tab->iws[0] : 1.f;
     layer_mma<TI, TJ, X3>(X, g, g.wT_off[0], FH, n0, lane, acc, mm, -1);
     for_each_acc<TI, TJ>(n0, lane, [&](int tj, int ti, int r, int col, int rowc, int row) {
       if (col < g.pe) GE[row * FEP + col] += acc[ti][tj][r] * INV;
@@ -482,157 +526,14 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TI == 2) ? 1 : 2) void fused_f
 // maximum of the NW per-wave values of this layer -> (tile maximum, scale, 1 / scale)
 template <int NW>
 __device__ inline float tile_scale(const float* wm, float& s, float& inv_s) {
-  float m = wm[0];
-#pragma unroll
-  for (int w = 1; w < NW; ++w) m = fmaxf(m, wm[w]);
+  const float m = tile_max<NW>(wm);
   x2h_dyn_scale(__builtin_bit_cast(unsigned, m), s, inv_s);
   return m;
-}
-__device__ inline float wave_max(float m) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-  return m;
-}
-// one atomic per tile, and only when the slot would grow
-__device__ inline void amax_tile_commit(unsigned* slot, float m) {
-  const unsigned b = __builtin_bit_cast(unsigned, m);
-  if (b > __atomic_load_n(slot, __ATOMIC_RELAXED)) atomicMax(slot, b);
-}
-
-template <int NW>
-__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_ra_h2_kernel(FusedBwdArgs g) {
-  constexpr int TI = 2, BT = 64, NT = 64 * NW, TJ = 8 / NW;
-  constexpr float IW = 1.f / kH2WScale;
-  __shared__ __attribute__((aligned(16))) float lds[BT * FP + BT * FEP];
-  __shared__ float wm[2][8];   // per-wave maxima over the real rows, by layer parity (see fused_fb_h2_kernel)
-  float* X = lds;
-  float* E = lds + BT * FP;   // adjoint of g_e of the tile (re-enters at the skip connection), unscaled
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = wave_id();
-  const int64_t row0 = (int64_t)blockIdx.x * BT;
-  const int n0 = wave * 32 * TJ;
-  const long long left = g.M - row0;
-  const int rows_ok = left >= BT ? BT : (int)(left < 0 ? 0 : left);
-  constexpr bool LATE = TJ == 2;
-
-  float unscale;
-  {
-    float m = 0.f;
-    for (int idx = tid; idx < BT * g.Ep; idx += NT) {
-      const int r = idx / g.Ep, c = idx - r * g.Ep;
-      const float v = g.geb[(row0 + r) * g.Ep + c];
-      X[r * FP + c] = v;
-      if (c < FEP) E[r * FEP + c] = v;
-      if (r < rows_ok) m = fmaxf(m, fabsf(v));
-    }
-    m = wave_max(m);
-    if (lane == 0) wm[1][wave] = m;
-    __syncthreads();
-    float s, inv;
-    const float gmax = tile_scale<NW>(wm[1], s, inv);
-    if (tid == 0 && g.amax != nullptr) amax_tile_commit(g.amax + AMAX_U, gmax);   // u_0 = geb
-    for (int idx = tid; idx < BT * g.Ep; idx += NT) {   // every thread rescales the elements it wrote
-      const int r = idx / g.Ep, c = idx - r * g.Ep;
-      X[r * FP + c] *= s;
-    }
-    __syncthreads();
-    unscale = inv * IW;
-  }
-
-  v16f acc[TI][TJ];
-  AuxTile<TI, TJ> aD, aG;
-  X3Mma<TI, TJ, 2> mm;
-  if constexpr (!LATE) mm.request(g.w3 + 2 * g.w_off[0], g.Kp[0], n0, lane);
-  for (int l = 0; l < g.nh; ++l) {
-    if constexpr (LATE) {
-      mm.request(g.w3 + 2 * g.w_off[l], g.Kp[l], n0, lane);
-      mm.run(X, g.w3 + 2 * g.w_off[l], g.Kp[l], n0, lane, acc, nullptr, 0, 0);   // gzb = u_l W_l^T
-    } else {
-      mm.run(X, g.w3 + 2 * g.w_off[l], g.Kp[l], n0, lane, acc, l + 1 < g.nh ? g.w3 + 2 * g.w_off[l + 1] : nullptr, FH, n0, [&]() {
-        prefetch_tile<TI, TJ>(g.D[l], row0, n0, lane, aD);
-        prefetch_tile<TI, TJ>(g.gz[l], row0, n0, lane, aG);
-      });
-    }
-    const int lane_e = opaque_lane(lane);
-    const int h = lane_e >> 5;
-    if constexpr (LATE) {
-      prefetch_tile<TI, TJ>(g.D[l], row0, n0, lane_e, aD);
-      prefetch_tile<TI, TJ>(g.gz[l], row0, n0, lane_e, aG);
-    }
-    const int n_real = g.n_real[l];
-    const bool pe_tail = (l + 1 == g.skip);
-    const int par = l & 1;
-    const BufRsrc rzR = tile_rsrc(g.zR[l] + (size_t)row0 * FH, BT * FH * 4);
-    if (l + 1 == g.nh && g.ucol != nullptr) {   // last layer: column sums of u_nh instead of the matrix (see fused_ra_kernel)
-      float cs[TJ];
-#pragma unroll
-      for (int tj = 0; tj < TJ; ++tj) cs[tj] = 0.f;
-      for_each_acc<TI, TJ>(n0, lane_e, [&](int tj, int ti, int r, int col, int rowc, int row) {
-        const float v = acc[ti][tj][r] * unscale;
-        const float un = col < n_real ? v * aD.v[ti][tj][r] : 0.f;
-        const float zr = col < n_real ? ((v - un) * aG.v[ti][tj][r]) * 100.f : 0.f;
-        bstore(rzR, (unsigned)(4 * h * FH + col) * 4u, rowc * FH * 4, zr);
-        cs[tj] += (row0 + row < g.M) ? un : 0.f;
-      });
-#pragma unroll
-      for (int tj = 0; tj < TJ; ++tj) {
-        const float tot = cs[tj] + __shfl_xor(cs[tj], 32, 64);
-        if (lane_e < 32) g.ucol[(size_t)blockIdx.x * FH + n0 + tj * 32 + lane_e] = tot;
-      }
-      break;
-    }
-    // phase 1 (registers and HBM only): u_{l+1} and zR_l, the maxima of u_{l+1}
-    const BufRsrc ru = tile_rsrc(g.u[l + 1] + (size_t)row0 * FH, BT * FH * 4);
-    for_each_acc_split<TI, TJ>(
-        n0, lane_e, n_real,
-        [&](int tj, int ti, int r, int col, int rowc, int row) {
-          const unsigned voff = (unsigned)(4 * h * FH + col) * 4u;
-          const unsigned soff = rowc * FH * 4;
-          const float v = acc[ti][tj][r] * unscale;
-          const float un = v * aD.v[ti][tj][r];
-          const float zr = ((v - un) * aG.v[ti][tj][r]) * 100.f;   // 100 v gz (1 - D)
-          bstore(rzR, voff, soff, zr);
-          bstore(ru, voff, soff, un);
-          acc[ti][tj][r] = un;
-        },
-        [&](int tj, int ti, int r, int col, int rowc, int row) {
-          const unsigned voff = (unsigned)(4 * h * FH + col) * 4u;
-          const unsigned soff = rowc * FH * 4;
-          const float v = acc[ti][tj][r] * unscale;
-          float zr, un;
-          if (col < n_real) {
-            un = v * aD.v[ti][tj][r];
-            zr = ((v - un) * aG.v[ti][tj][r]) * 100.f;
-          } else {
-            zr = 0.f;
-            un = (pe_tail && col < n_real + g.pe) ? E[row * FEP + (col - n_real)] : 0.f;
-          }
-          bstore(rzR, voff, soff, zr);
-          bstore(ru, voff, soff, un);
-          acc[ti][tj][r] = un;
-        });
-    {
-      const float mr = wave_max(acc_absmax<TI, TJ>(acc, lane_e, rows_ok));
-      if (lane_e == 0) wm[par][wave] = mr;
-    }
-    lds_barrier();   // every wave has finished reading the tile; the maxima are visible
-    float s, inv;
-    const float tmax = tile_scale<NW>(wm[par], s, inv);
-    if (tid == 0 && g.amax != nullptr) amax_tile_commit(g.amax + AMAX_U + l + 1, tmax);
-    if (l + 1 == g.nh) break;   // (only without ucol: nothing follows)
-    // phase 2: the tile for the next product, scaled by this layer's own maximum
-    for_each_acc<TI, TJ>(n0, lane_e, [&](int tj, int ti, int r, int col, int rowc, int row) {
-      X[row * FP + col] = acc[ti][tj][r] * s;
-    });
-    lds_barrier();
-    unscale = inv * IW;
-  }
 }
 
 template <int NW>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_fb_h2_kernel(FusedBwdArgs g) {
   constexpr int TI = 2, BT = 64, NT = 64 * NW, TJ = 8 / NW;
-  constexpr float IW = 1.f / kH2WScale;
   __shared__ __attribute__((aligned(16))) float lds[BT * FP];
   __shared__ float wm[2][8];   // per-wave maxima over the real rows, by layer parity (padding rows hold workspace garbage:
                                // they may overflow the scaled tile — their products are never read)
@@ -678,7 +579,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_fb_h2_kernel(F
     __syncthreads();
     if constexpr (LATE) mm.request(g.w3 + 2 * g.wfT_off, FH, n0, lane);
     mm.run(X, g.w3 + 2 * g.wfT_off, FH, n0, lane, acc, (!LATE && g.nh > 1) ? g.w3 + 2 * g.wT_off[g.nh - 1] : nullptr, FH, n0);
-    unscale = inv * IW;
+    unscale = inv * g.h2tab->iws[g.nh];   // (tile scale x the feature head's scale in the mirror)
   }
   if constexpr (LATE) {
     prefetch_tile<TI, TJ>(g.D[g.nh - 1], row0, n0, lane, aD);
@@ -735,7 +636,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_fb_h2_kernel(F
         prefetch_tile<TI, TJ>(g.zR[l - 1], row0, n0, lane, aZ);
       });
     }
-    unscale = inv * IW;
+    unscale = inv * g.h2tab->iws[l];
   }
 }
 
@@ -770,6 +671,8 @@ static void fill_args(const Layout& L, const float* packed, PointBufs& pb, Fused
   g.geb = pb.geb;
   g.sbar = pb.sbar;
   g.amax = is_x2h(L) ? pb.amax : nullptr;
+  g.h2tab = is_x2h(L) ? h2_tab(L, packed) : nullptr;
+  g.smax = nullptr;
 }
 
 // Variant of the three sweeps: tile height TI (32 / 64 points) x waves per workgroup NW (4: 64 columns per wave;
@@ -809,6 +712,7 @@ int fused_reverse(const Layout& L, const float* packed, PointBufs& pb, hipStream
   const dim3 grid((unsigned)(pb.Mp / (32 * ti))), block(64 * nw);
   if (is_x2h(L)) {
     g.w3 = x2h_mirror(L, packed);
+    g.smax = pb.smax;   // (nullptr outside a render forward)
     if (ti == 2 && nw == 8) hipLaunchKernelGGL((fused_reverse_kernel<2, 8, true, true>), grid, block, 0, s, g);
     else if (ti == 2) hipLaunchKernelGGL((fused_reverse_kernel<2, 4, true, true>), grid, block, 0, s, g);
     else if (nw == 8) hipLaunchKernelGGL((fused_reverse_kernel<1, 8, true, true>), grid, block, 0, s, g);
@@ -839,14 +743,9 @@ int fused_ra(const Layout& L, const float* packed, PointBufs& pb, hipStream_t s,
   }
   const dim3 grid((unsigned)(pb.Mp / (32 * ti))), block(64 * nw);
   // RA stays on the six bf16 terms: it reads D_l, gz_l and writes zR_l, u_{l+1} — 2.1 GB per 65,536 points, 0.42 ms at
-  // 5 TB/s against 0.45 ms measured: the matrix time hides under the state traffic, and the x2h form (fused_ra_h2_kernel,
-  // kept for RNB_VARIANT_X2H with RNB_VARIANT_REG_TILE as the A/B switch), whose two-phase epilogue stores later, measured
-  // 0.505 (8 waves) / 0.545 ms (4 waves, 24 spilled registers) against 0.475 (profiles/r04_ab_experiments.txt).
-  if (is_x2h(L) && ti == 2 && (L.variant & RNB_VARIANT_REG_TILE)) {
-    g.w3 = x2h_mirror(L, packed);
-    if (nw == 8) hipLaunchKernelGGL((fused_ra_h2_kernel<8>), grid, block, 0, s, g);
-    else hipLaunchKernelGGL((fused_ra_h2_kernel<4>), grid, block, 0, s, g);
-  } else if (is_x3(L)) {
+  // 5 TB/s against 0.45 ms measured: the matrix time hides under the state traffic.  (An x2h form with FB's two-phase
+  // epilogue was built and measured in round 4 — 0.505 / 0.545 ms against 0.475, profiles/r04_ab_experiments.txt — and removed.)
+  if (is_x3(L)) {
     if (ti == 2 && nw == 8) hipLaunchKernelGGL((fused_ra_kernel<2, 8, true>), grid, block, 0, s, g);
     else if (ti == 2) hipLaunchKernelGGL((fused_ra_kernel<2, 4, true>), grid, block, 0, s, g);
     else if (nw == 8) hipLaunchKernelGGL((fused_ra_kernel<1, 8, true>), grid, block, 0, s, g);

@@ -35,7 +35,35 @@ struct FusedFwdArgs {
   float* D[RNB_MAX_LIN];
   float* gz_last;       // [Mp,256] seed of the reverse sweep: w_sdf * D_last (optional)
   GridGen grid;         // on: points come from the regular grid, sdf (scaled) goes to rows < M only
+  const H2Tab* h2tab;   // RNB_VARIANT_X2H: scales of the fp16 mirror's matrices (hidden layer l: id l, feature head: id nh)
+  unsigned* smax;       // SAVE (render forward only): PointBufs::smax, grown by the tile maxima of e, a_l and the features; or nullptr
 };
+
+// ---- x2h: per-tile scale of the operand tile in LDS -----------------------------------------------------------------
+// The tile holds its values times a power of two: kH2ActScale (2^6, the round-4 constant: results unchanged) while the tile's
+// maximum stays below kH2ActLimit, else the power of two that puts the maximum in [2^13, 2^14) — chosen per tile and layer
+// from the values just written (the waves' maxima meet in LDS behind the barrier that ends the layer), so NO activation,
+// network input or Jacobian row is out of range.  Writers store times kH2ActScale; when the tile's maximum calls for less,
+// every thread rescales the elements it wrote (an exact multiplication) behind one more barrier — a path a sane network
+// never takes.
+constexpr float kH2ActLimit = 256.f;   // 2^8 * 2^6 = 2^14: the first maximum that leaves [.., 2^14)
+__device__ inline float wave_max(float m) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  return m;
+}
+template <int NW>
+__device__ inline float tile_max(const float* wm) {
+  float m = wm[0];
+#pragma unroll
+  for (int w = 1; w < NW; ++w) m = fmaxf(m, wm[w]);
+  return m;
+}
+// one atomic per tile, and only when the slot would grow
+__device__ inline void amax_tile_commit(unsigned* slot, float m) {
+  const unsigned b = __builtin_bit_cast(unsigned, m);
+  if (b > __atomic_load_n(slot, __ATOMIC_RELAXED)) atomicMax(slot, b);
+}
 
 // One (32*TI) x (32*TJ) output block per wave (TJ = 2 unless stated): C[rows][n0..] = X[rows][K] * W[n][K]^T, K a
 // multiple of 32.

@@ -292,6 +292,8 @@ struct DwPair {
   // is saved forward state of known range) and where its producer left max |.| over the real rows (float bits)
   int adj = 0;
   const unsigned* amax = nullptr;
+  // ... and where the forward left max |.| of the OTHER operand (saved state: PointBufs::smax), or nullptr: the fixed 2^6
+  const unsigned* smax = nullptr;
 };
 
 template <bool GUARD, int KT>
@@ -1021,7 +1023,9 @@ template <int TJ, class Epi, int NP = 3>
 __global__ __launch_bounds__(512, 1) void gemm_rows_x3m_kernel(const float* __restrict__ A, int lda,
                                                                const x3raw* __restrict__ W3, int N, int K, Epi epi,
                                                                unsigned* amax = nullptr, long long m_real = 0,
-                                                               const unsigned* in_amax = nullptr) {
+                                                               const unsigned* in_amax = nullptr,
+                                                               const float* w_iscale = nullptr) {
+  // w_iscale (NP == 2): 1 / the scale this matrix carries in the fp16 mirror (H2Tab::iws of its id)
   constexpr int ROWS = 128;
   constexpr int PLB = ROWS * XP;              // bytes of one plane
   constexpr int BUFB = NP * PLB;              // one staging buffer (three planes: 18,432 B)
@@ -1061,6 +1065,7 @@ __global__ __launch_bounds__(512, 1) void gemm_rows_x3m_kernel(const float* __re
   [[maybe_unused]] float sa = kH2ActScale, isa = 1.f / kH2ActScale;
   if constexpr (NP == 2) {
     if (in_amax != nullptr) x2h_dyn_scale(*in_amax, sa, isa);
+    isa *= w_iscale != nullptr ? *w_iscale : 1.f / kH2WScale;   // (from here on: accumulator -> product)
   }
   auto stage = [&](const vf4& x, int buf) {
     char* w = swr + buf * BUFB;
@@ -1138,7 +1143,7 @@ __global__ __launch_bounds__(512, 1) void gemm_rows_x3m_kernel(const float* __re
       for (int ti = 0; ti < 4; ++ti) t[ti][0] = acc[ti][tj];
       m = fmaxf(m, acc_absmax<4, 1>(t, lane, left >= ROWS ? ROWS : (int)(left < 0 ? 0 : left)));
     }
-    if constexpr (NP == 2) m *= isa * (1.f / kH2WScale);   // (the accumulators are still scaled)
+    if constexpr (NP == 2) m *= isa;   // (the accumulators are still scaled)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     if (lane == 0) wmx[wave] = m;
@@ -1155,7 +1160,7 @@ __global__ __launch_bounds__(512, 1) void gemm_rows_x3m_kernel(const float* __re
     if (!on[tj]) continue;
     v16f t[4][1];
 #pragma unroll
-    for (int ti = 0; ti < 4; ++ti) t[ti][0] = NP == 3 ? acc[ti][tj] : acc[ti][tj] * (isa * (1.f / kH2WScale));
+    for (int ti = 0; ti < 4; ++ti) t[ti][0] = NP == 3 ? acc[ti][tj] : acc[ti][tj] * isa;
     run_epilogue<1, Epi, 4>(t, strip, m_blk, nt[tj] * 32, lane, 1u, epi);
   }
 }
@@ -1330,13 +1335,19 @@ __device__ inline void dw_x3_body(const DwGroup& g, const DwJob& J, int split, c
   double bs[4] = {0.0, 0.0, 0.0, 0.0};
   // x2h: one scale for the adjoint operands of all pairs of the job (they share the accumulators), from the larger of
   // their recorded maxima; the state operands (activations, Jacobian rows, network inputs) carry kH2ActScale
-  [[maybe_unused]] float s_adj = 1.f, unscale = 1.f;
+  [[maybe_unused]] float s_adj = 1.f, s_state = kH2ActScale, unscale = 1.f;
   if constexpr (NP == 2) {
     unsigned mb = J.p1.amax ? *J.p1.amax : 0u;
     if (J.npairs > 1 && J.p2.amax) mb = max(mb, *J.p2.amax);
     float inv;
     x2h_dyn_scale(mb, s_adj, inv);
-    unscale = inv * (1.f / kH2ActScale);
+    // the state operands: 2^6 (the round-4 constant: results unchanged) while their recorded maximum stays below 2^8, else
+    // the power of two that puts it in [2^13, 2^14) — no saved activation / Jacobian row is out of range
+    unsigned sb = J.p1.smax ? *J.p1.smax : 0u;
+    if (J.npairs > 1 && J.p2.smax) sb = max(sb, *J.p2.smax);
+    float inv_state = 1.f / kH2ActScale;
+    if ((sb >> 23) >= 127u + 8u && (sb >> 23) < 255u) x2h_dyn_scale(sb, s_state, inv_state);
+    unscale = inv * inv_state;
   }
   [[maybe_unused]] unsigned long long t_bar = 0, t_chunk = 0, t_load = 0, t_all = 0;
   [[maybe_unused]] const unsigned long long t_begin = DUMMY == 1 ? __builtin_amdgcn_s_memtime() : 0;
@@ -1344,7 +1355,7 @@ __device__ inline void dw_x3_body(const DwGroup& g, const DwJob& J, int split, c
   for (int pi = 0; pi < J.npairs; ++pi) {
     const DwPair p = pi == 0 ? J.p1 : J.p2;
     const int ld = sop == 0 ? p.ldx : p.ldy;
-    [[maybe_unused]] const float sc = NP == 2 ? (sop == p.adj ? s_adj : kH2ActScale) : 1.f;   // this thread's operand
+    [[maybe_unused]] const float sc = NP == 2 ? (sop == p.adj ? s_adj : s_state) : 1.f;   // this thread's operand
     // resource based at this split's first row: 32-bit offsets stay inside the split whatever the total point count
     const BufRsrc src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>((sop == 0 ? p.X : p.Y) + (size_t)m_begin * ld), 0,
                                                           0xfffffffc, 0x00020000);

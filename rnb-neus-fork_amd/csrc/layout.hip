@@ -122,13 +122,21 @@ int make_layout(const rnb_model_desc* d, Layout* L) {
     L->variant |= RNB_VARIANT_X3;
   if (L->variant & RNB_VARIANT_X3)
     L->total_all = L->total + L->total / 2 * 3;   // hi / mid / lo bf16 mirror of the weights behind the fp32 ones
+  if ((d->variant & RNB_VARIANT_REG_TILE) && (d->variant & RNB_VARIANT_LDS_TILE))
+    RNB_FAIL(RNB_E_INVALID, "RNB_VARIANT_REG_TILE and RNB_VARIANT_LDS_TILE exclude each other");
   if ((d->variant & RNB_VARIANT_X2H) && (d->variant & RNB_VARIANT_NO_X2H))
     RNB_FAIL(RNB_E_INVALID, "RNB_VARIANT_X2H and RNB_VARIANT_NO_X2H exclude each other");
   if ((d->variant & RNB_VARIANT_X2H) && !(L->variant & RNB_VARIANT_X3))
     RNB_FAIL(RNB_E_INVALID, "RNB_VARIANT_X2H is a form of the x3 path (256-wide SDF network, fp32)");
   // forward-type sweeps of the x3 path: three fp16 terms unless switched off
   if ((L->variant & RNB_VARIANT_X3) && !(d->variant & RNB_VARIANT_NO_X2H)) L->variant |= RNB_VARIANT_X2H;
-  if (L->variant & RNB_VARIANT_X2H) L->total_all += L->total;   // + hi / lo fp16 mirror (W and W^T of the SDF network used)
+  L->h2tab_off = -1;
+  if (L->variant & RNB_VARIANT_X2H) {
+    L->total_all += L->total;   // + hi / lo fp16 mirror (W and W^T of the SDF network used)
+    L->h2tab_off = L->total_all;   // + the mirror's scale table (H2Tab)
+    L->total_all += 256;
+    if (L->nh + 1 + L->nc > kH2TabSlots) RNB_FAIL(RNB_E_INVALID, "too many layers for the x2h scale table");
+  }
   return RNB_OK;
 }
 
@@ -144,6 +152,7 @@ void carve_points(const Layout& L, Carver& c, int64_t M, int mode, PointBufs* pb
   pb->e = c.take<float>(Mp * L.Ep);
   for (int l = 0; l < L.nh; ++l) pb->a[l] = take_state(Mp * L.Hp);
   pb->sdf = c.take<float>(Mp);
+  pb->smax = c.take<unsigned>(SMAX_SLOTS);
   if (mode & (PM_WITH_NORMAL | PM_WITH_COLOR | PM_WITH_BACKWARD)) {
     for (int l = 0; l < L.nh; ++l) pb->gz[l] = take_state(Mp * L.Hp);
     for (int l = 0; l < L.nh; ++l) pb->D[l] = take_state(Mp * L.Hp);

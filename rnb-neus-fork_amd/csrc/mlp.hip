@@ -426,6 +426,17 @@ __global__ void scale_copy_kernel(const float* __restrict__ src, float scale, in
   if (i < n) dst[i] = src[i] * scale;
 }
 
+// max |.| of a buffer into one slot (float bits, atomicMax; the slot only grows): the maxima of the saved state that the
+// per-layer albedo path leaves for the x2h weight-gradient jobs (the fused kernels record theirs on the way)
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, int64_t n4, unsigned* __restrict__ slot) {
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const vf4 v = *reinterpret_cast<const vf4*>(x + 4 * i);
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+  amax_commit(slot, m, threadIdx.x & 63);
+}
+
 // strided [rows, ld] (first ncols columns) -> dense [M, ncols]
 __global__ void copy_cols_kernel(const float* __restrict__ src, int ld, int ncols, int64_t M, float* __restrict__ out) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -636,13 +647,15 @@ static inline double mm_flops(int64_t M, const Lin& ln) { return 2.0 * (double)M
 template <bool B_KMAJOR, class Epi>
 static int launch_rows(const float* A, int lda, const float* W, int ldw, int64_t Mp, int N, int K, const Epi& epi,
                        double flops, hipStream_t s, bool x3 = false, const x3raw* W3 = nullptr, const x3raw* Wh2 = nullptr,
-                       unsigned* amax = nullptr, int64_t m_real = 0, const unsigned* in_amax = nullptr) {
+                       unsigned* amax = nullptr, int64_t m_real = 0, const unsigned* in_amax = nullptr,
+                       const float* w_iscale = nullptr) {
   ProfScope prof(flops, s, (Wh2 && !in_amax) ? "layer_gemm(forward)" : "layer_gemm");
   if constexpr (!B_KMAJOR) {
     // Wh2: this matrix in the fp16 mirror (x2h; forward layers only)
     if (x3 && Wh2 != nullptr && N % 32 == 0 && N <= 512 && K % 32 == 0 && Mp % 128 == 0) {
-      if (N <= 256) hipLaunchKernelGGL((gemm_rows_x3m_kernel<1, Epi, 2>), dim3((unsigned)(Mp / 128)), dim3(512), 0, s, A, lda, Wh2, N, K, epi, amax, (long long)m_real, in_amax);
-      else hipLaunchKernelGGL((gemm_rows_x3m_kernel<2, Epi, 2>), dim3((unsigned)(Mp / 128)), dim3(512), 0, s, A, lda, Wh2, N, K, epi, amax, (long long)m_real, in_amax);
+      if (w_iscale == nullptr) RNB_FAIL(RNB_E_INVALID, "x2h layer GEMM without the matrix's scale");
+      if (N <= 256) hipLaunchKernelGGL((gemm_rows_x3m_kernel<1, Epi, 2>), dim3((unsigned)(Mp / 128)), dim3(512), 0, s, A, lda, Wh2, N, K, epi, amax, (long long)m_real, in_amax, w_iscale);
+      else hipLaunchKernelGGL((gemm_rows_x3m_kernel<2, Epi, 2>), dim3((unsigned)(Mp / 128)), dim3(512), 0, s, A, lda, Wh2, N, K, epi, amax, (long long)m_real, in_amax, w_iscale);
       RNB_CHECK_LAUNCH();
       return RNB_OK;
     }
@@ -653,6 +666,9 @@ static int launch_rows(const float* A, int lda, const float* W, int ldw, int64_t
       RNB_CHECK_LAUNCH();
       return RNB_OK;
     }
+    // (only the mirror kernels above leave max |.| of their outputs: a weight-gradient job scaled by a slot nobody wrote
+    // would overflow — refuse instead of falling through)
+    if (amax != nullptr) RNB_FAIL(RNB_E_INVALID, "layer GEMM %d x %d: the x2h maxima were requested from a kernel that does not record them", N, K);
     if (x3 && N >= 256 && K % XK == 0) {
       dim3 grid((unsigned)(Mp / BM), (unsigned)((N + 255) / 256));
       if (N % 256 == 0) hipLaunchKernelGGL((gemm_rows_x3_kernel<256, false, Epi>), grid, dim3(256), 0, s, A, lda, W, ldw, N, K, epi);
@@ -791,12 +807,15 @@ struct DwBatch {
       slab += need;
       slab_left -= need;
     }
-    {
-      ProfScope prof(flops[3], s, "dW(x3: 256x256 + narrow jobs + reduce)");
+    {   // (two scopes: the class time of the weight-gradient kernel is then its own launch duration, as a kernel trace shows it)
+      ProfScope prof(flops[3], s, "dW(x3: 256x256 + narrow jobs)");
       if (x3 && h2) hipLaunchKernelGGL((gemm_dw_x3_kernel<0, 2>), dim3((unsigned)end), dim3(512), 0, s, g);
       else if (x3) hipLaunchKernelGGL((gemm_dw_x3_kernel<0, 3>), dim3((unsigned)end), dim3(512), 0, s, g);
       else hipLaunchKernelGGL(gemm_dw_staged_kernel<0>, dim3((unsigned)end), dim3(1024), 0, s, g);
-      RNB_CHECK_LAUNCH();
+    }
+    RNB_CHECK_LAUNCH();
+    {
+      ProfScope prof(0.0, s, "dW(slab reduce)");
       hipLaunchKernelGGL(dw_reduce_kernel<0>, dim3(256, g.njobs), dim3(256), 0, s, g);
     }
     g.njobs = 0;
@@ -980,6 +999,12 @@ int launch_fill_cols(const float* src, int ncols, int64_t M, int64_t Mp, int ld,
   return RNB_OK;
 }
 
+static int launch_absmax(const float* x, int64_t n, unsigned* slot, hipStream_t s) {
+  hipLaunchKernelGGL(absmax_kernel, dim3(1024), dim3(256), 0, s, x, n / 4, slot);
+  RNB_CHECK_LAUNCH();
+  return RNB_OK;
+}
+
 int launch_pe_points(const Layout& L, const float* pts, int64_t M, PointBufs& pb, hipStream_t s) {
   hipLaunchKernelGGL(pe_points_kernel, dim3(blocks_for(pb.Mp, 256)), dim3(256), 0, s, pts, M, pb.Mp, L.sdf_scale,
                      L.multires, L.Ep, pb.x, pb.e);
@@ -1044,10 +1069,14 @@ int sweep_color(const Layout& L, const float* packed, PointBufs& pb, const float
     const float* in = l == 0 ? pb.cin : pb.ac[l - 1];
     const int lda = l == 0 ? L.Cinp : L.Hcp;
     EpiRelu epi{packed + ln.b_off, pb.ac[l], L.Hcp, ln.N};
-    // forward layers: inputs of known range (points, normals, features, relu outputs) -> the fp16 three-term form
-    const x3raw* wh2 = is_x2h(L) ? x2h_mirror(L, packed) + 2 * ln.w_off : nullptr;
+    // (per-layer path of an albedo net the fused kernels do not cover: six bf16 terms — no operand range to look after)
     RNB_TRY((launch_rows<false, EpiRelu>(in, lda, packed + ln.w_off, ln.Kp, pb.Mp, ln.Np, ln.Kp, epi, mm_flops(pb.M, ln), s, is_x3(L),
-                                         x3_mirror(L, packed, ln.w_off), wh2)));
+                                         x3_mirror(L, packed, ln.w_off), nullptr)));
+    // x2h weight gradients take this layer's input / output as a state operand: its maximum (PointBufs::smax)
+    if (is_x2h(L) && pb.smax != nullptr) {
+      if (l == 0) RNB_TRY(launch_absmax(pb.cin, pb.Mp * L.Cinp, pb.smax + SMAX_CIN, s));
+      RNB_TRY(launch_absmax(pb.ac[l], pb.Mp * L.Hcp, pb.smax + SMAX_AC + l, s));
+    }
   }
   hipLaunchKernelGGL(color_out_kernel, dim3(blocks_for(pb.Mp * 16, 256)), dim3(256), 0, s, pb.ac[L.nc - 1], L.Hcp,
                      L.Hc, packed + L.colo.w_off, L.colo.Kp, packed + L.colo.b_off, L.Co, L.squeeze, pb.Mp, pb.alb);
@@ -1092,19 +1121,22 @@ int sweep_backward(const Layout& L, const float* packed, PointBufs& pb, bool wit
       const Lin& ln = L.col[l];
       const float* in = l == 0 ? pb.cin : pb.ac[l - 1];
       const int ldin = l == 0 ? L.Cinp : L.Hcp;
-      DwPair p{pb.zc[l], L.Hcp, in, ldin, 0, h2 ? pb.amax + AMAX_ZC + l : nullptr};
+      DwPair p{pb.zc[l], L.Hcp, in, ldin, 0, h2 ? pb.amax + AMAX_ZC + l : nullptr,
+               h2 ? pb.smax + (l == 0 ? SMAX_CIN : SMAX_AC + l - 1) : nullptr};
       RNB_TRY(dw.add(p, p, 1, ln.Np, ln.Kp, packed_grad + ln.w_off, ln.Kp, packed_grad + ln.b_off, 0, mm_flops(M, ln)));
       if (l > 0) {
         EpiReluMask epi{pb.ac[l - 1], pb.zc[l - 1], L.Hcp, L.col[l - 1].N};
         // zc_{l-1} = (zc_l W_l) * relu': k-contiguous product against the transposed copy W_l^T [Kp x Np]
         RNB_TRY((launch_rows<false, EpiReluMask>(pb.zc[l], L.Hcp, packed + ln.wT_off, ln.Np, Mp, ln.Kp, ln.Np, epi, mm_flops(M, ln), s, is_x3(L),
                                                  x3_mirror(L, packed, ln.wT_off), h2 ? x2h_mirror(L, packed) + 2 * ln.wT_off : nullptr,
-                                                 h2 ? pb.amax + AMAX_ZC + (l - 1) : nullptr, M, h2 ? pb.amax + AMAX_ZC + l : nullptr)));
+                                                 h2 ? pb.amax + AMAX_ZC + (l - 1) : nullptr, M, h2 ? pb.amax + AMAX_ZC + l : nullptr,
+                                                 h2 ? &h2_tab(L, packed)->iws[L.nh + 1 + l] : nullptr)));
       } else {
         EpiStore epi{pb.cinb, L.Cinp};
         RNB_TRY((launch_rows<false, EpiStore>(pb.zc[0], L.Hcp, packed + ln.wT_off, ln.Np, Mp, ln.Kp, ln.Np, epi, mm_flops(M, ln), s, is_x3(L),
                                               x3_mirror(L, packed, ln.wT_off), h2 ? x2h_mirror(L, packed) + 2 * ln.wT_off : nullptr,
-                                              h2 ? pb.amax + AMAX_CINB : nullptr, M, h2 ? pb.amax + AMAX_ZC + 0 : nullptr)));
+                                              h2 ? pb.amax + AMAX_CINB : nullptr, M, h2 ? pb.amax + AMAX_ZC + 0 : nullptr,
+                                              h2 ? &h2_tab(L, packed)->iws[L.nh + 1] : nullptr)));
       }
     }
   }
@@ -1159,7 +1191,7 @@ int sweep_backward(const Layout& L, const float* packed, PointBufs& pb, bool wit
                                         with_color ? mm_flops(M, L.feat) : 0.0, s)));
     }
     if (with_color) {
-      DwPair p{pb.cinb, L.Cinp, pb.a[L.nh - 1], L.Hp, 0, h2 ? pb.amax + AMAX_CINB : nullptr};
+      DwPair p{pb.cinb, L.Cinp, pb.a[L.nh - 1], L.Hp, 0, h2 ? pb.amax + AMAX_CINB : nullptr, h2 ? pb.smax + SMAX_A + L.nh - 1 : nullptr};
       RNB_TRY(dw.add(p, p, 1, L.feat.Np, L.feat.Kp, packed_grad + L.feat.w_off, L.feat.Kp,
                      packed_grad + L.feat.b_off, 0, mm_flops(M, L.feat)));
     }
@@ -1170,8 +1202,10 @@ int sweep_backward(const Layout& L, const float* packed, PointBufs& pb, bool wit
     const float* in = l == 0 ? pb.e : pb.a[l - 1];
     const int ldin = l == 0 ? L.Ep : L.Hp;
     const float* uin = l == 0 ? pb.geb : pb.u[l];
-    DwPair p1{pb.gz[l], L.Hp, uin, ldin, 1, h2 ? pb.amax + AMAX_U + l : nullptr};
-    DwPair p2{pb.zb[l], L.Hp, in, ldin, 0, h2 ? pb.amax + AMAX_ZB + l : nullptr};
+    // (x2h: adjoint operand, its recorded maximum; the state operand's recorded maximum)
+    DwPair p1{pb.gz[l], L.Hp, uin, ldin, 1, h2 ? pb.amax + AMAX_U + l : nullptr, h2 ? pb.smax + SMAX_GZ + l : nullptr};
+    DwPair p2{pb.zb[l], L.Hp, in, ldin, 0, h2 ? pb.amax + AMAX_ZB + l : nullptr,
+              h2 ? pb.smax + (l == 0 ? SMAX_E : SMAX_A + l - 1) : nullptr};
     RNB_TRY(dw.add(p1, p2, 2, ln.Np, ln.Kp, packed_grad + ln.w_off, ln.Kp, packed_grad + ln.b_off, 1,
                    2.0 * mm_flops(M, ln)));
     if (l > 0 && !fused) {

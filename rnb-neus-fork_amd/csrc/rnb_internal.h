@@ -69,6 +69,7 @@ struct Layout {
   int squeeze;
   int64_t total;          // floats of fp32 packed weights (also the length of a gradient buffer)
   int64_t total_all;      // floats of the packed buffer = total (+ total / 2 for the bf16 mirror, RNB_VARIANT_BF16)
+  int64_t h2tab_off;      // RNB_VARIANT_X2H: float offset of the scale table of the fp16 mirror (H2Tab), else -1
   int variant;            // rnb_model_desc.variant (RNB_VARIANT_* bits)
   int knob(int shift) const { return (variant >> shift) & 3; }
 };
@@ -119,6 +120,22 @@ struct Carver {
   }
 };
 
+// ---- RNB_VARIANT_X2H: scales of the fp16 mirror -----------------------------------------------------------------------
+// Every matrix of the fp16 mirror is stored times a power of two chosen from the matrix's own maximum: 2^8 while
+// max |w| < 64 (the round-4 constant), else the power of two that puts the maximum in [2^13, 2^14) — so NO weight is out of
+// range.  The table sits behind the mirror in the packed buffer (256 floats): per matrix id the float bits of max |w|
+// (atomicMax by x3_pack_kernel, zeroed by wn_fwd_kernel), the scale and its inverse (written by x2h_pack_kernel, read by
+// every kernel that multiplies with the mirror).  ids: hidden layer l -> l, feature head -> nh, albedo hidden layer l ->
+// nh + 1 + l; W and W^T share an id.
+constexpr int kH2TabSlots = 48;
+struct H2Tab {
+  unsigned wmax[kH2TabSlots];
+  float ws[kH2TabSlots];
+  float iws[kH2TabSlots];
+};
+static_assert(sizeof(H2Tab) <= 256 * sizeof(float), "the packed buffer reserves 256 floats for the table");
+inline int h2_id_hid(int l) { return l; }
+
 // State of one batch of points going through the SDF (+albedo) network(s).  All activation matrices
 // are [Mp x width_padded] row-major fp32.
 struct PointBufs {
@@ -150,12 +167,17 @@ struct PointBufs {
   void* zc8[RNB_MAX_LIN];   //   pre-activation adjoints as bf16 K8 [Mp,256]
   void* fbar_k8;            // RNB_VARIANT_BF16: feature part of cinb as bf16 K8 [Mp,256] (written by the FB sweep)
   unsigned* amax;           // [AMAX_SLOTS] max |.| of the adjoint tensors (float bits; zeroed at the start of a backward)
+  unsigned* smax;           // [SMAX_SLOTS] max |.| of the saved forward state the x2h weight-gradient jobs take as operands
+                            // (float bits; zeroed by the first kernel of a render forward, grown by the forward sweeps)
   float* dw_part;           // partial slabs of the split-K weight-gradient GEMMs: [deterministic variant | staged kernel]
   int64_t dw_part_floats;
 };
 
 // slots of PointBufs::amax: zb_l, u_l (u_0 = geb), zc_l, cinb
 enum { AMAX_ZB = 0, AMAX_U = RNB_MAX_LIN, AMAX_ZC = 2 * RNB_MAX_LIN + 1, AMAX_CINB = 3 * RNB_MAX_LIN + 1, AMAX_SLOTS = 3 * RNB_MAX_LIN + 2 };
+// slots of PointBufs::smax: a_l, gz_l (hidden layers), e (positional encoding), cin (albedo-net input), ac_l (its hidden layers)
+enum { SMAX_A = 0, SMAX_GZ = RNB_MAX_LIN, SMAX_E = 2 * RNB_MAX_LIN, SMAX_CIN = 2 * RNB_MAX_LIN + 1, SMAX_AC = 2 * RNB_MAX_LIN + 2,
+       SMAX_SLOTS = 3 * RNB_MAX_LIN + 2 };
 enum PointMode { PM_SDF_ONLY = 0, PM_WITH_NORMAL = 1, PM_WITH_COLOR = 2, PM_WITH_BACKWARD = 4 };
 void carve_points(const Layout& L, Carver& c, int64_t M, int mode, PointBufs* pb);
 
@@ -204,6 +226,12 @@ inline unsigned short* x2h_mirror(const Layout& L, float* packed) {
 }
 inline const unsigned short* x2h_mirror(const Layout& L, const float* packed) {
   return reinterpret_cast<const unsigned short*>(packed + L.total + L.total / 2 * 3);
+}
+inline const H2Tab* h2_tab(const Layout& L, const float* packed) {
+  return L.h2tab_off >= 0 ? reinterpret_cast<const H2Tab*>(packed + L.h2tab_off) : nullptr;
+}
+inline H2Tab* h2_tab(const Layout& L, float* packed) {
+  return L.h2tab_off >= 0 ? reinterpret_cast<H2Tab*>(packed + L.h2tab_off) : nullptr;
 }
 int x3_pack_weights(const Layout& L, float* packed, hipStream_t s);
 
@@ -276,7 +304,7 @@ struct CompBwdArgs {
 };
 
 int launch_fine_points(const float* rays_o, const float* rays_d, const float* z, int64_t B, int S, float sample_dist,
-                       float* pts, float* dists, hipStream_t s);
+                       float* pts, float* dists, unsigned* smax_to_zero, hipStream_t s);
 int launch_composite_fwd(const CompArgs& a, float* gerr, float* gerr_den, float* gerr_partial, hipStream_t s);
 int launch_composite_bwd(const CompBwdArgs& g, float* dvar, hipStream_t s);
 

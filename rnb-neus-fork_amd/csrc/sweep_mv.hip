@@ -122,8 +122,8 @@ __device__ __attribute__((always_inline)) inline void mv_issue(const MvRing& q, 
 // ---- LDS counters between a matrix wave and its vector wave -----------------------------------------------------
 // An LDS instruction of one wave executes after the LDS instructions that wave issued before it: a counter store behind
 // the data stores needs no wait in front of it.  The waits are bounded: a wave that has polled for ~20 ms gives up and
-// sets the error word (wrong results, but every wave still reaches every barrier and the grid drains; later waits
-// of the pair return at once).
+// sets the error word (every wave still reaches every barrier and the grid drains; later waits of the pair return at
+// once) — and the pair's SDF values are then written as NaN: the failure is loud in the results.
 __device__ __attribute__((always_inline)) inline void mv_signal(LDSP(int) c, int v, int lane) {
   asm volatile("" ::: "memory");
   if (lane == 0) *(LDSP(volatile int))c = v;
@@ -687,7 +687,10 @@ __global__ __launch_bounds__(128 * MV_MW, 2) void sweep_mv_forward_kernel(MvFwdA
     s += __shfl_xor(s, 2, 64);
     s += __shfl_xor(s, 4, 64);
     if (v.c == 0) {
-      const float val = (s + g.packed[g.bsdf_off]) / g.scale;
+      float val = (s + g.packed[g.bsdf_off]) / g.scale;
+      // a bounded wait of this pair gave up (never expected): what was computed is wrong — return NaN, the library's way of
+      // failing loudly without a device synchronisation (the host cannot see the error word before the caller syncs)
+      if (*(LDSP(volatile int))(pr.sync + 3) != 0) val = __builtin_nanf("");
       if (!g.grid.on) g.sdf[v.row[i]] = val;
       else if (v.row[i] < g.M) g.sdf[v.row[i]] = val * g.grid.out_scale;   // the volume has exactly M entries
     }

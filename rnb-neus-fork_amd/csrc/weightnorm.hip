@@ -21,7 +21,9 @@ struct WnEntry {
   long long w_off, b_off;
   long long wT_off;  // transposed copy [Kp x Nrows] or -1
   float scale;
+  int skip;          // this is the skip layer: `scale` stands for 1 / sqrt(2), taken at fp64 precision by both kernels
 };
+__device__ inline double wn_scale(const WnEntry& en) { return en.skip ? 0.70710678118654752440 : (double)en.scale; }
 constexpr int kMaxEntries = 2 * RNB_MAX_LIN + 2;
 struct WnTable {
   int n;
@@ -63,8 +65,10 @@ __device__ inline double block_sum_f64(double v, double* red) {
 // -1.1e-7 with the factor in fp32, profiles/r04_sdf_bias.txt), which a sharp surface (inv_s ~ 400) turns into twice the
 // weight_sum error of the fp32 CPU oracle.  So the factor is formed in fp64 and every W element is rounded once, from
 // the fp64 product (675k elements per step: nothing).
-__global__ __launch_bounds__(256) void wn_fwd_kernel(WnTable tab, float* __restrict__ packed) {
+__global__ __launch_bounds__(256) void wn_fwd_kernel(WnTable tab, float* __restrict__ packed, unsigned* __restrict__ wmax_zero) {
   __shared__ double red[4];
+  // x2h: the per-matrix maxima of the mirror's scale table start from zero (x3_pack_kernel, the next launch, grows them)
+  if (wmax_zero != nullptr && blockIdx.x == 0 && threadIdx.x < kH2TabSlots) wmax_zero[threadIdx.x] = 0u;
   int ei = 0;
   while (ei + 1 < tab.n && (int)blockIdx.x >= tab.e[ei + 1].row_begin) ++ei;
   const WnEntry& en = tab.e[ei];
@@ -82,7 +86,7 @@ __global__ __launch_bounds__(256) void wn_fwd_kernel(WnTable tab, float* __restr
   const int src = en.src_row0 + r;
   const float* vrow = en.v + (long long)src * en.K;
   // the skip layer's 1/sqrt(2) (models/fields.py:93 divides the activations by np.sqrt(2)) at fp64 precision
-  const double scale = en.scale == 0.70710678118654752440f ? 0.70710678118654752440 : (double)en.scale;
+  const double scale = wn_scale(en);
   double mult = scale;
   if (en.g != nullptr) {
     double ss = 0.0;
@@ -104,7 +108,7 @@ __global__ __launch_bounds__(256) void wn_fwd_kernel(WnTable tab, float* __restr
 }
 
 __global__ __launch_bounds__(256) void wn_bwd_kernel(WnTable tab, const float* __restrict__ pgrad) {
-  __shared__ float red[4];
+  __shared__ double red[4];
   int ei = 0;
   while (ei + 1 < tab.n && (int)blockIdx.x >= tab.e[ei + 1].row_begin) ++ei;
   const WnEntry& en = tab.e[ei];
@@ -114,30 +118,32 @@ __global__ __launch_bounds__(256) void wn_bwd_kernel(WnTable tab, const float* _
   const float* vrow = en.v + (long long)src * en.K;
   const float* dwrow = pgrad + en.w_off + (long long)r * en.Kp;
   float* dvrow = en.dv + (long long)src * en.K;
+  // the same row factor as the forward's (fp64: scale * g / ||v||), so that W and dW/dv, dW/dg describe one function
+  const double scale = wn_scale(en);
   if (en.g == nullptr) {
-    for (int i = threadIdx.x; i < en.K; i += blockDim.x) dvrow[i] = en.scale * dwrow[cmap(en, i)];
+    for (int i = threadIdx.x; i < en.K; i += blockDim.x) dvrow[i] = (float)(scale * (double)dwrow[cmap(en, i)]);
   } else {
-    float ss = 0.f, t = 0.f;
+    double ss = 0.0, t = 0.0;
     for (int i = threadIdx.x; i < en.K; i += blockDim.x) {
-      const float vv = vrow[i];
-      ss = fmaf(vv, vv, ss);
-      t = fmaf(dwrow[cmap(en, i)], vv, t);
+      const double vv = (double)vrow[i];
+      ss = fma(vv, vv, ss);
+      t = fma((double)dwrow[cmap(en, i)], vv, t);
     }
-    ss = block_sum(ss, red);
-    t = block_sum(t, red);
-    const float inv_norm = 1.f / sqrtf(ss);
-    const float gg = en.g[src];
-    const float coef = en.scale * gg * inv_norm;
-    const float proj = t * inv_norm * inv_norm;   // (v . dW) / ||v||^2
-    for (int i = threadIdx.x; i < en.K; i += blockDim.x) dvrow[i] = coef * (dwrow[cmap(en, i)] - vrow[i] * proj);
-    if (threadIdx.x == 0) en.dg[src] = en.scale * t * inv_norm;
+    ss = block_sum_f64(ss, red);
+    t = block_sum_f64(t, red);
+    const double inv_norm = 1.0 / sqrt(ss);
+    const double coef = scale * (double)en.g[src] * inv_norm;
+    const double proj = t * inv_norm * inv_norm;   // (v . dW) / ||v||^2
+    for (int i = threadIdx.x; i < en.K; i += blockDim.x)
+      dvrow[i] = (float)(coef * ((double)dwrow[cmap(en, i)] - (double)vrow[i] * proj));
+    if (threadIdx.x == 0) en.dg[src] = (float)(scale * t * inv_norm);
   }
   if (threadIdx.x == 0) en.db[src] = pgrad[en.b_off + r];
 }
 
 static void add_entry(WnTable& t, const rnb_mlp_params* p, const rnb_mlp_grads* g, int lin, bool wn, int src_row0,
                       int N, int Nrows, int K, int Kp, long long w_off, long long b_off, float scale, int cmap_f,
-                      int cmap_2pev, long long wT_off = -1) {
+                      int cmap_2pev, long long wT_off = -1, int skip = 0) {
   WnEntry& e = t.e[t.n];
   e.g = wn ? p->g[lin] : nullptr;
   e.v = p->v[lin];
@@ -157,6 +163,7 @@ static void add_entry(WnTable& t, const rnb_mlp_params* p, const rnb_mlp_grads* 
   e.wT_off = wT_off;
   e.b_off = b_off;
   e.scale = scale;
+  e.skip = skip;
   t.total_rows += Nrows;
   t.n++;
 }
@@ -173,7 +180,7 @@ static int build_table(const rnb_model_desc* d, const Layout& L, const rnb_mlp_p
       if (!sdf->v[l] || !sdf->b[l] || (wn && !sdf->g[l])) RNB_FAIL(RNB_E_NULL, "sdf lin%d has a NULL leaf", l);
     for (int l = 0; l < L.nh; ++l) {
       const Lin& ln = L.hid[l];
-      add_entry(t, sdf, gs, l, wn, 0, ln.N, ln.Np, ln.K, ln.Kp, ln.w_off, ln.b_off, ln.scale, 0, 0, ln.wT_off);
+      add_entry(t, sdf, gs, l, wn, 0, ln.N, ln.Np, ln.K, ln.Kp, ln.w_off, ln.b_off, ln.scale, 0, 0, ln.wT_off, l == L.skip ? 1 : 0);
     }
     // output layer: row 0 -> sdf head, rows 1.. -> feature head
     add_entry(t, sdf, gs, L.nh, wn, 0, 1, 1, L.H, L.Hp, L.wsdf_off, L.bsdf_off, 1.f, 0, 0);
@@ -201,7 +208,8 @@ int weightnorm_fwd(const rnb_model_desc* d, const Layout& L, const rnb_mlp_param
                    float* packed, hipStream_t s) {
   WnTable t;
   RNB_TRY(build_table(d, L, sdf, color, nullptr, nullptr, t));
-  hipLaunchKernelGGL(wn_fwd_kernel, dim3(t.total_rows), dim3(256), 0, s, t, packed);
+  H2Tab* h2 = h2_tab(L, packed);
+  hipLaunchKernelGGL(wn_fwd_kernel, dim3(t.total_rows), dim3(256), 0, s, t, packed, h2 ? h2->wmax : (unsigned*)nullptr);
   RNB_CHECK_LAUNCH();
   return RNB_OK;
 }

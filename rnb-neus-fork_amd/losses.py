@@ -25,7 +25,7 @@ import torch
 import torch.distributed as dist
 
 from . import native
-from .parallel import local_mask_count
+from .parallel import all_reduce_sum, local_mask_count
 
 
 class _RnbLoss(torch.autograd.Function):
@@ -70,7 +70,7 @@ class _RnbLoss(torch.autograd.Function):
             world = dist.get_world_size(group)
             # ONE collective for every batch-global normaliser: [eikonal numerator, eikonal count, sum(mask > 0.5), rays]
             glob = torch.cat([token.gerr_partial, local_mask_count(mk, mask_weight > 0.0)])
-            dist.all_reduce(glob, op=dist.ReduceOp.SUM, group=group)
+            all_reduce_sum(glob, group)
             token.gerr_den_global.copy_(glob[1:2] + 1e-5)       # what the renderer's backward divides by
             ge_global = (glob[0:1] / token.gerr_den_global).contiguous()
             batch_global = glob[2:4].contiguous()
@@ -84,7 +84,7 @@ class _RnbLoss(torch.autograd.Function):
             # report_global=False keeps this rank's additive share instead and saves the collective.
             if report_global:
                 rep = torch.cat([loss.reshape(1), parts])
-                dist.all_reduce(rep, op=dist.ReduceOp.SUM, group=group)
+                all_reduce_sum(rep, group)
                 loss, parts = rep[0].clone(), rep[1:].clone()
         else:
             with native.on_device(color) as stream:

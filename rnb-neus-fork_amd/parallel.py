@@ -32,17 +32,52 @@ def shard_batch(batch: dict, rank: int, world_size: int, n_rays: int | None = No
     return out
 
 
+# Optional timing of the step's collectives (bench.py, N > 1): while enabled, every all-reduce issued through
+# `all_reduce_sum` is bracketed by two events on the current stream (the collective is waited for on that stream before
+# the call returns, so the interval covers it).  Off by default: no events, no overhead.
+_TIMED = None
+
+
+def time_collectives(enable: bool):
+    """Starts (True) or stops (False) recording event pairs around the data-parallel all-reduces of this process."""
+    global _TIMED
+    _TIMED = [] if enable else None
+
+
+def collective_ms():
+    """(summed milliseconds, number of collectives) recorded since `time_collectives(True)`; call after a device
+    synchronisation.  Clears the record."""
+    global _TIMED
+    if not _TIMED:
+        return 0.0, 0
+    ms, n = sum(a.elapsed_time(b) for a, b in _TIMED), len(_TIMED)
+    _TIMED = []
+    return ms, n
+
+
+def all_reduce_sum(t: torch.Tensor, group=None):
+    """dist.all_reduce(SUM) in place; timed when `time_collectives(True)` is in effect and `t` lives on a GPU."""
+    if _TIMED is not None and t.is_cuda:
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        b.record()
+        _TIMED.append((a, b))
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
 def allreduce_mean_(flat: torch.Tensor, group=None):
     """In-place mean over ranks of one flat fp32 buffer (675,771 floats = 2.7 MB for the full model)."""
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    all_reduce_sum(flat, group)
     flat.mul_(1.0 / dist.get_world_size(group))
     return flat
 
 
 def allreduce_sum_(flat: torch.Tensor, group=None):
     """In-place sum over ranks (the exact large-batch gradient when every rank's loss is its additive share)."""
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-    return flat
+    return all_reduce_sum(flat, group)
 
 
 def local_mask_count(mask: torch.Tensor, use_mask: bool) -> torch.Tensor:

@@ -101,9 +101,10 @@ def test_packed_layout_size_and_workspace_queries():
     # the default variant of this shape multiplies fp32 operands as three bf16 terms (x3): a split mirror of 1.5 x the
     # floats follows the fp32 weights, and behind it the two fp16 planes of the forward-type sweeps (x2h: 1 x); the
     # native-fp32-MFMA and generic variants carry no mirror, bf16 one of 0.5 x
-    assert n.value == expect + expect // 2 * 3 + expect
+    # (+ 256 floats behind the fp16 planes: the per-matrix scale table of that mirror)
+    assert n.value == expect + expect // 2 * 3 + expect + 256
     for kw, extra in ((dict(f32_mfma=True), 0), (dict(generic=True), 0), (dict(bf16=True), expect // 2),
-                      (dict(x2h=False), expect // 2 * 3), (dict(x2h=True), expect // 2 * 3 + expect)):
+                      (dict(x2h=False), expect // 2 * 3), (dict(x2h=True), expect // 2 * 3 + expect + 256)):
         d2 = _desc()
         d2.variant = R.native.variant_bits(**kw)
         R.native.check(lib.rnb_packed_floats(C.byref(d2), C.byref(n)))
