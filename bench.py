@@ -75,7 +75,7 @@ def measured_mfma_busy(build_id, name="sq_counters.json"):
 CLASS_KERNELS = {"RA_sweep": "fused_ra_kernel", "FB_sweep": "fused_fb_", "R_sweep": "fused_reverse_kernel",
                  "F_sweep(save)": "fused_forward_kernel<2, true", "dW(x3: 256x256 + narrow jobs)": "gemm_dw_x3_kernel",
                  "dW(all)": "bf_dw_kernel", "dW(other)": "gemm_dw_direct_kernel", "layer_gemm": ("EpiReluMask", "EpiStore"),
-                 "layer_gemm(forward)": "EpiRelu,"}
+                 "layer_gemm(forward)": "EpiRelu,", "albedo_fwd": "color_fwd_h2_kernel", "albedo_bwd": "color_bwd_h2_kernel"}
 HBM_BOUND_TBS = 4.0    # a class that moves more than this (PMC bytes / event time) is labelled hbm-bound: half of the 8 TB/s
                        # spec, ~2/3 of what a plain copy reaches (6.3 TB/s)
 
@@ -83,7 +83,8 @@ HBM_BOUND_TBS = 4.0    # a class that moves more than this (PMC bytes / event ti
 # matrix terms per fp32 product of every kernel class under the default arithmetic (RNB_VARIANT_X3 + X2H): three fp16 terms
 # except the RA sweep, which keeps the six bf16 terms (state-traffic bound: DESIGN 4)
 X2H_TERMS = {"F_sweep(save)": 3, "F_sweep(forward_only)": 3, "R_sweep": 3, "FB_sweep": 3,
-             "dW(x3: 256x256 + narrow jobs)": 3, "layer_gemm(forward)": 3, "RA_sweep": 6, "layer_gemm": 3}
+             "dW(x3: 256x256 + narrow jobs)": 3, "layer_gemm(forward)": 6, "RA_sweep": 6, "layer_gemm": 6, "albedo_fwd": 3,
+             "albedo_bwd": 3}
 
 
 def class_peak(tag, default_peak, terms):

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 HIP_SOURCES = ["api.hip", "layout.hip", "mlp.hip", "weightnorm.hip", "sampling.hip", "composite.hip", "prof.hip", "fused.hip",
-               "sweep_mv.hip", "fused_bwd.hip", "bf16.hip", "train.hip", "raygen.hip", "mcubes.hip"]
+               "sweep_mv.hip", "fused_bwd.hip", "color_h2.hip", "bf16.hip", "train.hip", "raygen.hip", "mcubes.hip"]
 COMMON_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 EXTRA_FLAGS = {
     # sampling.hip must round like the reference's separate PyTorch ops (no fused multiply-add contraction)

@@ -483,6 +483,7 @@ RNB_API int rnb_render_fwd(const rnb_model_desc* desc, const float* packed, cons
   }
   RNB_TRY(reverse_points(L, packed, rb.pb, s));
   if (color_bf16) RNB_TRY(bf16_color_forward(L, packed, rb.pb, rb.pts, s));
+  else if (use_color && use_fused(L) && color_h2_supported(L)) RNB_TRY(color_h2_forward(L, packed, rb.pb, rb.pts, rb.pb.nrm, s));
   else if (use_color) RNB_TRY(sweep_color(L, packed, rb.pb, rb.pts, rb.pb.nrm, 4, s));
   CompArgs c = comp_args_of(L, a, rb);
   RNB_TRY(launch_composite_fwd(c, a->gradient_error, rb.gerr_den, a->gerr_partial, s));

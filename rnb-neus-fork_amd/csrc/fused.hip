@@ -350,7 +350,10 @@ int x3_pack_weights(const Layout& L, float* packed, hipStream_t s) {
   H2Tab* tab = is_x2h(L) ? h2_tab(L, packed) : nullptr;
   hipLaunchKernelGGL(x3_pack_kernel, dim3((unsigned)((t.total_units + 255) / 256)), dim3(256), 0, s, packed, t, dst, tab);
   RNB_CHECK_LAUNCH();
-  if (is_x2h(L)) {   // every matrix once more as two fp16 planes (same table: the scales come from the maxima just taken)
+  if (is_x2h(L)) {   // every matrix once more as two fp16 planes (the scales come from the maxima just taken)
+    // the fp16 planes of the albedo network's matrices are read by its fused kernels (color_h2.hip) through the same
+    // product loop as the SDF network's (X3Mma): same k order inside a step
+    for (int q = 0; q < t.n; ++q) t.e[q].tperm = 1;
     hipLaunchKernelGGL(x2h_pack_kernel, dim3((unsigned)((t.total_units + 255) / 256)), dim3(256), 0, s, packed, t,
                        x2h_mirror(L, packed), tab);
     RNB_CHECK_LAUNCH();

@@ -49,71 +49,6 @@ struct FusedBwdArgs {
   unsigned* smax;       // x2h R sweep of a render forward: PointBufs::smax (slots SMAX_GZ + l grown by the tile maxima), or nullptr
 };
 
-// AuxTile<TI, TJ>: one value per accumulator element of the wave's (32 TI) x (32 TJ) block
-template <int TI, int TJ = 2>
-struct AuxTile {
-  float v[TI][TJ][16];
-};
-
-// visits the wave's BT x 64 accumulator block: f(tj, ti, r, col, rowc, row) with rowc the lane-independent
-// part of the row (compile-time after unrolling) and row = rowc + 4*(lane>>5)
-template <int TI, int TJ = 2, class F>
-__device__ inline void for_each_acc(int n0, int lane, F f) {
-  const int h = lane >> 5, cl = lane & 31;
-#pragma unroll
-  for (int tj = 0; tj < TJ; ++tj) {
-    const int col = n0 + tj * 32 + cl;
-#pragma unroll
-    for (int ti = 0; ti < TI; ++ti) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int rowc = ti * 32 + (r & 3) + 8 * (r >> 2);
-        f(tj, ti, r, col, rowc, rowc + 4 * h);
-      }
-    }
-  }
-}
-
-// Same visit, split per 32-column tile into a branch-free body for tiles that lie entirely below `limit`
-// (wave-uniform test: n0 and limit are scalars) and a general body for the one tile that may straddle it.
-// On gfx950 the fp32 MFMA and ordinary vector instructions exclude each other on a SIMD (tools/overlap_probe),
-// so every per-element compare / exec-mask round trip in an epilogue is matrix time lost.
-template <int TI, int TJ = 2, class FF, class FS>
-__device__ inline void for_each_acc_split(int n0, int lane, int limit, FF fast, FS slow) {
-  const int h = lane >> 5, cl = lane & 31;
-#pragma unroll
-  for (int tj = 0; tj < TJ; ++tj) {
-    const int col = n0 + tj * 32 + cl;
-    if (n0 + tj * 32 + 32 <= limit) {
-#pragma unroll
-      for (int ti = 0; ti < TI; ++ti)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int rowc = ti * 32 + (r & 3) + 8 * (r >> 2);
-          fast(tj, ti, r, col, rowc, rowc + 4 * h);
-        }
-    } else {
-#pragma unroll
-      for (int ti = 0; ti < TI; ++ti)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int rowc = ti * 32 + (r & 3) + 8 * (r >> 2);
-          slow(tj, ti, r, col, rowc, rowc + 4 * h);
-        }
-    }
-  }
-}
-
-// issues the buffer loads of one [BT x 256] tile in accumulator layout (no wait: consumed after the MFMA loop)
-template <int TI, int TJ = 2>
-__device__ inline void prefetch_tile(const float* base, int64_t row0, int n0, int lane, AuxTile<TI, TJ>& t) {
-  const BufRsrc rs = tile_rsrc(base + (size_t)row0 * FH, 32 * TI * FH * 4);
-  const int h = lane >> 5;
-  for_each_acc<TI, TJ>(n0, lane, [&](int tj, int ti, int r, int col, int rowc, int row) {
-    t.v[ti][tj][r] = bload(rs, (unsigned)(4 * h * FH + col) * 4u, rowc * FH * 4);
-  });
-}
-
 // matrix loop of one layer (weights at float offset `off` of the packed buffer): two alternating weight-register
 // sets, except for 64-point tiles with 64-column waves, which use the one-set ring (register budget).  X3: the same
 // product as six bf16 MFMA terms per 16 k (fused_common.hip.h).
@@ -523,14 +458,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TI == 2) ? 1 : 2) void fused_f
 // within 2^-16 of its tile's maximum keeps the full two-plane precision.  The same maxima (real rows only), folded
 // over the tiles with one atomic per tile, are the scales of the weight-gradient jobs (PointBufs::amax).
 // ---------------------------------------------------------------------------------------------------------
-// maximum of the NW per-wave values of this layer -> (tile maximum, scale, 1 / scale)
-template <int NW>
-__device__ inline float tile_scale(const float* wm, float& s, float& inv_s) {
-  const float m = tile_max<NW>(wm);
-  x2h_dyn_scale(__builtin_bit_cast(unsigned, m), s, inv_s);
-  return m;
-}
-
 template <int NW>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_fb_h2_kernel(FusedBwdArgs g) {
   constexpr int TI = 2, BT = 64, NT = 64 * NW, TJ = 8 / NW;

@@ -59,6 +59,14 @@ __device__ inline float tile_max(const float* wm) {
   for (int w = 1; w < NW; ++w) m = fmaxf(m, wm[w]);
   return m;
 }
+// maximum of the NW per-wave values of a layer -> (tile maximum, the scale that puts it in [2^13, 2^14), 1 / scale): tiles of
+// loss adjoints, whose magnitude nothing bounds a priori, are always scaled from their own maximum
+template <int NW>
+__device__ inline float tile_scale(const float* wm, float& s, float& inv_s) {
+  const float m = tile_max<NW>(wm);
+  x2h_dyn_scale(__builtin_bit_cast(unsigned, m), s, inv_s);
+  return m;
+}
 // one atomic per tile, and only when the slot would grow
 __device__ inline void amax_tile_commit(unsigned* slot, float m) {
   const unsigned b = __builtin_bit_cast(unsigned, m);
@@ -321,6 +329,45 @@ struct X3Mma {
     __builtin_amdgcn_s_setprio(0);
     if (W3n) x3_load_b<TJ, NP>(W3n, Kn >> 4, n0n, 1, lane, b1);
   }
+  // The same product over a RANGE of k: weight steps ks0 .. ks0 + cnt of a matrix whose rows hold nks_tot steps, against the
+  // first 16 cnt columns of the tile at X (cnt even, >= 2).  ACC: the accumulators are added to instead of overwritten.
+  // The product that follows is named by (W3n, nksn_tot, ks0n, n0n).  Used by the albedo network's first layer, whose 320
+  // input columns pass through the 256-column tile in two parts.
+  __device__ inline void request_at(const x3raw* __restrict__ W3, int nks_tot, int ks0, int n0, int lane) {
+    x3_load_b<TJ, NP>(W3, nks_tot, n0, ks0, lane, b0);
+    x3_load_b<TJ, NP>(W3, nks_tot, n0, ks0 + 1, lane, b1);
+  }
+  template <bool ACC, class Hook = NoHook>
+  __device__ inline void run_at(const float* __restrict__ X, const x3raw* __restrict__ W3, int nks_tot, int ks0, int cnt, int n0,
+                                int lane, v16f (&acc)[TI][TJ], const x3raw* __restrict__ W3n, int nksn_tot, int ks0n, int n0n,
+                                Hook hook = Hook()) {
+    const int i = lane & 31, h = lane >> 5;
+    const float* xp = X + i * FP + h * 4;
+    vu4x a0[TI][NP], a1[TI][NP];
+    vf4 raw[TI][2];
+    x3_read_a<TI>(xp, 0, raw);
+    x3_split<TI, NP>(raw, a0);
+    x3_read_a<TI>(xp, 1, raw);
+    __builtin_amdgcn_sched_barrier(0);
+    const int last = cnt - 1;
+    __builtin_amdgcn_s_setprio(1);
+    x3_stage<TI, TJ, !ACC, NP>(xp, min(2, last), raw, a0, a1, b0, acc);
+    hook();
+    for (int ks = 1; ks + 1 < cnt; ks += 2) {
+      x3_load_b<TJ, NP>(W3, nks_tot, n0, ks0 + ks + 1, lane, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      x3_stage<TI, TJ, false, NP>(xp, ks + 2, raw, a1, a0, b1, acc);
+      x3_load_b<TJ, NP>(W3, nks_tot, n0, ks0 + ks + 2, lane, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      x3_stage<TI, TJ, false, NP>(xp, min(ks + 3, last), raw, a0, a1, b0, acc);
+    }
+    if (W3n) x3_load_b<TJ, NP>(W3n, nksn_tot, n0n, ks0n, lane, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    x3_mfma<TI, TJ, false, NP>(a1, b1, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(0);
+    if (W3n) x3_load_b<TJ, NP>(W3n, nksn_tot, n0n, ks0n + 1, lane, b1);
+  }
 };
 template <int TI, int TJ = 2, class Hook = NoHook>
 __device__ inline void layer_mma_x3(const float* __restrict__ X, const x3raw* __restrict__ W3, int K, int n0, int lane,
@@ -328,6 +375,71 @@ __device__ inline void layer_mma_x3(const float* __restrict__ X, const x3raw* __
   X3Mma<TI, TJ> m;
   m.request(W3, K, n0, lane);
   m.run(X, W3, K, n0, lane, acc, nullptr, 0, 0, hook);
+}
+
+// AuxTile<TI, TJ>: one value per accumulator element of the wave's (32 TI) x (32 TJ) block
+template <int TI, int TJ = 2>
+struct AuxTile {
+  float v[TI][TJ][16];
+};
+
+// visits the wave's BT x 64 accumulator block: f(tj, ti, r, col, rowc, row) with rowc the lane-independent
+// part of the row (compile-time after unrolling) and row = rowc + 4*(lane>>5)
+template <int TI, int TJ = 2, class F>
+__device__ inline void for_each_acc(int n0, int lane, F f) {
+  const int h = lane >> 5, cl = lane & 31;
+#pragma unroll
+  for (int tj = 0; tj < TJ; ++tj) {
+    const int col = n0 + tj * 32 + cl;
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rowc = ti * 32 + (r & 3) + 8 * (r >> 2);
+        f(tj, ti, r, col, rowc, rowc + 4 * h);
+      }
+    }
+  }
+}
+
+// Same visit, split per 32-column tile into a branch-free body for tiles that lie entirely below `limit`
+// (wave-uniform test: n0 and limit are scalars) and a general body for the one tile that may straddle it.
+// On gfx950 the fp32 MFMA and ordinary vector instructions exclude each other on a SIMD (tools/overlap_probe),
+// so every per-element compare / exec-mask round trip in an epilogue is matrix time lost.
+template <int TI, int TJ = 2, class FF, class FS>
+__device__ inline void for_each_acc_split(int n0, int lane, int limit, FF fast, FS slow) {
+  const int h = lane >> 5, cl = lane & 31;
+#pragma unroll
+  for (int tj = 0; tj < TJ; ++tj) {
+    const int col = n0 + tj * 32 + cl;
+    if (n0 + tj * 32 + 32 <= limit) {
+#pragma unroll
+      for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rowc = ti * 32 + (r & 3) + 8 * (r >> 2);
+          fast(tj, ti, r, col, rowc, rowc + 4 * h);
+        }
+    } else {
+#pragma unroll
+      for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rowc = ti * 32 + (r & 3) + 8 * (r >> 2);
+          slow(tj, ti, r, col, rowc, rowc + 4 * h);
+        }
+    }
+  }
+}
+
+// issues the buffer loads of one [BT x 256] tile in accumulator layout (no wait: consumed after the MFMA loop)
+template <int TI, int TJ = 2>
+__device__ inline void prefetch_tile(const float* base, int64_t row0, int n0, int lane, AuxTile<TI, TJ>& t) {
+  const BufRsrc rs = tile_rsrc(base + (size_t)row0 * FH, 32 * TI * FH * 4);
+  const int h = lane >> 5;
+  for_each_acc<TI, TJ>(n0, lane, [&](int tj, int ti, int r, int col, int rowc, int row) {
+    t.v[ti][tj][r] = bload(rs, (unsigned)(4 * h * FH + col) * 4u, rowc * FH * 4);
+  });
 }
 
 template <int TI>

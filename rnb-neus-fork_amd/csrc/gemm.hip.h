@@ -486,8 +486,9 @@ struct DwJob {
   int npairs, N, K, lddw, bias_pair, splits, rows_per_split, block_end;
 };
 constexpr int kMaxDwJobs = 12;
+constexpr int kMaxDwExtra = 2;   // reduce-only jobs (slabs written by other kernels) that ride in the reduction launch
 struct DwGroup {
-  DwJob job[kMaxDwJobs];
+  DwJob job[kMaxDwJobs + kMaxDwExtra];
   int njobs, M;
 };
 
@@ -716,6 +717,40 @@ __global__ __launch_bounds__(256) void dw_reduce_kernel(const DwGroup g) {
   // slabs [split][N][K] (K == lddw for whole-matrix jobs; a column range of a wider matrix has K < lddw)
   const size_t n = (size_t)J.N * J.K;
   const bool dense = J.K == J.lddw;
+  if (J.splits > 64) {
+    // many small slabs (the per-tile column sums of the fused albedo backward: a thousand slabs of a few hundred elements):
+    // 16 elements x 16 split phases per workgroup pass, each thread a fixed subsequence of the slabs, the 16 phases summed in
+    // phase order — as reproducible as one chain, 256 loads in flight per workgroup instead of one per element.  The bias
+    // slabs ride as elements n .. n + N.
+    __shared__ double red[16][17];
+    const size_t ntot = n + ((J.db != nullptr && J.partb != nullptr) ? (size_t)J.N : 0);
+    const int e = threadIdx.x & 15, ph = threadIdx.x >> 4;
+    for (size_t base = (size_t)blockIdx.x * 16; base < ntot; base += (size_t)gridDim.x * 16) {   // (uniform per workgroup)
+      const size_t idx = base + e;
+      double s[4] = {0.0, 0.0, 0.0, 0.0};
+      if (idx < ntot) {
+        const float* src = idx < n ? J.part + idx : J.partb + (idx - n);
+        const size_t stride = idx < n ? n : (size_t)J.N;
+        int sp = ph;
+        for (; sp + 48 < J.splits; sp += 64) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) s[u] += (double)src[(size_t)(sp + 16 * u) * stride];
+        }
+        for (int u = 0; sp < J.splits; sp += 16, ++u) s[u] += (double)src[(size_t)sp * stride];
+      }
+      red[ph][e] = (s[0] + s[1]) + (s[2] + s[3]);
+      __syncthreads();
+      if (threadIdx.x < 16 && base + threadIdx.x < ntot) {
+        const size_t i2 = base + threadIdx.x;
+        double t = 0.0;
+        for (int q = 0; q < 16; ++q) t += red[q][threadIdx.x];
+        if (i2 < n) J.dW[dense ? i2 : (i2 / (size_t)J.K) * (size_t)J.lddw + i2 % (size_t)J.K] = (float)t;
+        else J.db[i2 - n] = (float)t;
+      }
+      __syncthreads();
+    }
+    return;
+  }
   for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (size_t)gridDim.x * 256) {
     // four interleaved running sums (splits 0, 4, 8 .. / 1, 5, .. / ..) combined in a fixed order: as reproducible as one
     // chain, but four loads in flight instead of one
@@ -1015,17 +1050,12 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_x3_kernel(const float* __res
 // (x3_pack_weights; one contiguous 1 KB per load, as in the fused sweeps), two steps ahead in registers.  One 8-wave
 // workgroup per 128 rows; wave w owns ALL 128 rows x the column tiles w and (TJ == 2) w + 8 — every weight fragment is
 // fetched once per workgroup, every activation split once.  N <= 32 * 8 * TJ, N % 32 == 0, K % 32 == 0.
-// NP = 2: the fp16 three-term form (x2h; forward layers: the inputs are activations of known range): W3 is then the
-// fp16 mirror (weights times kH2WScale), the rows are scaled by kH2ActScale as they are staged and the accumulators
-// rescaled before the epilogue.
 // amax != nullptr: max |acc| over the rows below m_real is left there (an upper bound of the epilogue's masked outputs)
-template <int TJ, class Epi, int NP = 3>
+template <int TJ, class Epi>
 __global__ __launch_bounds__(512, 1) void gemm_rows_x3m_kernel(const float* __restrict__ A, int lda,
                                                                const x3raw* __restrict__ W3, int N, int K, Epi epi,
-                                                               unsigned* amax = nullptr, long long m_real = 0,
-                                                               const unsigned* in_amax = nullptr,
-                                                               const float* w_iscale = nullptr) {
-  // w_iscale (NP == 2): 1 / the scale this matrix carries in the fp16 mirror (H2Tab::iws of its id)
+                                                               unsigned* amax = nullptr, long long m_real = 0) {
+  constexpr int NP = 3;   // (an fp16 two-plane form of this kernel existed in round 4; the fused albedo kernels replaced it)
   constexpr int ROWS = 128;
   constexpr int PLB = ROWS * XP;              // bytes of one plane
   constexpr int BUFB = NP * PLB;              // one staging buffer (three planes: 18,432 B)
@@ -1060,27 +1090,13 @@ __global__ __launch_bounds__(512, 1) void gemm_rows_x3m_kernel(const float* __re
   auto load_a = [&](int ks) {
     return __builtin_bit_cast(vf4, __builtin_amdgcn_raw_buffer_load_b128(rsA, aoff, (unsigned)ks * 64u, RNB_AUX_LD));
   };
-  // NP == 2: scale of the rows: fixed for forward activations; for a loss adjoint (backward layers) from the maximum its
-  // producer recorded (in_amax), like the weight-gradient jobs
-  [[maybe_unused]] float sa = kH2ActScale, isa = 1.f / kH2ActScale;
-  if constexpr (NP == 2) {
-    if (in_amax != nullptr) x2h_dyn_scale(*in_amax, sa, isa);
-    isa *= w_iscale != nullptr ? *w_iscale : 1.f / kH2WScale;   // (from here on: accumulator -> product)
-  }
   auto stage = [&](const vf4& x, int buf) {
     char* w = swr + buf * BUFB;
-    if constexpr (NP == 3) {
-      vu2x hi, mid, lo;
-      x3_split4(x, hi, mid, lo);
-      *reinterpret_cast<vu2x*>(w) = hi;
-      *reinterpret_cast<vu2x*>(w + PLB) = mid;
-      *reinterpret_cast<vu2x*>(w + 2 * PLB) = lo;
-    } else {
-      vu2x hi, lo;
-      x2h_split4(x * sa, hi, lo);
-      *reinterpret_cast<vu2x*>(w) = hi;
-      *reinterpret_cast<vu2x*>(w + PLB) = lo;
-    }
+    vu2x hi, mid, lo;
+    x3_split4(x, hi, mid, lo);
+    *reinterpret_cast<vu2x*>(w) = hi;
+    *reinterpret_cast<vu2x*>(w + PLB) = mid;
+    *reinterpret_cast<vu2x*>(w + 2 * PLB) = lo;
   };
   v16f acc[4][TJ];
 #pragma unroll
@@ -1106,23 +1122,17 @@ __global__ __launch_bounds__(512, 1) void gemm_rows_x3m_kernel(const float* __re
     for (int ti = 0; ti < 4; ++ti)
 #pragma unroll
       for (int pl = 0; pl < NP; ++pl) a[ti][pl] = *reinterpret_cast<const vu4x*>(f + pl * PLB + ti * 32 * XP);
-    constexpr int NT = NP == 3 ? 6 : 3;
-    constexpr int PA[6] = {NP == 3 ? 2 : 1, 0, NP == 3 ? 1 : 0, 1, 0, 0};   // small terms first (x3_mfma)
-    constexpr int PB[6] = {0, NP == 3 ? 2 : 1, NP == 3 ? 1 : 0, 0, 1, 0};
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0};   // small terms first (x3_mfma)
+    constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
     for (int tj = 0; tj < TJ; ++tj) {
       if (TJ == 2 && tj == 1 && !on[1]) continue;   // (wave-uniform)
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
+      for (int t = 0; t < 6; ++t)
 #pragma unroll
-        for (int ti = 0; ti < 4; ++ti) {
-          if constexpr (NP == 3)
-            acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(x3bf8, a[ti][PA[t]]),
-                                                                  __builtin_bit_cast(x3bf8, b[tj][PB[t]]), acc[ti][tj], 0, 0, 0);
-          else
-            acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(x2h8, a[ti][PA[t]]),
-                                                                 __builtin_bit_cast(x2h8, b[tj][PB[t]]), acc[ti][tj], 0, 0, 0);
-        }
+        for (int ti = 0; ti < 4; ++ti)
+          acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(x3bf8, a[ti][PA[t]]),
+                                                                __builtin_bit_cast(x3bf8, b[tj][PB[t]]), acc[ti][tj], 0, 0, 0);
     }
     load_b(min(ks + 2, nks - 1), b);
   };
@@ -1143,7 +1153,6 @@ __global__ __launch_bounds__(512, 1) void gemm_rows_x3m_kernel(const float* __re
       for (int ti = 0; ti < 4; ++ti) t[ti][0] = acc[ti][tj];
       m = fmaxf(m, acc_absmax<4, 1>(t, lane, left >= ROWS ? ROWS : (int)(left < 0 ? 0 : left)));
     }
-    if constexpr (NP == 2) m *= isa;   // (the accumulators are still scaled)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     if (lane == 0) wmx[wave] = m;
@@ -1160,7 +1169,7 @@ __global__ __launch_bounds__(512, 1) void gemm_rows_x3m_kernel(const float* __re
     if (!on[tj]) continue;
     v16f t[4][1];
 #pragma unroll
-    for (int ti = 0; ti < 4; ++ti) t[ti][0] = NP == 3 ? acc[ti][tj] : acc[ti][tj] * isa;
+    for (int ti = 0; ti < 4; ++ti) t[ti][0] = acc[ti][tj];
     run_epilogue<1, Epi, 4>(t, strip, m_blk, nt[tj] * 32, lane, 1u, epi);
   }
 }

@@ -193,6 +193,8 @@ void carve_points(const Layout& L, Carver& c, int64_t M, int mode, PointBufs* pb
       if (L.variant & RNB_VARIANT_DETERMINISTIC)
         pb->dw_part_floats += dw_partial_floats(L, M, wc) + (bf ? bf16_dw_partial_floats(L, M, wc) : 0);
       pb->dw_part = c.take<float>(pb->dw_part_floats > 0 ? pb->dw_part_floats : 64);
+      if (wc && color_h2_supported(L)) pb->col_part = c.take<float>(color_h2_part_floats(L, M));
+      pb->sdfh_part = c.take<float>((int64_t)kSdfHeadSlabs * (L.Hp + 1));
     }
   }
 }

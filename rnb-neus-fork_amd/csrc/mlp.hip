@@ -364,7 +364,10 @@ __global__ __launch_bounds__(512) void sdf_head_bwd_kernel(const float* __restri
                                                            const float* __restrict__ ucol, int ntiles,
                                                            int Hp, int H, const float* __restrict__ sbar,
                                                            float inv_scale, int64_t M, int rows_per_blk,
-                                                           float* __restrict__ dwsdf, float* __restrict__ dbsdf) {
+                                                           float* __restrict__ dwsdf, float* __restrict__ dbsdf,
+                                                           float* __restrict__ part_w, float* __restrict__ part_b) {
+  // part_w != nullptr: this row slab's sums go to part_w[slab][Hp] / part_b[slab] with plain stores (summed in slab order by
+  // dw_reduce_kernel: bit-reproducible) instead of into dwsdf / dbsdf through fp32 atomics
   __shared__ double red[64][33];
   __shared__ double redb[64];
   const int tid = threadIdx.x, cg = tid & 7, ph = tid >> 3;
@@ -400,11 +403,14 @@ __global__ __launch_bounds__(512) void sdf_head_bwd_kernel(const float* __restri
   if (tid < 32) {
     double t = 0.0;
     for (int q = 0; q < 64; ++q) t += red[q][tid];
-    if (blockIdx.y * 32 + tid < H) atomicAdd(dwsdf + blockIdx.y * 32 + tid, (float)t);
+    const int col = blockIdx.y * 32 + tid;
+    if (part_w != nullptr) part_w[(size_t)blockIdx.x * Hp + col] = col < H ? (float)t : 0.f;
+    else if (col < H) atomicAdd(dwsdf + col, (float)t);
   } else if (tid == 32 && blockIdx.y == 0) {
     double t = 0.0;
     for (int q = 0; q < 64; ++q) t += redb[q];
-    atomicAdd(dbsdf, (float)t);
+    if (part_b != nullptr) part_b[blockIdx.x] = (float)t;
+    else atomicAdd(dbsdf, (float)t);
   }
 }
 
@@ -646,19 +652,10 @@ static inline double mm_flops(int64_t M, const Lin& ln) { return 2.0 * (double)M
 // x3: the product as six bf16 MFMA terms (RNB_VARIANT_X3; k-contiguous weights, N >= 256, K % 16 == 0)
 template <bool B_KMAJOR, class Epi>
 static int launch_rows(const float* A, int lda, const float* W, int ldw, int64_t Mp, int N, int K, const Epi& epi,
-                       double flops, hipStream_t s, bool x3 = false, const x3raw* W3 = nullptr, const x3raw* Wh2 = nullptr,
-                       unsigned* amax = nullptr, int64_t m_real = 0, const unsigned* in_amax = nullptr,
-                       const float* w_iscale = nullptr) {
-  ProfScope prof(flops, s, (Wh2 && !in_amax) ? "layer_gemm(forward)" : "layer_gemm");
+                       double flops, hipStream_t s, bool x3 = false, const x3raw* W3 = nullptr, unsigned* amax = nullptr,
+                       int64_t m_real = 0, const char* tag = "layer_gemm") {
+  ProfScope prof(flops, s, tag);
   if constexpr (!B_KMAJOR) {
-    // Wh2: this matrix in the fp16 mirror (x2h; forward layers only)
-    if (x3 && Wh2 != nullptr && N % 32 == 0 && N <= 512 && K % 32 == 0 && Mp % 128 == 0) {
-      if (w_iscale == nullptr) RNB_FAIL(RNB_E_INVALID, "x2h layer GEMM without the matrix's scale");
-      if (N <= 256) hipLaunchKernelGGL((gemm_rows_x3m_kernel<1, Epi, 2>), dim3((unsigned)(Mp / 128)), dim3(512), 0, s, A, lda, Wh2, N, K, epi, amax, (long long)m_real, in_amax, w_iscale);
-      else hipLaunchKernelGGL((gemm_rows_x3m_kernel<2, Epi, 2>), dim3((unsigned)(Mp / 128)), dim3(512), 0, s, A, lda, Wh2, N, K, epi, amax, (long long)m_real, in_amax, w_iscale);
-      RNB_CHECK_LAUNCH();
-      return RNB_OK;
-    }
     // W3: this matrix in the split mirror (x3_pack_weights): the weights are then read as ready-made fragments
     if (x3 && W3 != nullptr && N % 32 == 0 && N <= 512 && K % 32 == 0 && Mp % 128 == 0) {
       if (N <= 256) hipLaunchKernelGGL((gemm_rows_x3m_kernel<1, Epi>), dim3((unsigned)(Mp / 128)), dim3(512), 0, s, A, lda, W3, N, K, epi, amax, (long long)m_real);
@@ -763,15 +760,27 @@ struct DwBatch {
   int64_t slab_left;
   float* const slab_base;         // the slab workspace as handed in: every flushed group starts from it again
   const int64_t slab_floats;
+  // reduce-only jobs: slabs that OTHER kernels wrote (per-tile column sums of the fused albedo backward, per-slab sums of the
+  // sdf-head row): summed by the reduction launch that follows the last group of weight-gradient jobs, no launch of their own
+  DwJob extra[kMaxDwExtra];
+  int nextra = 0;
+  int add_reduce_only(float* dW, int lddw, float* db, float* part, float* partb, int N, int K, int splits) {
+    if (nextra == kMaxDwExtra) RNB_FAIL(RNB_E_INVALID, "too many reduce-only jobs");
+    DwJob& j = extra[nextra++];
+    memset(&j, 0, sizeof(j));
+    j.dW = dW; j.db = db; j.part = part; j.partb = partb;
+    j.N = N; j.K = K; j.lddw = lddw; j.splits = splits;
+    return RNB_OK;
+  }
   DwBatch(int64_t M_, hipStream_t s_, bool lds_path_, float* part_, int64_t part_floats, float* slab_, int64_t slab_floats_)
       : M(M_), s(s_), lds_path(lds_path_), part(part_), part_left(part_floats), slab(slab_), slab_left(slab_floats_),
         slab_base(slab_), slab_floats(slab_floats_) {
     for (int v = 0; v < 4; ++v) { grp[v].njobs = 0; grp[v].M = (int)M_; flops[v] = 0.0; }
   }
   // the staged kernel: every job of the group is split the same way, decided when the group is complete
-  int flush_staged() {
+  int flush_staged(bool final = false) {
     DwGroup& g = grp[3];
-    if (g.njobs == 0) return RNB_OK;
+    if (g.njobs == 0 && !(final && nextra > 0)) return RNB_OK;
     int total_pairs = 0;   // (work units: x3_job_units)
     for (int q = 0; q < g.njobs; ++q) total_pairs += x3_job_units(g.job[q].npairs, g.job[q].K);
     for (int a = 0, b = g.njobs - 1; a < b; ++a, --b) {   // most recently produced operands first (see flush)
@@ -807,16 +816,25 @@ struct DwBatch {
       slab += need;
       slab_left -= need;
     }
-    {   // (two scopes: the class time of the weight-gradient kernel is then its own launch duration, as a kernel trace shows it)
+    if (end > 0) {   // (two scopes: the class time of the weight-gradient kernel is then its own launch duration, as a kernel trace shows it)
       ProfScope prof(flops[3], s, "dW(x3: 256x256 + narrow jobs)");
       if (x3 && h2) hipLaunchKernelGGL((gemm_dw_x3_kernel<0, 2>), dim3((unsigned)end), dim3(512), 0, s, g);
       else if (x3) hipLaunchKernelGGL((gemm_dw_x3_kernel<0, 3>), dim3((unsigned)end), dim3(512), 0, s, g);
       else hipLaunchKernelGGL(gemm_dw_staged_kernel<0>, dim3((unsigned)end), dim3(1024), 0, s, g);
     }
     RNB_CHECK_LAUNCH();
+    int nred = g.njobs;
+    if (final) {   // the reduce-only jobs ride behind the real ones (no blocks of the kernel above: block_end stays `end`)
+      for (int q = 0; q < nextra; ++q) {
+        g.job[nred] = extra[q];
+        g.job[nred].block_end = end;
+        ++nred;
+      }
+      nextra = 0;
+    }
     {
       ProfScope prof(0.0, s, "dW(slab reduce)");
-      hipLaunchKernelGGL(dw_reduce_kernel<0>, dim3(256, g.njobs), dim3(256), 0, s, g);
+      hipLaunchKernelGGL(dw_reduce_kernel<0>, dim3(256, nred), dim3(256), 0, s, g);
     }
     g.njobs = 0;
     flops[3] = 0.0;
@@ -916,7 +934,7 @@ struct DwBatch {
   }
   int flush_all() {
     RNB_TRY(flush(1));   // holds the first layer's job: its operands are the most recent
-    RNB_TRY(flush_staged());
+    RNB_TRY(flush_staged(true));
     RNB_TRY(flush(0));
     return flush(2);
   }
@@ -1071,7 +1089,7 @@ int sweep_color(const Layout& L, const float* packed, PointBufs& pb, const float
     EpiRelu epi{packed + ln.b_off, pb.ac[l], L.Hcp, ln.N};
     // (per-layer path of an albedo net the fused kernels do not cover: six bf16 terms — no operand range to look after)
     RNB_TRY((launch_rows<false, EpiRelu>(in, lda, packed + ln.w_off, ln.Kp, pb.Mp, ln.Np, ln.Kp, epi, mm_flops(pb.M, ln), s, is_x3(L),
-                                         x3_mirror(L, packed, ln.w_off), nullptr)));
+                                         x3_mirror(L, packed, ln.w_off), nullptr, 0, "layer_gemm(forward)")));
     // x2h weight gradients take this layer's input / output as a state operand: its maximum (PointBufs::smax)
     if (is_x2h(L) && pb.smax != nullptr) {
       if (l == 0) RNB_TRY(launch_absmax(pb.cin, pb.Mp * L.Cinp, pb.smax + SMAX_CIN, s));
@@ -1104,9 +1122,24 @@ int sweep_backward(const Layout& L, const float* packed, PointBufs& pb, bool wit
   dw.h2 = h2;
   if (h2) RNB_CHECK_HIP(hipMemsetAsync(pb.amax, 0, AMAX_SLOTS * sizeof(unsigned), s));
   const bool color_bf16 = is_bf16(L) && with_color && bf16_color_supported(L) && pb.cin8 != nullptr;
+  // the albedo network's backward as ONE fused sweep (color_h2.hip), which also forms geb = J_pe(x) nbar_total
+  const bool color_h2 = with_color && h2 && color_h2_supported(L) && pb.col_part != nullptr;
   // ---- C': albedo network backward ---------------------------------------------------------------
   if (color_bf16) {
     RNB_TRY(bf16_color_backward(L, packed, pb, packed_grad, s));
+  } else if (color_h2) {
+    RNB_TRY(color_h2_backward(L, packed, pb, s));
+    for (int l = L.nc - 1; l >= 0; --l) {
+      const Lin& ln = L.col[l];
+      const float* in = l == 0 ? pb.cin : pb.ac[l - 1];
+      const int ldin = l == 0 ? L.Cinp : L.Hcp;
+      DwPair p{pb.zc[l], L.Hcp, in, ldin, 0, pb.amax + AMAX_ZC + l, pb.smax + (l == 0 ? SMAX_CIN : SMAX_AC + l - 1)};
+      RNB_TRY(dw.add(p, p, 1, ln.Np, ln.Kp, packed_grad + ln.w_off, ln.Kp, packed_grad + ln.b_off, 0, mm_flops(M, ln)));
+    }
+    // the output layer's gradient: per-tile column sums, summed in tile order by the reduction launch of the weight gradients
+    const int64_t tiles = Mp / 64;
+    RNB_TRY(dw.add_reduce_only(packed_grad + L.colo.w_off, L.colo.Kp, packed_grad + L.colo.b_off, pb.col_part,
+                               pb.col_part + tiles * L.Co * L.Hcp, L.Co, L.Hcp, (int)tiles));
   } else if (with_color) {
     const int chunks = L.Hcp / 32;   // 32-column chunks x row slabs, ~256 workgroups, slabs a multiple of 64 rows
     int64_t slabs = det ? 1 : (256 + chunks - 1) / chunks;   // deterministic: ONE slab, i.e. one add per address onto zero
@@ -1127,21 +1160,18 @@ int sweep_backward(const Layout& L, const float* packed, PointBufs& pb, bool wit
       if (l > 0) {
         EpiReluMask epi{pb.ac[l - 1], pb.zc[l - 1], L.Hcp, L.col[l - 1].N};
         // zc_{l-1} = (zc_l W_l) * relu': k-contiguous product against the transposed copy W_l^T [Kp x Np]
+        // (per-layer path: six bf16 terms; the kernel leaves max |acc| for the x2h weight-gradient job of zc_{l-1})
         RNB_TRY((launch_rows<false, EpiReluMask>(pb.zc[l], L.Hcp, packed + ln.wT_off, ln.Np, Mp, ln.Kp, ln.Np, epi, mm_flops(M, ln), s, is_x3(L),
-                                                 x3_mirror(L, packed, ln.wT_off), h2 ? x2h_mirror(L, packed) + 2 * ln.wT_off : nullptr,
-                                                 h2 ? pb.amax + AMAX_ZC + (l - 1) : nullptr, M, h2 ? pb.amax + AMAX_ZC + l : nullptr,
-                                                 h2 ? &h2_tab(L, packed)->iws[L.nh + 1 + l] : nullptr)));
+                                                 x3_mirror(L, packed, ln.wT_off), h2 ? pb.amax + AMAX_ZC + (l - 1) : nullptr, M)));
       } else {
         EpiStore epi{pb.cinb, L.Cinp};
         RNB_TRY((launch_rows<false, EpiStore>(pb.zc[0], L.Hcp, packed + ln.wT_off, ln.Np, Mp, ln.Kp, ln.Np, epi, mm_flops(M, ln), s, is_x3(L),
-                                              x3_mirror(L, packed, ln.wT_off), h2 ? x2h_mirror(L, packed) + 2 * ln.wT_off : nullptr,
-                                              h2 ? pb.amax + AMAX_CINB : nullptr, M, h2 ? pb.amax + AMAX_ZC + 0 : nullptr,
-                                              h2 ? &h2_tab(L, packed)->iws[L.nh + 1] : nullptr)));
+                                              x3_mirror(L, packed, ln.wT_off), h2 ? pb.amax + AMAX_CINB : nullptr, M)));
       }
     }
   }
   // ---- nbar (+ albedo-net contribution) -> geb = u_0 -----------------------------------------------
-  {
+  if (!color_h2) {
     const int wt = (with_color && L.Cinp - L.F > L.Ep) ? L.Cinp - L.F : L.Ep;
     hipLaunchKernelGGL(nbar_geb_kernel, dim3(blocks_for(Mp, 64)), dim3(64), (size_t)64 * (wt + 1) * sizeof(float), s,
                        pb.x, pb.nrm, pb.nbar, pb.cinb, L.Cinp, L.F, L.F + L.pev, L.multires_view, with_color ? 1 : 0,
@@ -1174,11 +1204,24 @@ int sweep_backward(const Layout& L, const float* packed, PointBufs& pb, bool wit
     int64_t slabs = det ? 1 : (256 + chunks - 1) / chunks;
     int rows_per_blk = (int)((M + slabs - 1) / slabs);
     rows_per_blk = (rows_per_blk + 63) / 64 * 64;
-    hipLaunchKernelGGL(sdf_head_bwd_kernel, dim3(blocks_for(M, rows_per_blk), chunks), dim3(512), 0, s, pb.a[L.nh - 1],
+    // with the one-workgroup-per-gradient kernels (x3 / staged) there is a slab reduction at the end of the backward: the row
+    // slabs' sums ride in it (no atomics: bit-reproducible); otherwise fp32 atomics (one slab in the deterministic variant)
+    const bool slab_out = !dw.no_staged && !dw.lds_path && pb.sdfh_part != nullptr && M % kStChunk == 0;
+    if (slab_out) {
+      slabs = kSdfHeadSlabs;
+      rows_per_blk = (int)((M + slabs - 1) / slabs);
+      rows_per_blk = (rows_per_blk + 63) / 64 * 64;
+    }
+    const unsigned nslab = blocks_for(M, rows_per_blk);
+    float* part_w = slab_out ? pb.sdfh_part : nullptr;
+    float* part_b = slab_out ? pb.sdfh_part + (size_t)nslab * L.Hp : nullptr;
+    hipLaunchKernelGGL(sdf_head_bwd_kernel, dim3(nslab, chunks), dim3(512), 0, s, pb.a[L.nh - 1],
                        fused ? (const float*)nullptr : (const float*)pb.u[L.nh], (const float*)pb.u[L.nh], u_tiles, L.Hp,
                        L.H, pb.sbar, 1.f / L.sdf_scale, M, rows_per_blk,
-                       packed_grad + L.wsdf_off, packed_grad + L.bsdf_off);
+                       packed_grad + L.wsdf_off, packed_grad + L.bsdf_off, part_w, part_b);
     RNB_CHECK_LAUNCH();
+    if (slab_out)
+      RNB_TRY(dw.add_reduce_only(packed_grad + L.wsdf_off, L.Hp, packed_grad + L.bsdf_off, part_w, part_b, 1, L.Hp, (int)nslab));
   }
   // ---- FB head: zb_{nh-1} = (fbar Wf + sbar/scale w_sdf) * D + zR ----------------------------------
   if (fused) RNB_TRY(fused_fb(L, packed, pb, with_color, s));   // all zb_l in one launch

@@ -171,6 +171,8 @@ struct PointBufs {
                             // (float bits; zeroed by the first kernel of a render forward, grown by the forward sweeps)
   float* dw_part;           // partial slabs of the split-K weight-gradient GEMMs: [deterministic variant | staged kernel]
   int64_t dw_part_floats;
+  float* col_part;          // fused albedo backward: per-tile column sums of the output layer's gradient [tiles][Co][256] + [tiles][Co]
+  float* sdfh_part;         // sdf-head row gradient: per-slab column sums [kSdfHeadSlabs][Hp] + [kSdfHeadSlabs]
 };
 
 // slots of PointBufs::amax: zb_l, u_l (u_0 = geb), zc_l, cinb
@@ -234,6 +236,13 @@ inline H2Tab* h2_tab(const Layout& L, float* packed) {
   return L.h2tab_off >= 0 ? reinterpret_cast<H2Tab*>(packed + L.h2tab_off) : nullptr;
 }
 int x3_pack_weights(const Layout& L, float* packed, hipStream_t s);
+
+// ---- the albedo network as two fused sweeps in the x2h arithmetic (color_h2.hip) ----
+bool color_h2_supported(const Layout& L);
+int color_h2_forward(const Layout& L, const float* packed, PointBufs& pb, const float* pts, const float* nrm, hipStream_t s);
+int color_h2_backward(const Layout& L, const float* packed, PointBufs& pb, hipStream_t s);
+int64_t color_h2_part_floats(const Layout& L, int64_t M);
+constexpr int kSdfHeadSlabs = 32;   // row slabs of sdf_head_bwd_kernel's partial sums (summed in slab order: no atomics)
 
 // ---- RNB_VARIANT_BF16 (bf16.hip): bf16-operand sweeps of the 256-wide network, saved state in bf16 "K8" layout ----
 inline bool is_bf16(const Layout& L) { return (L.variant & RNB_VARIANT_BF16) != 0; }
