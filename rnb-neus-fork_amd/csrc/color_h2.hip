@@ -60,7 +60,7 @@ __device__ inline float col_fwd_epilogue(const v16f (&acc)[2][2], float inv, con
                                          float* __restrict__ out, int64_t row0, int n0, int lane) {
   const int h = lane >> 5, cl = lane & 31;
   const BufRsrc ro = tile_rsrc(out + (size_t)row0 * FH, CT * FH * 4);
-  float am = 0.f;
+  unsigned amb = 0u;   // (relu outputs are >= +0: their maximum on the bit patterns, h2_track2)
 #pragma unroll
   for (int tj = 0; tj < 2; ++tj) {
     const int col = n0 + tj * 32 + cl;
@@ -76,22 +76,28 @@ __device__ inline float col_fwd_epilogue(const v16f (&acc)[2][2], float inv, con
         const float a1 = relu_keep_nan(__builtin_fmaf(acc[ti][tj][r + 1], inv, bc));
         X[row * FP + col] = a0 * kH2ActScale;
         X[(row + 1) * FP + col] = a1 * kH2ActScale;
-        am = fmaxf(am, fmaxf(a0, a1));   // (>= 0: no abs; a NaN stays out of the maximum and in the tile)
+        h2_track2(amb, a0, a1);
         bstore(ro, voff, rowc * FH * 4, a0);
         bstore(ro, voff, (rowc + 1) * FH * 4, a1);
       }
   }
-  return am;
+  return __builtin_bit_cast(float, amb);
 }
 
-// after a layer's closing barrier: the tile's scale for the next product from the waves' maxima (see kH2ActLimit)
-__device__ inline void col_tile_rescale(const float* wm, float* X, int n0, int lane, unsigned* smax_slot, int tid, float& sa,
-                                        float& isa) {
-  const float tm = tile_max<4>(wm);
-  if (smax_slot != nullptr && tid == 0) amax_tile_commit(smax_slot, tm);
+// after a layer's closing barrier: the tile's scale for the next product.  Common case: the flag is down, the tile keeps
+// kH2ActScale.  Flag up (some value reached kH2ActLimit): the waves exchange their maxima, rescale what they wrote and leave
+// the tile's maximum in PointBufs::smax (fused_common.hip.h).
+__device__ inline void col_tile_rescale(int* flag, float am, float* wmx, float* X, int n0, int lane, int wave, unsigned* smax_slot,
+                                        int tid, float& sa, float& isa) {
   sa = kH2ActScale;
   isa = 1.f / kH2ActScale;
-  if (tm >= kH2ActLimit) {   // (workgroup-uniform)
+  if (h2_flag_up(flag)) {   // (workgroup-uniform)
+    am = wave_max(am);
+    if (lane == 0) wmx[wave] = am;
+    lds_barrier();
+    const float tm = tile_max<4>(wmx);
+    if (smax_slot != nullptr && tid == 0) amax_tile_commit(smax_slot, tm);
+    if (tid == 0) *reinterpret_cast<volatile int*>(flag) = 0;
     x2h_dyn_scale(__builtin_bit_cast(unsigned, tm), sa, isa);
     const float f = sa * (1.f / kH2ActScale);
     for_each_acc<2, 2>(n0, lane, [&](int, int, int, int col, int, int row) { X[row * FP + col] *= f; });
@@ -102,7 +108,8 @@ __device__ inline void col_tile_rescale(const float* wm, float* X, int n0, int l
 __global__ __launch_bounds__(256, 2) void color_fwd_h2_kernel(ColH2Args g) {
   constexpr int NT = 256;
   __shared__ __attribute__((aligned(16))) float X[CT * FP];
-  __shared__ float wmx[2][4];
+  __shared__ float wmx[4];
+  __shared__ int ovf[2];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = wave_id();
   const int64_t row0 = (int64_t)blockIdx.x * CT;
@@ -111,11 +118,20 @@ __global__ __launch_bounds__(256, 2) void color_fwd_h2_kernel(ColH2Args g) {
   const x3raw* W0 = g.w2 + 2 * g.w_off[0];
   const x3raw* W1 = g.w2 + 2 * g.w_off[1];
   X3Mma<2, 2, 2> mm;
+  const float iwsv = h2_iws_load(g.h2tab, lane);
   mm.request_at(W0, nks0, ksF, n0, lane);
   const int PW = g.Cinp - g.F;   // encoding columns (64)
+  // the feature tile (written by the F sweep) is requested now and lands while the encoding is computed and multiplied
+  vf4 fr[CT * (FH / 4) / NT];
+#pragma unroll
+  for (int i = 0; i < CT * (FH / 4) / NT; ++i) {
+    const int idx = tid + NT * i;
+    fr[i] = *reinterpret_cast<const vf4*>(g.cin + (size_t)(row0 + (idx >> 6)) * g.Cinp + (idx & 63) * 4);
+  }
 
   // ---- pe(p), pe(n) (fp32 math, models/embedder.py:40-46) -> tile columns 0 .. PW: 4 threads per point = (which vector,
   //      even / odd octaves) ----
+  float pm;
   {
     const int p = tid & 63, part = tid >> 6, which = part >> 1, sub = part & 1;
     const int64_t row = row0 + p;
@@ -141,13 +157,20 @@ __global__ __launch_bounds__(256, 2) void color_fwd_h2_kernel(ColH2Args g) {
         xr[3 + 6 * k + 3 + d] = co * kH2ActScale;
       }
     }
-    const float m = wave_max(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fabsf(v[2])));   // (the only unbounded entries)
-    if (lane == 0) wmx[1][wave] = m;
+    pm = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fabsf(v[2]));   // (the only unbounded entries of the encoding)
+    // (every wave leaves its own word: nothing to initialise; the layers' flags start from zero behind the same barrier)
+    if (lane == 0) wmx[wave] = __builtin_amdgcn_ballot_w64(pm >= kH2ActLimit) != 0 ? 1.f : 0.f;
+    if (tid < 2) ovf[tid] = 0;
   }
   __syncthreads();
   float sa_p = kH2ActScale, isa_p = 1.f / kH2ActScale;
-  const float tm_p = fmaxf(tile_max<4>(wmx[1]), 1.f);
-  if (tm_p >= kH2ActLimit) {   // (workgroup-uniform)
+  if (tile_max<4>(wmx) != 0.f) {   // (workgroup-uniform) a coordinate or a normal component beyond 256
+    __syncthreads();
+    pm = wave_max(pm);
+    if (lane == 0) wmx[wave] = pm;
+    __syncthreads();
+    const float tm_p = fmaxf(tile_max<4>(wmx), 1.f);
+    if (g.smax != nullptr && tid == 0) amax_tile_commit(g.smax + SMAX_CIN, tm_p);
     x2h_dyn_scale(__builtin_bit_cast(unsigned, tm_p), sa_p, isa_p);
     const float f = sa_p * (1.f / kH2ActScale);
     for (int idx = tid; idx < CT * PW; idx += NT) {
@@ -165,58 +188,58 @@ __global__ __launch_bounds__(256, 2) void color_fwd_h2_kernel(ColH2Args g) {
   v16f acc[2][2];
   mm.run_at<false>(X, W0, nks0, ksF, PW >> 4, n0, lane, acc, W0, nks0, 0, n0);   // acc = pe . W0[:, F ..]^T
   lds_barrier();   // every wave has finished reading the encoding columns
-  // ---- features (written by the F sweep) -> tile, their maximum ----
-  {
-    float m = 0.f;
-    for (int idx = tid; idx < CT * (FH / 4); idx += NT) {
-      const int r = idx >> 6, c4 = idx & 63;
-      const vf4 v = *reinterpret_cast<const vf4*>(g.cin + (size_t)(row0 + r) * g.Cinp + c4 * 4);
-      *reinterpret_cast<vf4*>(X + r * FP + c4 * 4) = v * kH2ActScale;
-      m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
-    }
-    m = wave_max(m);
-    if (lane == 0) wmx[0][wave] = m;
+  // ---- features -> tile ----
+  float fm = 0.f;
+#pragma unroll
+  for (int i = 0; i < CT * (FH / 4) / NT; ++i) {
+    const int idx = tid + NT * i;
+    const vf4 v = fr[i];
+    *reinterpret_cast<vf4*>(X + (idx >> 6) * FP + (idx & 63) * 4) = v * kH2ActScale;
+    fm = fmaxf(fmaxf(fm, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
   }
+  h2_raise_flag(fm, &ovf[0], lane);
   __syncthreads();
   float sa = kH2ActScale, isa = 1.f / kH2ActScale;
-  {
-    const float tm = tile_max<4>(wmx[0]);
-    if (g.smax != nullptr && tid == 0) amax_tile_commit(g.smax + SMAX_CIN, fmaxf(tm, tm_p));
-    if (tm >= kH2ActLimit) {   // (workgroup-uniform)
-      x2h_dyn_scale(__builtin_bit_cast(unsigned, tm), sa, isa);
-      const float f = sa * (1.f / kH2ActScale);
-      for (int idx = tid; idx < CT * (FH / 4); idx += NT) {
-        vf4* q = reinterpret_cast<vf4*>(X + (idx >> 6) * FP + (idx & 63) * 4);
-        *q = *q * f;
-      }
-      __syncthreads();
+  if (h2_flag_up(&ovf[0])) {   // (workgroup-uniform) a feature beyond 256
+    fm = wave_max(fm);
+    if (lane == 0) wmx[wave] = fm;
+    __syncthreads();
+    const float tm = tile_max<4>(wmx);
+    if (g.smax != nullptr && tid == 0) amax_tile_commit(g.smax + SMAX_CIN, tm);
+    if (tid == 0) ovf[0] = 0;
+    x2h_dyn_scale(__builtin_bit_cast(unsigned, tm), sa, isa);
+    const float f = sa * (1.f / kH2ActScale);
+    for (int idx = tid; idx < CT * (FH / 4); idx += NT) {
+      vf4* q = reinterpret_cast<vf4*>(X + (idx >> 6) * FP + (idx & 63) * 4);
+      *q = *q * f;
     }
-    if (sa != sa_p) {   // (workgroup-uniform) the two parts of the product share one scale: that of the feature tile
-      const float f = sa * isa_p;
+    __syncthreads();
+  }
+  if (sa != sa_p) {   // (workgroup-uniform) the two parts of the product share one scale: that of the feature tile
+    const float f = sa * isa_p;
 #pragma unroll
-      for (int ti = 0; ti < 2; ++ti)
+    for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
-        for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = acc[ti][tj] * f;
-    }
+      for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = acc[ti][tj] * f;
   }
   mm.run_at<true>(X, W0, nks0, 0, ksF, n0, lane, acc, W1, FH >> 4, 0, n0);   // acc += feature . W0[:, 0 .. F]^T
   lds_barrier();   // in-place update: every wave has finished reading the tile
   {
-    const float inv = isa * g.h2tab->iws[g.id0];
-    const float am = wave_max(col_fwd_epilogue(acc, inv, g.packed + g.b_off[0], X, g.ac[0], row0, n0, lane));
-    if (lane == 0) wmx[1][wave] = am;
+    const float inv = isa * h2_iws_at(iwsv, g.id0);
+    const float am = col_fwd_epilogue(acc, inv, g.packed + g.b_off[0], X, g.ac[0], row0, n0, lane);
+    h2_raise_flag(am, &ovf[1], lane);
+    lds_barrier();
+    col_tile_rescale(&ovf[1], am, wmx, X, n0, lane, wave, g.smax ? g.smax + SMAX_AC : nullptr, tid, sa, isa);
   }
-  lds_barrier();
-  col_tile_rescale(wmx[1], X, n0, lane, g.smax ? g.smax + SMAX_AC : nullptr, tid, sa, isa);
   mm.run(X, W1, FH, n0, lane, acc, nullptr, 0, 0);
   lds_barrier();
   {
-    const float inv = isa * g.h2tab->iws[g.id0 + 1];
-    const float am = wave_max(col_fwd_epilogue(acc, inv, g.packed + g.b_off[1], X, g.ac[1], row0, n0, lane));
-    if (lane == 0) wmx[0][wave] = am;
+    const float inv = isa * h2_iws_at(iwsv, g.id0 + 1);
+    const float am = col_fwd_epilogue(acc, inv, g.packed + g.b_off[1], X, g.ac[1], row0, n0, lane);
+    h2_raise_flag(am, &ovf[0], lane);
+    lds_barrier();
+    col_tile_rescale(&ovf[0], am, wmx, X, n0, lane, wave, g.smax ? g.smax + SMAX_AC + 1 : nullptr, tid, sa, isa);
   }
-  lds_barrier();
-  col_tile_rescale(wmx[0], X, n0, lane, g.smax ? g.smax + SMAX_AC + 1 : nullptr, tid, sa, isa);
   // ---- output layer + sigmoid: fp32 weights on the VALU, 16 rows per wave ----
   {
     float w[4][4];
@@ -265,6 +288,7 @@ __global__ __launch_bounds__(256, 2) void color_bwd_h2_kernel(ColH2Args g) {
   const int rows_ok = left >= CT ? CT : (int)(left < 0 ? 0 : left);
   const x3raw* W1T = g.w2 + 2 * g.wT_off[1];
   const x3raw* W0T = g.w2 + 2 * g.wT_off[0];
+  const float iwsv = h2_iws_load(g.h2tab, lane);
 
   // zo = albbar * sigmoid'  (rows >= M: 0)
   if (tid < CT) {
@@ -341,7 +365,7 @@ __global__ __launch_bounds__(256, 2) void color_bwd_h2_kernel(ColH2Args g) {
   // ---- zc_0 = (zc_1 W_1) * relu'(ac_0) ----
   mm.run(X, W1T, FH, n0, lane, acc, nullptr, 0, 0);
   {
-    const float unscale = inv * g.h2tab->iws[g.id0 + 1];
+    const float unscale = inv * h2_iws_at(iwsv, g.id0 + 1);
     const int lane_e = opaque_lane(lane);   // (per-lane offsets rebuilt here, not carried through the matrix loop: fused_bwd.hip)
     const int h = lane_e >> 5;
     // the operand tile is requested AFTER the matrix loop, into the registers its fragments leave behind; the CU's other
@@ -365,7 +389,7 @@ __global__ __launch_bounds__(256, 2) void color_bwd_h2_kernel(ColH2Args g) {
   mm.request(W0T, FH, n0, lane);
   lds_barrier();
   // ---- cinb = zc_0 W_0: the feature columns 0 .. 255 (the FB sweep's input, the feature head's weight gradient) ----
-  const float unscale0 = inv * g.h2tab->iws[g.id0];
+  const float unscale0 = inv * h2_iws_at(iwsv, g.id0);
   mm.run(X, W0T, FH, n0, lane, acc, nullptr, 0, 0);
   {
     const int lane_e = opaque_lane(lane);

@@ -15,6 +15,11 @@
 #ifndef RNB_X3_SCALAR_EPI
 #define RNB_X3_SCALAR_EPI 0
 #endif
+// A/B switches (compile time, tools/build_variant.sh): what the x2h range guard of the forward sweep costs.
+// 1: no maximum tracking and no flag (the tile is assumed in range: round 4's behaviour); 2: tracking, but the flag is not read
+#ifndef RNB_H2_GUARD_AB
+#define RNB_H2_GUARD_AB 0
+#endif
 
 namespace rnb {
 
@@ -39,7 +44,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_forward_kernel
   // workgroups per CU)
   constexpr int NBUF = TI == 1 ? 2 : 1;
   __shared__ __attribute__((aligned(16))) float lds[NBUF * FT * FP + FT * FEP];
-  __shared__ float wmx[2][8];     // x2h: the waves' maxima of the values just written, by layer parity
+  __shared__ float wmx[8];        // x2h, rare path: the waves' maxima of the values just written
+  __shared__ int ovf[2];          // x2h: "a value of the tile just written reached kH2ActLimit", by layer parity
   float* X = lds;
   float* Y = lds + (NBUF - 1) * FT * FP;
   float* E = lds + NBUF * FT * FP;
@@ -49,8 +55,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_forward_kernel
   const int n0 = wave * 32 * TJ;
   // x2h: the tile in LDS holds its values times `sa` (a power of two, per tile and layer; isa = 1 / sa)
   [[maybe_unused]] float sa = SA, isa = 1.f / SA;
+  [[maybe_unused]] float iwsv = 0.f;
+  if constexpr (H2) iwsv = h2_iws_load(g.h2tab, lane);
 
   // ---- positional encoding of the tile: X[:, 0:Ep] = [x, sin(2^k x), cos(2^k x)], zero padded -------
+  [[maybe_unused]] float xm = 0.f;
   {
     constexpr int PARTS = NT / FT;
     const int p = tid % FT, part = tid / FT;
@@ -95,15 +104,21 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_forward_kernel
       }
     }
     if constexpr (H2) {   // the only unbounded entries of the encoding are the coordinates themselves
-      const float m = wave_max(fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fabsf(x[2])));
-      if (lane == 0) wmx[1][wave] = m;
+      xm = fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fabsf(x[2]));
+      // (every wave leaves its own word: nothing to initialise; the layers' flags start from zero behind the same barrier)
+      if (lane == 0) wmx[wave] = __builtin_amdgcn_ballot_w64(xm >= kH2ActLimit) != 0 ? 1.f : 0.f;
+      if (tid < 2) ovf[tid] = 0;
     }
   }
   __syncthreads();
   if constexpr (H2) {
-    const float tm = fmaxf(tile_max<NW>(wmx[1]), 1.f);
-    if (SAVE && g.smax != nullptr && tid == 0) amax_tile_commit(g.smax + SMAX_E, tm);
-    if (tm >= kH2ActLimit) {   // (workgroup-uniform) coordinates beyond 256: this tile carries a smaller scale
+    if (tile_max<NW>(wmx) != 0.f) {   // (workgroup-uniform) coordinates beyond 256: this tile carries a smaller scale
+      __syncthreads();                // (every wave has read the words)
+      xm = wave_max(xm);
+      if (lane == 0) wmx[wave] = xm;
+      __syncthreads();
+      const float tm = fmaxf(tile_max<NW>(wmx), 1.f);
+      if (SAVE && g.smax != nullptr && tid == 0) amax_tile_commit(g.smax + SMAX_E, tm);
       x2h_dyn_scale(__builtin_bit_cast(unsigned, tm), sa, isa);
       const float f = sa * (1.f / SA);
       for (int idx = tid; idx < FT * g.Ep; idx += NT) {
@@ -126,7 +141,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_forward_kernel
   if constexpr (X3) mm.request(g.w3 + WP * g.w_off[0], g.Kp[0], n0, lane);
   for (int l = 0; l < g.nh; ++l) {
     // x2h: accumulator -> pre-activation: 1 / (scale of the tile x scale of this layer's matrix in the mirror)
-    [[maybe_unused]] const float inv = H2 ? isa * g.h2tab->iws[l] : 1.f;
+    [[maybe_unused]] const float inv = H2 ? isa * h2_iws_at(iwsv, l) : 1.f;
     if constexpr (X3) {   // the next product's first weight steps are requested before this layer's epilogue
       const x3raw* wn = l + 1 < g.nh ? g.w3 + WP * g.w_off[l + 1] : (g.with_feat ? g.w3 + WP * g.wf_off : nullptr);
       mm.run(X, g.w3 + WP * g.w_off[l], g.Kp[l], n0, lane, acc, wn, FH, n0);
@@ -142,7 +157,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_forward_kernel
     const int n_real = g.n_real[l];
     const bool pe_tail = (l + 1 == g.skip);
     const bool last = (l + 1 == g.nh);
-    [[maybe_unused]] float am = 0.f;   // x2h: max |.| of what this thread writes to the tile
+    // x2h: max |.| of what this thread writes to the tile.  Softplus outputs are >= +0, where floats order like their bit
+    // patterns: ONE v_max3_u32 per pair of values (a NaN reads as a large integer and raises the flag, harmlessly).
+    [[maybe_unused]] unsigned amb = 0u;
+    [[maybe_unused]] float am = 0.f;
 #pragma unroll
     for (int tj = 0; tj < TJ; ++tj) {
       const int col = n0 + tj * 32 + cl;
@@ -169,7 +187,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_forward_kernel
           }
           Y[row * FP + col] = a.x * SA;
           Y[(row + 1) * FP + col] = a.y * SA;
-          if constexpr (H2) am = fmaxf(am, fmaxf(fabsf(a.x), fabsf(a.y)));   // (one v_max3_f32 per pair)
+          if constexpr (H2 && RNB_H2_GUARD_AB != 1) {
+            if (tile_full) h2_track2(amb, a.x, a.y);
+            else h2_track2(amb, fabsf(a.x), fabsf(a.y));   // (the tile with the skip connection's signed encoding)
+          }
           if (SAVE) {
             bstore(ra, voff, rowc * FH * 4, a.x);
             bstore(ra, voff, (rowc + 1) * FH * 4, a.y);
@@ -183,17 +204,21 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_forward_kernel
         }
       }
     }
-    if constexpr (H2) {
-      am = wave_max(am);
-      if (lane == 0) wmx[l & 1][wave] = am;
+    if constexpr (H2 && RNB_H2_GUARD_AB != 1) {
+      am = __builtin_bit_cast(float, amb);
+      h2_raise_flag(am, &ovf[l & 1], lane);
     }
     lds_barrier();   // the new activations are visible to every wave
-    if constexpr (H2) {
-      const float tm = tile_max<NW>(wmx[l & 1]);
-      if (SAVE && g.smax != nullptr && tid == 0) amax_tile_commit(g.smax + SMAX_A + l, tm);
+    if constexpr (H2 && RNB_H2_GUARD_AB == 0) {
       sa = SA;
       isa = 1.f / SA;
-      if (tm >= kH2ActLimit) {   // (workgroup-uniform; never taken by a network whose activations stay below 256)
+      if (h2_flag_up(&ovf[l & 1])) {   // (workgroup-uniform; never taken by a network whose activations stay below 256)
+        am = wave_max(am);
+        if (lane == 0) wmx[wave] = am;
+        lds_barrier();
+        const float tm = tile_max<NW>(wmx);
+        if (SAVE && g.smax != nullptr && tid == 0) amax_tile_commit(g.smax + SMAX_A + l, tm);
+        if (tid == 0) ovf[l & 1] = 0;
         x2h_dyn_scale(__builtin_bit_cast(unsigned, tm), sa, isa);
         const float f = sa * (1.f / SA);
 #pragma unroll
@@ -231,7 +256,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_forward_kernel
   }
   // ---- feature head: rows 1.. of the output layer, written into the albedo network's input ------------
   if (g.with_feat) {
-    [[maybe_unused]] const float inv = H2 ? isa * g.h2tab->iws[g.nh] : 1.f;
+    [[maybe_unused]] const float inv = H2 ? isa * h2_iws_at(iwsv, g.nh) : 1.f;
     if constexpr (X3) mm.run(X, g.w3 + WP * g.wf_off, FH, n0, lane, acc, nullptr, 0, 0);   // (requested by the last hidden layer)
     else layer_mma_nt<TI, NoHook, TJ>(X, g.packed + g.wf_off, FH, n0, lane, acc);
     const float* bias = g.packed + g.bf_off;
@@ -267,30 +292,48 @@ struct X3Table { int n, total_units; X3Entry e[kMaxX3]; };
 // LDS-tile kernels read their activation rows in the same order (x3_read_a), so one mirror serves both families.
 // tab != nullptr (x2h): the maximum |w| of every matrix is left in tab->wmax[id] on the way (float bits, zeroed by
 // wn_fwd_kernel; W entries only: W^T holds the same values) — x2h_pack_kernel, which follows, takes the matrix's scale from it.
-__global__ void x3_pack_kernel(const float* __restrict__ src, X3Table t, x3raw* __restrict__ dst, H2Tab* __restrict__ tab) {
-  const int u = blockIdx.x * blockDim.x + threadIdx.x;
-  if (u >= t.total_units) return;
+__global__ __launch_bounds__(256) void x3_pack_kernel(const float* __restrict__ src, X3Table t, x3raw* __restrict__ dst,
+                                                      H2Tab* __restrict__ tab) {
+  __shared__ float wmx[4];
+  const int u = blockIdx.x * 256 + threadIdx.x;
+  const bool live = u < t.total_units;
   int ei = 0;
   while (ei + 1 < t.n && u >= t.e[ei + 1].unit_begin) ++ei;
   const X3Entry en = t.e[ei];
-  const int lu = u - en.unit_begin;            // fragment lu / 64, lane lu % 64
-  const int frag = lu >> 6, lane = lu & 63;
-  const int nks = en.K >> 4;
-  const int nt = frag / nks, ks = frag - nt * nks;
-  const int c = lane & 31, h = lane >> 5;
-  const float* sp = src + en.off + (size_t)(nt * 32 + c) * en.K + ks * 16 + h * (en.tperm ? 4 : 8);
-  const vf4 x0 = *reinterpret_cast<const vf4*>(sp), x1 = *reinterpret_cast<const vf4*>(sp + (en.tperm ? 8 : 4));
-  vu4x hi, mid, lo;
-  x3_split8(x0, x1, hi, mid, lo);
-  x3raw* dp = dst + 3 * en.off + ((size_t)frag * 3 * 64 + lane) * 8;
-  *reinterpret_cast<vu4x*>(dp) = hi;
-  *reinterpret_cast<vu4x*>(dp + 512) = mid;
-  *reinterpret_cast<vu4x*>(dp + 1024) = lo;
-  if (tab != nullptr && en.id >= 0 && !en.tr) {   // (wave-uniform: an entry's units are a multiple of 64)
-    float m = fmaxf(fmaxf(fmaxf(fabsf(x0.x), fabsf(x0.y)), fmaxf(fabsf(x0.z), fabsf(x0.w))),
-                    fmaxf(fmaxf(fabsf(x1.x), fabsf(x1.y)), fmaxf(fabsf(x1.z), fabsf(x1.w))));
-    amax_commit(tab->wmax + en.id, m, lane);
+  float m = 0.f;
+  if (live) {
+    const int lu = u - en.unit_begin;            // fragment lu / 64, lane lu % 64
+    const int frag = lu >> 6, lane = lu & 63;
+    const int nks = en.K >> 4;
+    const int nt = frag / nks, ks = frag - nt * nks;
+    const int c = lane & 31, h = lane >> 5;
+    const float* sp = src + en.off + (size_t)(nt * 32 + c) * en.K + ks * 16 + h * (en.tperm ? 4 : 8);
+    const vf4 x0 = *reinterpret_cast<const vf4*>(sp), x1 = *reinterpret_cast<const vf4*>(sp + (en.tperm ? 8 : 4));
+    vu4x hi, mid, lo;
+    x3_split8(x0, x1, hi, mid, lo);
+    x3raw* dp = dst + 3 * en.off + ((size_t)frag * 3 * 64 + lane) * 8;
+    *reinterpret_cast<vu4x*>(dp) = hi;
+    *reinterpret_cast<vu4x*>(dp + 512) = mid;
+    *reinterpret_cast<vu4x*>(dp + 1024) = lo;
+    m = fmaxf(fmaxf(fmaxf(fabsf(x0.x), fabsf(x0.y)), fmaxf(fabsf(x0.z), fabsf(x0.w))),
+              fmaxf(fmaxf(fabsf(x1.x), fabsf(x1.y)), fmaxf(fabsf(x1.z), fabsf(x1.w))));
   }
+  if (tab == nullptr) return;   // (uniform)
+  // x2h: max |w| of the matrix -> tab->wmax[id] (W entries only).  A wave lies inside one entry (units are multiples of 64);
+  // when the whole workgroup does (the shipped shapes), its four waves' maxima meet in LDS and ONE conditional atomic leaves
+  // — one per wave put ~260 same-address atomics in a row on every slot: +16 us per step.
+  const bool rec = live && en.id >= 0 && !en.tr;
+  const int blk0 = blockIdx.x * 256;
+  const bool whole = en.unit_begin <= blk0 && blk0 + 256 <= en.unit_begin + en.N * en.K / 8;   // (workgroup-uniform)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if (!whole) {
+    if (rec && (threadIdx.x & 63) == 0) amax_tile_commit(tab->wmax + en.id, m);
+    return;
+  }
+  if ((threadIdx.x & 63) == 0) wmx[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (rec && threadIdx.x == 0) amax_tile_commit(tab->wmax + en.id, fmaxf(fmaxf(wmx[0], wmx[1]), fmaxf(wmx[2], wmx[3])));
 }
 // the scale of a matrix of the fp16 mirror from the float bits of its max |w|: 2^8 (the round-4 constant: results unchanged)
 // while the maximum is below 64; beyond, the power of two that puts the maximum in [2^13, 2^14) — no finite weight overflows

@@ -85,7 +85,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TI == 2) ? 1 : 2) void fused_r
   [[maybe_unused]] constexpr bool BOTH_IN_LOOP = !(TI == 2 && TJ == 2);
   constexpr int NBUF = TI == 1 ? 2 : 1;
   __shared__ __attribute__((aligned(16))) float lds[NBUF * BT * FP + BT * FEP];
-  __shared__ float wmx[2][8];              // x2h: the waves' maxima of the values just written, by layer parity
+  __shared__ float wmx[8];                 // x2h: the waves' words (seed: "reached the limit"; rare path: maxima)
+  __shared__ int ovf[2];                   // x2h: "a value of the tile just written reached kH2ActLimit", by layer parity
   float* X = lds;                          // input of the current layer
   float* Y = lds + (NBUF - 1) * BT * FP;   // output of the current layer (== X when updated in place)
   float* GE = lds + NBUF * BT * FP;        // d sdf / d e of the tile
@@ -94,8 +95,11 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TI == 2) ? 1 : 2) void fused_r
   const int64_t row0 = (int64_t)blockIdx.x * BT;
   const int n0 = wave * 32 * TJ;
   [[maybe_unused]] float sg = SG, isg = 1.f / SG;   // x2h: the tile holds gz times sg
+  [[maybe_unused]] float iwsv = 0.f;
+  if constexpr (H2) iwsv = h2_iws_load(g.h2tab, lane);
 
   // seed: gz_{nh-1} = w_sdf * D_{nh-1}  (row 0 of the output layer is d sdf / d a_last)
+  [[maybe_unused]] float sm = 0.f;
   {
     const float* Dl = g.D[g.nh - 1] + (size_t)row0 * FH;
     float* gzl = g.gz[g.nh - 1] + (size_t)row0 * FH;
@@ -111,16 +115,21 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TI == 2) ? 1 : 2) void fused_r
       if constexpr (H2) m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
     }
     for (int idx = tid; idx < BT * FEP; idx += NT) GE[idx] = 0.f;
-    if constexpr (H2) {
-      m = wave_max(m);
-      if (lane == 0) wmx[g.nh & 1][wave] = m;
+    if constexpr (H2) {   // (every wave leaves its own word: nothing to initialise; see fused_forward_kernel)
+      if (lane == 0) wmx[wave] = __builtin_amdgcn_ballot_w64(m >= kH2ActLimit) != 0 ? 1.f : 0.f;
+      if (tid < 2) ovf[tid] = 0;
     }
+    if constexpr (H2) sm = m;
   }
   __syncthreads();
   if constexpr (H2) {
-    const float tm = tile_max<NW>(wmx[g.nh & 1]);
-    if (g.smax != nullptr && tid == 0) amax_tile_commit(g.smax + SMAX_GZ + g.nh - 1, tm);
-    if (tm >= kH2ActLimit) {   // (workgroup-uniform)
+    if (tile_max<NW>(wmx) != 0.f) {   // (workgroup-uniform)
+      __syncthreads();
+      sm = wave_max(sm);
+      if (lane == 0) wmx[wave] = sm;
+      __syncthreads();
+      const float tm = tile_max<NW>(wmx);
+      if (g.smax != nullptr && tid == 0) amax_tile_commit(g.smax + SMAX_GZ + g.nh - 1, tm);
       x2h_dyn_scale(__builtin_bit_cast(unsigned, tm), sg, isg);
       const float f = sg * (1.f / SG);
       for (int idx = tid; idx < BT * FH / 4; idx += NT) {
@@ -139,7 +148,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TI == 2) ? 1 : 2) void fused_r
   }
   for (int l = g.nh - 1; l >= 1; --l) {
     // x2h: accumulator -> g: 1 / (scale of the tile x scale of this layer's matrix in the mirror)
-    [[maybe_unused]] const float INV = H2 ? isg * g.h2tab->iws[l] : 1.f;
+    [[maybe_unused]] const float INV = H2 ? isg * h2_iws_at(iwsv, l) : 1.f;
     const long long nxt = (l > 1 || n0 < 64) ? g.wT_off[l - 1] : -1;   // layer 0's product: the waves of columns 0..63
     // x3, 64 x 64-output waves: the operand tile is requested AFTER the matrix loop, into the registers the loop's
     // fragments leave behind; the other workgroup of the CU multiplies while it travels
@@ -175,17 +184,18 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TI == 2) ? 1 : 2) void fused_r
           bstore(rg, (unsigned)(4 * h * FH + col) * 4u, rowc * FH * 4, gzv);
           if constexpr (H2) gm[r & 1] = fmaxf(gm[r & 1], fabsf(gzv));
         });
-    if constexpr (H2) {
-      const float m = wave_max(fmaxf(gm[0], gm[1]));
-      if (lane_e == 0) wmx[l & 1][wave] = m;
-    }
+    if constexpr (H2) h2_raise_flag(fmaxf(gm[0], gm[1]), &ovf[l & 1], lane_e);
     lds_barrier();
     if constexpr (H2) {
-      const float tm = tile_max<NW>(wmx[l & 1]);
-      if (g.smax != nullptr && tid == 0) amax_tile_commit(g.smax + SMAX_GZ + l - 1, tm);
       sg = SG;
       isg = 1.f / SG;
-      if (tm >= kH2ActLimit) {   // (workgroup-uniform; a Jacobian row beyond 256: this tile carries a smaller scale)
+      if (h2_flag_up(&ovf[l & 1])) {   // (workgroup-uniform; a Jacobian row beyond 256: this tile carries a smaller scale)
+        const float m = wave_max(fmaxf(gm[0], gm[1]));
+        if (lane_e == 0) wmx[wave] = m;
+        lds_barrier();
+        const float tm = tile_max<NW>(wmx);
+        if (g.smax != nullptr && tid == 0) amax_tile_commit(g.smax + SMAX_GZ + l - 1, tm);
+        if (tid == 0) ovf[l & 1] = 0;
         x2h_dyn_scale(__builtin_bit_cast(unsigned, tm), sg, isg);
         const float f = sg * (1.f / SG);
         for_each_acc<TI, TJ>(n0, lane_e, [&](int tj, int ti, int r, int col, int rowc, int row) { Y[row * FP + col] *= f; });
@@ -196,7 +206,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TI == 2) ? 1 : 2) void fused_r
   }
   // layer 0: g_e += gz_0 W_0 (Ep = 64 columns: the waves that own columns 0..63)
   if (n0 < 64) {
-    [[maybe_unused]] const float INV = H2 ? isg * g.h2tab->iws[0] : 1.f;
+    [[maybe_unused]] const float INV = H2 ? isg * h2_iws_at(iwsv, 0) : 1.f;
     layer_mma<TI, TJ, X3>(X, g, g.wT_off[0], FH, n0, lane, acc, mm, -1);
     for_each_acc<TI, TJ>(n0, lane, [&](int tj, int ti, int r, int col, int rowc, int row) {
       if (col < g.pe) GE[row * FEP + col] += acc[ti][tj][r] * INV;
@@ -262,8 +272,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TI == 2) ? 1 : 2) void fused_r
   if (g.amax != nullptr && tid == 0) {
     float m = wmx[1][0];
     for (int w = 1; w < NW; ++w) m = fmaxf(m, wmx[1][w]);
-    const unsigned bq = __builtin_bit_cast(unsigned, m);
-    if (bq > __atomic_load_n(g.amax + AMAX_U, __ATOMIC_RELAXED)) atomicMax(g.amax + AMAX_U, bq);
+    amax_tile_commit(g.amax + AMAX_U, m);
   }
 
   v16f acc[TI][TJ];
@@ -352,8 +361,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TI == 2) ? 1 : 2) void fused_r
     if (g.amax != nullptr && tid == 0) {
       float m = wmx[l & 1][0];
       for (int w = 1; w < NW; ++w) m = fmaxf(m, wmx[l & 1][w]);
-      const unsigned b = __builtin_bit_cast(unsigned, m);
-      if (b > __atomic_load_n(g.amax + AMAX_U + l + 1, __ATOMIC_RELAXED)) atomicMax(g.amax + AMAX_U + l + 1, b);
+      amax_tile_commit(g.amax + AMAX_U + l + 1, m);
     }
     if constexpr (NBUF == 2) { float* t = X; X = Y; Y = t; }
   }
@@ -484,6 +492,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_fb_h2_kernel(F
   }
   for (int ti_ = 0; ti_ < TI; ++ti_) for (int tj_ = 0; tj_ < TJ; ++tj_) for (int r_ = 0; r_ < 16; ++r_) acc[ti_][tj_][r_] = 0.f;
   float unscale = 1.f;   // accumulator -> ab (true units)
+  const float iwsv = h2_iws_load(g.h2tab, lane);
   if (g.fbar != nullptr) {   // ab_{nh-1} = fbar W_feat (+ the sdf-head term below)
     const float* fb = g.fbar + (size_t)row0 * g.ld_fbar;
     float m = 0.f;
@@ -506,7 +515,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_fb_h2_kernel(F
     __syncthreads();
     if constexpr (LATE) mm.request(g.w3 + 2 * g.wfT_off, FH, n0, lane);
     mm.run(X, g.w3 + 2 * g.wfT_off, FH, n0, lane, acc, (!LATE && g.nh > 1) ? g.w3 + 2 * g.wT_off[g.nh - 1] : nullptr, FH, n0);
-    unscale = inv * g.h2tab->iws[g.nh];   // (tile scale x the feature head's scale in the mirror)
+    unscale = inv * h2_iws_at(iwsv, g.nh);   // (tile scale x the feature head's scale in the mirror)
   }
   if constexpr (LATE) {
     prefetch_tile<TI, TJ>(g.D[g.nh - 1], row0, n0, lane, aD);
@@ -563,7 +572,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_fb_h2_kernel(F
         prefetch_tile<TI, TJ>(g.zR[l - 1], row0, n0, lane, aZ);
       });
     }
-    unscale = inv * g.h2tab->iws[l];
+    unscale = inv * h2_iws_at(iwsv, l);
   }
 }
 

@@ -40,12 +40,14 @@ struct FusedFwdArgs {
 };
 
 // ---- x2h: per-tile scale of the operand tile in LDS -----------------------------------------------------------------
-// The tile holds its values times a power of two: kH2ActScale (2^6, the round-4 constant: results unchanged) while the tile's
-// maximum stays below kH2ActLimit, else the power of two that puts the maximum in [2^13, 2^14) — chosen per tile and layer
-// from the values just written (the waves' maxima meet in LDS behind the barrier that ends the layer), so NO activation,
-// network input or Jacobian row is out of range.  Writers store times kH2ActScale; when the tile's maximum calls for less,
-// every thread rescales the elements it wrote (an exact multiplication) behind one more barrier — a path a sane network
-// never takes.
+// The tile holds its values times a power of two: kH2ActScale (2^6, the round-4 constant: results unchanged) while every
+// value of the tile stays below kH2ActLimit, else the power of two that puts the tile's maximum in [2^13, 2^14) — chosen
+// per tile and layer from the values just written, so NO activation, network input or Jacobian row is out of range.
+// Writers store times kH2ActScale and keep the maximum of what they wrote (one v_max3 per pair of values); a wave in which
+// any lane reached the limit (one ballot) raises a flag in LDS before the barrier that ends the layer, every wave reads the
+// flag behind it — that is all the common case costs.  Only when the flag is up do the waves exchange their maxima, every
+// thread rescales the elements it wrote (an exact multiplication) and the tile's maximum is left in PointBufs::smax for the
+// weight-gradient kernel (whose state operands then take their scale from it): a path a sane network never takes.
 constexpr float kH2ActLimit = 256.f;   // 2^8 * 2^6 = 2^14: the first maximum that leaves [.., 2^14)
 __device__ inline float wave_max(float m) {
 #pragma unroll
@@ -67,10 +69,32 @@ __device__ inline float tile_scale(const float* wm, float& s, float& inv_s) {
   x2h_dyn_scale(__builtin_bit_cast(unsigned, m), s, inv_s);
   return m;
 }
-// one atomic per tile, and only when the slot would grow
+// m = max(m, a, b) on the BIT PATTERNS of two floats that are >= +0 (where floats order like unsigned integers): one
+// v_max3_u32 for two values.  (Written as asm: from the nested max the compiler made a float maximum plus an integer one.)
+__device__ inline void h2_track2(unsigned& m, float a, float b) {
+  asm("v_max3_u32 %0, %1, %2, %3" : "=v"(m) : "v"(m), "v"(a), "v"(b));
+}
+// the waves of a workgroup agree on whether the tile just written needs a smaller scale: `mine` = this thread's maximum;
+// flag = one LDS word (zero unless raised; reset by the slow path)
+__device__ inline void h2_raise_flag(float mine, int* flag, int lane) {
+  if (__builtin_amdgcn_ballot_w64(mine >= kH2ActLimit) != 0 && lane == 0) *reinterpret_cast<volatile int*>(flag) = 1;
+}
+__device__ inline bool h2_flag_up(const int* flag) {   // (expected down: the rescaling path is laid out off the hot path)
+  return __builtin_expect(__builtin_amdgcn_readfirstlane(*reinterpret_cast<const volatile int*>(flag)) != 0, 0);
+}
+// The inverse scales of the mirror's matrices, one per lane (lane id = table id), loaded ONCE at the top of a kernel: a load
+// per layer would sit in the in-order vector-memory queue in front of that layer's weight fragments.  h2_iws_at picks a
+// layer's value out of the register (v_readlane with a uniform index).
+__device__ inline float h2_iws_load(const H2Tab* tab, int lane) { return tab->iws[lane < kH2TabSlots ? lane : 0]; }
+__device__ inline float h2_iws_at(float iwsv, int id) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, iwsv), id));
+}
+// One atomic per tile (and layer): fire and forget.  The result is not used, so the instruction does not return and the wave
+// does not wait for it — a "does the slot grow?" load in front of it (round 4) made the committing wave sit out a global round
+// trip before every layer's matrix loop, with its partners waiting for it at the next barrier.  A thousand tiles spread over a
+// launch put a few atomics per microsecond on a slot: nothing for the L2.
 __device__ inline void amax_tile_commit(unsigned* slot, float m) {
-  const unsigned b = __builtin_bit_cast(unsigned, m);
-  if (b > __atomic_load_n(slot, __ATOMIC_RELAXED)) atomicMax(slot, b);
+  (void)__hip_atomic_fetch_max(slot, __builtin_bit_cast(unsigned, m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // One (32*TI) x (32*TJ) output block per wave (TJ = 2 unless stated): C[rows][n0..] = X[rows][K] * W[n][K]^T, K a

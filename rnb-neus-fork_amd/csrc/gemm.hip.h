@@ -359,12 +359,11 @@ __device__ inline void x3_split8(const vf4& x0, const vf4& x1, vu4x& hi, vu4x& m
 __device__ inline void amax_commit(unsigned* slot, float m, int lane) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-  // the slot only grows: a wave whose maximum is not above what is already there sends no atomic (thousands of same-address
-  // atomics arriving together serialise in the L2: 35 us at the end of a 60 us kernel when every wave sent one)
-  if (lane == 0 && slot != nullptr) {
-    const unsigned b = __builtin_bit_cast(unsigned, m);
-    if (b > __atomic_load_n(slot, __ATOMIC_RELAXED)) atomicMax(slot, b);
-  }
+  // fire and forget (the result is unused: the instruction does not return, the wave does not wait).  Callers keep the number
+  // of atomics per slot and launch in the thousands: every wave of a 65,536-row GEMM sending one at the same moment (round 4's
+  // first version) serialised in the L2 for 35 us.
+  if (lane == 0 && slot != nullptr)
+    (void)__hip_atomic_fetch_max(slot, __builtin_bit_cast(unsigned, m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // max |acc| over the accumulator rows below `rows_ok` (relative to the wave's first row) of a (32 TI) x (32 TJ) block
 template <int TI, int TJ>
