@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RNB_ABI_VERSION 4
+#define RNB_ABI_VERSION 5
 #define RNB_MAX_LIN 16 /* linear layers per MLP */
 
 enum {
@@ -101,13 +101,16 @@ typedef struct rnb_model_desc {
  *   RNB_VARIANT_X2H /         (with X3; ON by default, NO_X2H switches it off) every fp32 product of the fused path except the
  *   RNB_VARIANT_NO_X2H        RA sweep's is taken as THREE fp16 matrix terms (x = hi + lo in fp16 after a power-of-two scale)
  *                             instead of six bf16 ones: half the matrix time; operands represented to 2^-22 (rms 2^-23.6;
- *                             the measured SDF error against fp64 is below the six-term scheme's).  Scales:
- *                             FIXED for operands of known range — weights 2^8 (|w| < 255), activations, network inputs and
- *                             the Jacobian rows of the normal's reverse sweep 2^6 (|a| < 1023): beyond that range outputs are
- *                             inf / NaN, never silently wrong; TAKEN FROM THE DATA for loss adjoints (weight gradients,
- *                             FB sweep, albedo backward): their producers record max |.|, so any loss scale works (a loss
- *                             times 2^k gives gradients times 2^k bit for bit, tested at k = +-40).  The RA sweep is bound by
- *                             its saved-state traffic and keeps the six bf16 terms. */
+ *                             the measured SDF error against fp64 is below the six-term scheme's).  Every scale
+ *                             is TAKEN FROM THE DATA, so there is no operand range [round 5; through ABI 4 weights beyond 255
+ *                             and activations beyond 1023 gave inf / NaN]: the weights' per matrix (2^8 while max |w| < 64,
+ *                             else the power of two that puts the maximum in [2^13, 2^14); table behind the mirror in the
+ *                             packed buffer); activations', network inputs' and Jacobian rows' per 64-point tile and layer (2^6
+ *                             while the tile stays below 256); the saved state's that the weight gradients read per launch
+ *                             (from maxima the forward leaves in the workspace); loss adjoints' per tile / per launch from
+ *                             their recorded maxima, so any loss scale works (a loss times 2^k gives gradients times 2^k bit
+ *                             for bit, tested at k = +-40).  In the old range the results are bit-identical to ABI 4's.  The RA
+ *                             sweep is bound by its saved-state traffic and keeps the six bf16 terms. */
 enum {
   RNB_VARIANT_BF16 = 1,
   RNB_VARIANT_DETERMINISTIC = 2,
@@ -372,6 +375,20 @@ int rnb_loss_rnb_shard(const float* color_fine, const float* true_rgb, const flo
  * scalars (the learning-rate schedule of exp_runner.py:327-337 changes lr every step). */
 int rnb_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double lr,
                   double beta1, double beta2, double eps, double weight_decay, int64_t step, rnb_stream_t stream);
+
+/* Diagnostic (not part of the reference's interface): the largest magnitudes of one render's operands, read back from the
+ * workspace of rnb_render_fwd (after it) and, for out[4], of rnb_render_bwd (after it) — same desc / B / S / flags / ws as those
+ * calls.  out: device [8] floats:
+ *   [0] max |effective weight| over the matrices of both networks (0 unless the default x2h arithmetic keeps its scale table)
+ *   [1] max |hidden activation or encoded input| of the SDF network      [2] max |Jacobian row| of the normal's reverse sweep
+ *   [3] max |input or hidden activation| of the albedo network           [4] max |loss adjoint| recorded by the backward (x2h)
+ *   [5..7] 0 (reserved).
+ * The default arithmetic (RNB_VARIANT_X2H) takes every fp16 operand scale from the data — per matrix, per tile and layer, per
+ * launch — so none of these has a limit; the numbers document how far a model is from the fixed scales' old range (255 /
+ * 1023), e.g. over a training run (tools/soak.py, profiles/r05_x2h_range.txt).  Costs one pass over the saved state: not
+ * for the hot path.  [ABI 5] */
+int rnb_render_range(const rnb_model_desc* desc, const float* packed, const void* ws, size_t ws_bytes, int64_t B, int32_t S,
+                     int32_t flags, float* out, rnb_stream_t stream);
 
 /* Measurement aid for bench.py (not part of the reference's interface): while enabled, every launch of
  * the fp32-MFMA kernels (fused_*_kernel, gemm_dw_*_kernel, gemm_rows_kernel<...>) is bracketed by HIP events on

@@ -528,6 +528,23 @@ RNB_API int rnb_render_bwd(const rnb_model_desc* desc, const float* packed, cons
   return RNB_OK;
 }
 
+RNB_API int rnb_render_range(const rnb_model_desc* desc, const float* packed, const void* ws, size_t ws_bytes, int64_t B, int32_t S,
+                             int32_t flags, float* out, rnb_stream_t stream) {
+  RNB_REQUIRE(packed, "packed");
+  RNB_REQUIRE(ws, "workspace");
+  RNB_REQUIRE(out, "out");
+  if (B <= 0 || S < 1) RNB_FAIL(RNB_E_INVALID, "bad B/S");
+  hipStream_t s = (hipStream_t)stream;
+  Layout L;
+  RNB_TRY(make_layout(desc, &L));
+  Carver c(const_cast<void*>(ws), ws_bytes);
+  RenderBufs rb;
+  carve_render(L, c, B, S, flags, &rb);
+  if (!c.ok) RNB_FAIL(RNB_E_WORKSPACE, "workspace too small: need %zu bytes, have %zu", c.off, ws_bytes);
+  return launch_range_report(L, packed, rb.pb, (render_mode_of(flags, L) & PM_WITH_COLOR) != 0,
+                             !(flags & RNB_FLAG_FORWARD_ONLY), out, s);
+}
+
 RNB_API int rnb_profile_enable(int on) { return profile_enable(on); }
 RNB_API int rnb_profile_collect(double* gemm_ms, int64_t* gemm_launches, double* gemm_flops) {
   return profile_collect(gemm_ms, gemm_launches, gemm_flops);

@@ -35,6 +35,8 @@ struct ColH2Args {
   int ldwo;
   float* cin;              // [Mp,Cinp]: feature columns written by the F sweep; the forward adds the encoding columns
   float* ac[2];            // [Mp,256]
+  unsigned* ac0_mask;      // [tiles][256 threads][2]: relu'(ac_0) as one bit per element in the threads' accumulator layout —
+                           // all the backward needs of ac_0 (2 MB instead of a 67 MB tile read with its latency exposed)
   float* alb;              // [Mp,4]
   unsigned* smax;          // PointBufs::smax (forward: slots SMAX_CIN, SMAX_AC + l grown) or nullptr
   // backward
@@ -56,8 +58,17 @@ constexpr int CT = 64;     // points per tile
 __device__ inline float relu_keep_nan(float x) { return x < 0.f ? 0.f : x; }
 
 // hidden-layer epilogue of the forward: a = relu(acc * inv + b) -> tile (times kH2ActScale), HBM; returns the thread's max
+// m = 2 m + (a > 0): appends one bit of the relu mask — a compare into VCC and an add-with-carry.  After 32 elements the
+// first one appended sits in bit 31 (col_mask_bit).
+__device__ inline void col_mask_push(unsigned& m, float a) {
+  asm("v_cmp_gt_f32 vcc, %1, 0\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(a) : "vcc");
+}
+// all-ones / zero from the bit of element (ti, r) of a column tile's mask word
+__device__ inline unsigned col_mask_bit(unsigned m, int ti, int r) { return (unsigned)(((int)(m << (ti * 16 + r))) >> 31); }
+
+template <bool MASK>
 __device__ inline float col_fwd_epilogue(const v16f (&acc)[2][2], float inv, const float* __restrict__ bias, float* X,
-                                         float* __restrict__ out, int64_t row0, int n0, int lane) {
+                                         float* __restrict__ out, int64_t row0, int n0, int lane, unsigned* __restrict__ mask_out) {
   const int h = lane >> 5, cl = lane & 31;
   const BufRsrc ro = tile_rsrc(out + (size_t)row0 * FH, CT * FH * 4);
   unsigned amb = 0u;   // (relu outputs are >= +0: their maximum on the bit patterns, h2_track2)
@@ -65,6 +76,7 @@ __device__ inline float col_fwd_epilogue(const v16f (&acc)[2][2], float inv, con
   for (int tj = 0; tj < 2; ++tj) {
     const int col = n0 + tj * 32 + cl;
     const float bc = bias[col];
+    [[maybe_unused]] unsigned mk = 0u;
     const unsigned voff = (unsigned)(4 * h * FH + col) * 4u;
 #pragma unroll
     for (int ti = 0; ti < 2; ++ti)
@@ -77,9 +89,11 @@ __device__ inline float col_fwd_epilogue(const v16f (&acc)[2][2], float inv, con
         X[row * FP + col] = a0 * kH2ActScale;
         X[(row + 1) * FP + col] = a1 * kH2ActScale;
         h2_track2(amb, a0, a1);
+        if constexpr (MASK) { col_mask_push(mk, a0); col_mask_push(mk, a1); }
         bstore(ro, voff, rowc * FH * 4, a0);
         bstore(ro, voff, (rowc + 1) * FH * 4, a1);
       }
+    if constexpr (MASK) mask_out[tj] = mk;
   }
   return __builtin_bit_cast(float, amb);
 }
@@ -226,7 +240,8 @@ __global__ __launch_bounds__(256, 2) void color_fwd_h2_kernel(ColH2Args g) {
   lds_barrier();   // in-place update: every wave has finished reading the tile
   {
     const float inv = isa * h2_iws_at(iwsv, g.id0);
-    const float am = col_fwd_epilogue(acc, inv, g.packed + g.b_off[0], X, g.ac[0], row0, n0, lane);
+    const float am = col_fwd_epilogue<true>(acc, inv, g.packed + g.b_off[0], X, g.ac[0], row0, n0, lane,
+                                            g.ac0_mask + ((size_t)blockIdx.x * NT + tid) * 2);
     h2_raise_flag(am, &ovf[1], lane);
     lds_barrier();
     col_tile_rescale(&ovf[1], am, wmx, X, n0, lane, wave, g.smax ? g.smax + SMAX_AC : nullptr, tid, sa, isa);
@@ -235,7 +250,7 @@ __global__ __launch_bounds__(256, 2) void color_fwd_h2_kernel(ColH2Args g) {
   lds_barrier();
   {
     const float inv = isa * h2_iws_at(iwsv, g.id0 + 1);
-    const float am = col_fwd_epilogue(acc, inv, g.packed + g.b_off[1], X, g.ac[1], row0, n0, lane);
+    const float am = col_fwd_epilogue<false>(acc, inv, g.packed + g.b_off[1], X, g.ac[1], row0, n0, lane, nullptr);
     h2_raise_flag(am, &ovf[0], lane);
     lds_barrier();
     col_tile_rescale(&ovf[0], am, wmx, X, n0, lane, wave, g.smax ? g.smax + SMAX_AC + 1 : nullptr, tid, sa, isa);
@@ -302,6 +317,7 @@ __global__ __launch_bounds__(256, 2) void color_bwd_h2_kernel(ColH2Args g) {
   }
   AuxTile<2, 2> aA;
   prefetch_tile<2, 2>(g.ac[1], row0, n0, lane, aA);
+  const vu2 mk0 = *reinterpret_cast<const vu2*>(g.ac0_mask + ((size_t)blockIdx.x * 256 + tid) * 2);   // relu'(ac_0), this thread's bits
   __syncthreads();
   if (tid < g.Co) {   // d b_out of this tile
     float t = 0.f;
@@ -363,17 +379,14 @@ __global__ __launch_bounds__(256, 2) void color_bwd_h2_kernel(ColH2Args g) {
   mm.request(W1T, FH, n0, lane);
   lds_barrier();
   // ---- zc_0 = (zc_1 W_1) * relu'(ac_0) ----
-  mm.run(X, W1T, FH, n0, lane, acc, nullptr, 0, 0);
+  mm.run(X, W1T, FH, n0, lane, acc, W0T, FH, n0);   // (its tail requests the first weight steps of the product after it)
   {
     const float unscale = inv * h2_iws_at(iwsv, g.id0 + 1);
     const int lane_e = opaque_lane(lane);   // (per-lane offsets rebuilt here, not carried through the matrix loop: fused_bwd.hip)
     const int h = lane_e >> 5;
-    // the operand tile is requested AFTER the matrix loop, into the registers its fragments leave behind; the CU's other
-    // workgroup multiplies while it travels (as the 64 x 64-output waves of fused_fb_h2_kernel do)
-    prefetch_tile<2, 2>(g.ac[0], row0, n0, lane_e, aA);
     const BufRsrc rz = tile_rsrc(g.zc[0] + (size_t)row0 * FH, CT * FH * 4);
     for_each_acc<2, 2>(n0, lane_e, [&](int tj, int ti, int r, int col, int rowc, int) {
-      const float z = aA.v[ti][tj][r] > 0.f ? acc[ti][tj][r] * unscale : 0.f;
+      const float z = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, acc[ti][tj][r] * unscale) & col_mask_bit(mk0[tj], ti, r));
       bstore(rz, (unsigned)(4 * h * FH + col) * 4u, rowc * FH * 4, z);
       acc[ti][tj][r] = z;
     });
@@ -386,7 +399,6 @@ __global__ __launch_bounds__(256, 2) void color_bwd_h2_kernel(ColH2Args g) {
     if (tid == 0 && g.amax != nullptr) amax_tile_commit(g.amax + AMAX_ZC, tmax);
   }
   for_each_acc<2, 2>(n0, lane, [&](int tj, int ti, int r, int col, int, int row) { X[row * FP + col] = acc[ti][tj][r] * s; });
-  mm.request(W0T, FH, n0, lane);
   lds_barrier();
   // ---- cinb = zc_0 W_0: the feature columns 0 .. 255 (the FB sweep's input, the feature head's weight gradient) ----
   const float unscale0 = inv * h2_iws_at(iwsv, g.id0);
@@ -419,32 +431,46 @@ __global__ __launch_bounds__(256, 2) void color_bwd_h2_kernel(ColH2Args g) {
     for (int r = 0; r < 16; ++r) X[(rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * FP + 32 * ct + cl] = pacc[0][0][r] * unscale0;
   }
   lds_barrier();
-  // ---- nbar_total = nbar + J_pe(n)^T cinb[pe(n)];  geb = J_pe(x) nbar_total  (one thread per point) -> tile columns 64 .. ----
-  if (tid < CT) {
-    const int64_t row = row0 + tid;
-    float nb[3] = {0.f, 0.f, 0.f};
-    if (tid < rows_ok) {
-      const float* gq = X + tid * FP + g.pev;   // the pe(n) block
+  // ---- nbar_total = nbar + J_pe(n)^T cinb[pe(n)];  geb = J_pe(x) nbar_total -> tile columns 64 ..: four threads per point,
+  //      each one octave in four of both encodings (one thread per point left three waves idle through 30 sincos) ----
+  {
+    const int p = tid & 63, q = tid >> 6;
+    const int64_t row = row0 + p;
+    const bool ok = p < rows_ok;
+    float* part = X + p * FP + 128;          // [4][3] partial sums of J_pe(n)^T g at tile columns 128 .. 139
+    {
+      const float* gq = X + p * FP + g.pev;   // the pe(n) block of the adjoint
+      float t[3] = {0.f, 0.f, 0.f};
+      if (ok) {
+        for (int k = q; k < g.multires_view; k += 4) {
+          const float f = (float)(1 << k);
+          const int c = 3 + 6 * k;
 #pragma unroll
-      for (int d = 0; d < 3; ++d) nb[d] = g.nbar[row * 4 + d] + gq[d];
-      float f = 1.f;
-      int c = 3;
-      for (int k = 0; k < g.multires_view; ++k) {
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-          float sn, co;
-          sincosf(g.nrm[row * 4 + d] * f, &sn, &co);
-          nb[d] += f * (gq[c + d] * co - gq[c + 3 + d] * sn);
+          for (int d = 0; d < 3; ++d) {
+            float sn, co;
+            sincosf(g.nrm[row * 4 + d] * f, &sn, &co);
+            t[d] += f * (gq[c + d] * co - gq[c + 3 + d] * sn);
+          }
         }
-        c += 6;
-        f *= 2.f;
       }
+#pragma unroll
+      for (int d = 0; d < 3; ++d) part[q * 3 + d] = t[d];
     }
-    float* o = X + tid * FP + 64;
-    o[0] = nb[0]; o[1] = nb[1]; o[2] = nb[2];
-    int c = 3;
-    float f = 1.f;
-    for (int k = 0; k < g.multires; ++k) {
+    __syncthreads();
+    float nb[3] = {0.f, 0.f, 0.f};
+    if (ok) {
+      const float* gq = X + p * FP + g.pev;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) nb[d] = g.nbar[row * 4 + d] + gq[d] + ((part[d] + part[3 + d]) + (part[6 + d] + part[9 + d]));
+    }
+    float* o = X + p * FP + 64;
+    if (q == 0) {
+      o[0] = nb[0]; o[1] = nb[1]; o[2] = nb[2];
+      for (int c = 3 + 6 * g.multires; c < g.Ep; ++c) o[c] = 0.f;
+    }
+    for (int k = q; k < g.multires; k += 4) {
+      const float f = (float)(1 << k);
+      const int c = 3 + 6 * k;
 #pragma unroll
       for (int d = 0; d < 3; ++d) {
         float sn, co;
@@ -452,10 +478,7 @@ __global__ __launch_bounds__(256, 2) void color_bwd_h2_kernel(ColH2Args g) {
         o[c + d] = f * co * nb[d];
         o[c + 3 + d] = -f * sn * nb[d];
       }
-      c += 6;
-      f *= 2.f;
     }
-    for (; c < g.Ep; ++c) o[c] = 0.f;
   }
   __syncthreads();
   for (int idx = tid; idx < CT * (g.Ep / 4); idx += 256) {
@@ -495,6 +518,7 @@ static void col_fill(const Layout& L, const float* packed, PointBufs& pb, ColH2A
   g.ldwo = L.colo.Kp;
   g.cin = pb.cin;
   g.alb = pb.alb;
+  g.ac0_mask = pb.ac0_mask;
 }
 
 static double col_flops(const Layout& L, int64_t M) {

@@ -163,6 +163,7 @@ void carve_points(const Layout& L, Carver& c, int64_t M, int mode, PointBufs* pb
     pb->cin = c.take<float>(Mp * L.Cinp);
     for (int l = 0; l < L.nc; ++l) pb->ac[l] = c.take<float>(Mp * L.Hcp);
     pb->alb = c.take<float>(Mp * 4);
+    if (color_h2_supported(L)) pb->ac0_mask = c.take<unsigned>(Mp / 64 * 256 * 2);
     if (bf && bf16_color_supported(L)) {
       pb->cin8 = c.take<uint16_t>(Mp * L.Cinp);
       for (int l = 0; l < L.nc; ++l) pb->ac8[l] = c.take<uint16_t>(Mp * L.Hcp);

@@ -1023,6 +1023,44 @@ static int launch_absmax(const float* x, int64_t n, unsigned* slot, hipStream_t 
   return RNB_OK;
 }
 
+// out[k] = max over a list of word slots (float bits) — the finishing step of rnb_render_range
+__global__ void range_fold_kernel(const unsigned* __restrict__ words, int n, int k, float* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  unsigned m = 0u;
+  for (int i = 0; i < n; ++i) m = max(m, words[i]);
+  out[k] = __builtin_bit_cast(float, m);
+}
+
+// rnb_render_range: out[0..4] as documented in include/rnbneus.h.  The maxima of the saved state are taken by a pass over the
+// buffers themselves (the hot path records them only for tiles beyond the fixed scales' range); out doubles as scratch.
+int launch_range_report(const Layout& L, const float* packed, const PointBufs& pb, bool with_color, bool with_backward, float* out,
+                        hipStream_t s) {
+  RNB_CHECK_HIP(hipMemsetAsync(out, 0, 8 * sizeof(float), s));
+  unsigned* w = reinterpret_cast<unsigned*>(out);
+  const H2Tab* tab = h2_tab(L, packed);
+  if (tab != nullptr) {
+    hipLaunchKernelGGL(range_fold_kernel, dim3(1), dim3(64), 0, s, tab->wmax, L.nh + 1 + L.nc, 0, out);
+    RNB_CHECK_LAUNCH();
+  }
+  const int64_t n = pb.Mp * L.Hp;
+  const bool bf = is_bf16(L);   // (bf16 state is not fp32: only the fp32 buffers are scanned)
+  if (!bf) {
+    RNB_TRY(launch_absmax(pb.e, pb.Mp * L.Ep, w + 1, s));
+    for (int l = 0; l < L.nh; ++l) RNB_TRY(launch_absmax(pb.a[l], n, w + 1, s));
+    if (pb.gz[0] != nullptr)
+      for (int l = 0; l < L.nh; ++l) RNB_TRY(launch_absmax(pb.gz[l], n, w + 2, s));
+  }
+  if (with_color && pb.cin != nullptr) {
+    RNB_TRY(launch_absmax(pb.cin, pb.Mp * L.Cinp, w + 3, s));
+    for (int l = 0; l < L.nc; ++l) RNB_TRY(launch_absmax(pb.ac[l], pb.Mp * L.Hcp, w + 3, s));
+  }
+  if (with_backward && pb.amax != nullptr && is_x2h(L)) {
+    hipLaunchKernelGGL(range_fold_kernel, dim3(1), dim3(64), 0, s, pb.amax, (int)AMAX_SLOTS, 4, out);
+    RNB_CHECK_LAUNCH();
+  }
+  return RNB_OK;
+}
+
 int launch_pe_points(const Layout& L, const float* pts, int64_t M, PointBufs& pb, hipStream_t s) {
   hipLaunchKernelGGL(pe_points_kernel, dim3(blocks_for(pb.Mp, 256)), dim3(256), 0, s, pts, M, pb.Mp, L.sdf_scale,
                      L.multires, L.Ep, pb.x, pb.e);

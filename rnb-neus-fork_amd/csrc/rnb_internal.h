@@ -171,6 +171,7 @@ struct PointBufs {
                             // (float bits; zeroed by the first kernel of a render forward, grown by the forward sweeps)
   float* dw_part;           // partial slabs of the split-K weight-gradient GEMMs: [deterministic variant | staged kernel]
   int64_t dw_part_floats;
+  unsigned* ac0_mask;       // fused albedo kernels: relu'(ac_0) as bits [tiles][256][2] (color_h2.hip)
   float* col_part;          // fused albedo backward: per-tile column sums of the output layer's gradient [tiles][Co][256] + [tiles][Co]
   float* sdfh_part;         // sdf-head row gradient: per-slab column sums [kSdfHeadSlabs][Hp] + [kSdfHeadSlabs]
 };
@@ -191,6 +192,8 @@ int sweep_reverse(const Layout& L, const float* packed, PointBufs& pb, hipStream
 int sweep_color(const Layout& L, const float* packed, PointBufs& pb, const float* pts, const float* nrm, int nrm_ld,
                 hipStream_t s);
 int launch_copy_cols(const float* src, int ld, int ncols, int64_t M, float* out, hipStream_t s);
+int launch_range_report(const Layout& L, const float* packed, const PointBufs& pb, bool with_color, bool with_backward, float* out,
+                        hipStream_t s);
 int launch_fill_cols(const float* src, int ncols, int64_t M, int64_t Mp, int ld, float* dst, hipStream_t s);
 int64_t dw_partial_floats(const Layout& L, int64_t M, bool with_color);
 int64_t dw_staged_floats(const Layout& L, int64_t M, bool with_color);

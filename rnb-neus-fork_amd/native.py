@@ -7,7 +7,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librnbneus_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_LIN = 16
 
 MODE_CORE = 0
@@ -116,6 +116,8 @@ _SIGNATURES = {
     "rnb_render_fwd": (C.c_int, [_P(ModelDesc), C.c_void_p, _P(RenderArgs), C.c_void_p, C.c_size_t, C.c_void_p]),
     "rnb_render_bwd": (C.c_int, [_P(ModelDesc), C.c_void_p, _P(RenderArgs), _P(RenderGrads), C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rnb_render_range": (C.c_int, [_P(ModelDesc), C.c_void_p, C.c_void_p, C.c_size_t, C.c_int64, C.c_int32, C.c_int32,
+                                   C.c_void_p, C.c_void_p]),
     "rnb_algorithmic_flops": (C.c_int, [_P(ModelDesc), C.c_int64, C.c_int32, _P(C.c_double), _P(C.c_double)]),
     "rnb_algorithmic_bytes": (C.c_int, [_P(ModelDesc), C.c_int64, C.c_int32, _P(C.c_double)]),
     "rnb_gen_rays_at_view": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,

@@ -113,6 +113,8 @@ class _FinePass(torch.autograd.Function):
         with native.on_device(dev) as stream:
             native.check(lib.rnb_render_fwd(C.byref(desc), native.ptr(call["packed"]), C.byref(args), native.ptr(ws),
                                             ws.numel(), stream))
+        if renderer.track_range and (flags & native.FLAG_FORWARD_ONLY):
+            renderer._collect_range(desc, call["packed"], ws, B, S, flags)
         ctx.renderer, ctx.call, ctx.args, ctx.keep, ctx.ws, ctx.out = renderer, call, args, keep, ws, out
         # the descriptor AS OF this forward: the backward must carve the workspace with the layout the forward wrote,
         # whatever set_variant() did in between
@@ -164,6 +166,8 @@ class _FinePass(torch.autograd.Function):
             native.check(lib.rnb_render_bwd(C.byref(desc), native.ptr(call["packed"]), C.byref(ctx.args), C.byref(rg),
                                             native.ptr(packed_grad), C.c_void_p(dvar.data_ptr()), native.ptr(ctx.ws),
                                             ctx.ws.numel(), stream))
+        if renderer.track_range:
+            renderer._collect_range(desc, call["packed"], ctx.ws, ctx.args.B, ctx.args.S, ctx.args.flags)
         sdf_net, col_net = renderer.sdf_network, renderer.color_network
         sp = _mlp_struct(sdf_net.lins(), sdf_net.weight_norm)
         sg = _mlp_struct(sdf_net.lins(), sdf_net.weight_norm, grads=views)
@@ -213,6 +217,10 @@ class NeuSRenderer:
         self.last_z_vals = None
         self.last_extras = {}
         self.want_extras = False
+        # diagnostics: with track_range the largest operand magnitudes of every render are read back (rnb_render_range: one
+        # more pass over the saved state per step — off by default); range_report() returns the last ones
+        self.track_range = False
+        self._range = None
 
     # ------------------------------------------------------------------ data parallel
     def set_data_parallel(self, group=None, enabled=True, exact=True):
@@ -393,13 +401,30 @@ class NeuSRenderer:
                 u = slab[:res]
         return u.cpu().numpy() if to_host else u
 
+    def _collect_range(self, desc, packed, ws, B, S, flags):
+        if self._range is None or self._range.device != ws.device:
+            self._range = torch.zeros(8, dtype=torch.float32, device=ws.device)
+        with native.on_device(ws.device) as stream:
+            native.check(native.load().rnb_render_range(C.byref(desc), native.ptr(packed), native.ptr(ws), ws.numel(), B, S,
+                                                        flags, native.ptr(self._range), stream))
+
+    def range_report(self):
+        """Largest operand magnitudes of the last render made with `track_range = True` (one device-to-host copy):
+        `max_abs_weight`, `max_abs_activation` (SDF network, incl. the encoded input), `max_abs_jacobian_row`,
+        `max_abs_albedo_activation`, `max_abs_adjoint` (after a backward; 0 for forward-only renders).  The default arithmetic
+        takes every operand scale from the data (include/rnbneus.h, RNB_VARIANT_X2H): none of these has a limit; the
+        numbers say how far a model is from the range the fixed scales of ABI 4 assumed (weights 255, activations 1023)."""
+        if self._range is None:
+            raise RuntimeError("range_report(): set `track_range = True` and render first")
+        r = [float(x) for x in self._range.cpu()]
+        return {"max_abs_weight": r[0], "max_abs_activation": r[1], "max_abs_jacobian_row": r[2],
+                "max_abs_albedo_activation": r[3], "max_abs_adjoint": r[4]}
+
     def x2h_range_report(self):
-        """The default arithmetic (RNB_VARIANT_X2H, include/rnbneus.h) carries fixed power-of-two scales for operands of known
-        range: |effective weight| < 255.  (|activation| < 1023 depends on the inputs; a violation of either shows as
-        non-finite outputs.)  This helper — plain torch, off the hot path, one device-to-host copy — reports the largest
-        |g v / ||v||| over every layer of both networks, so that a model can be checked once after loading a checkpoint:
-        `{"max_abs_weight": m, "layer": name, "limit": 255.0, "ok": m < 255}`.  When `ok` is False, select the six-term
-        arithmetic with `set_variant(x2h=False)`."""
+        """Host-side (plain torch) maximum of |g v / ||v||| over every layer of both networks:
+        `{"max_abs_weight": m, "layer": name, "limit": 255.0, "ok": m < 255}`.  Kept from ABI 4, where a weight beyond 255
+        overflowed the fixed fp16 scale of the default arithmetic; since ABI 5 the scale of every matrix is taken from its own
+        maximum and `ok` is informative only.  `range_report()` gives the device-side maxima of a whole render."""
         worst, where = 0.0, None
         with torch.no_grad():
             for prefix, net in (("sdf", self.sdf_network), ("color", self.color_network)):

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/rnbneus.h but not exported"
     assert set(declared) == set(R.native.EXPORTED_SYMBOLS)
-    assert lib.rnb_abi_version() == 4
+    assert lib.rnb_abi_version() == 5
 
 
 def test_build_id_ties_stored_profiles_to_the_library(tmp_path, monkeypatch):
