@@ -109,7 +109,7 @@ typedef struct rnb_model_desc {
  *                             while the tile stays below 256); the saved state's that the weight gradients read per launch
  *                             (from maxima the forward leaves in the workspace); loss adjoints' per tile / per launch from
  *                             their recorded maxima, so any loss scale works (a loss times 2^k gives gradients times 2^k bit
- *                             for bit, tested at k = +-40).  In the old range the results are bit-identical to ABI 4's.  The RA
+ *                             for bit, tested at k = +-40).  In the old range the SDF network's sweeps give the same bits as ABI 4's.  The RA
  *                             sweep is bound by its saved-state traffic and keeps the six bf16 terms. */
 enum {
   RNB_VARIANT_BF16 = 1,

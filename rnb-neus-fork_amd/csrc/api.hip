@@ -486,7 +486,10 @@ RNB_API int rnb_render_fwd(const rnb_model_desc* desc, const float* packed, cons
   else if (use_color && use_fused(L) && color_h2_supported(L)) RNB_TRY(color_h2_forward(L, packed, rb.pb, rb.pts, rb.pb.nrm, s));
   else if (use_color) RNB_TRY(sweep_color(L, packed, rb.pb, rb.pts, rb.pb.nrm, 4, s));
   CompArgs c = comp_args_of(L, a, rb);
-  RNB_TRY(launch_composite_fwd(c, a->gradient_error, rb.gerr_den, a->gerr_partial, s));
+  c.gerr = a->gradient_error;
+  c.gerr_den = rb.gerr_den;
+  c.gerr_partial = a->gerr_partial;
+  RNB_TRY(launch_composite_fwd(c, s));
   return RNB_OK;
 }
 
@@ -522,7 +525,9 @@ RNB_API int rnb_render_bwd(const rnb_model_desc* desc, const float* packed, cons
   g.nbar = rb.pb.nbar;
   g.albbar = rb.pb.albbar;
   g.invs_part = rb.invs_part;
-  RNB_TRY(launch_composite_bwd(g, variance_grad, s));
+  g.dvar = variance_grad;
+  g.amax_to_zero = rb.pb.amax;
+  RNB_TRY(launch_composite_bwd(g, s));
   RNB_CHECK_HIP(hipMemsetAsync(packed_grad, 0, (size_t)L.total * sizeof(float), s));
   RNB_TRY(sweep_backward(L, packed, rb.pb, use_color, packed_grad, use_fused(L), s));
   return RNB_OK;

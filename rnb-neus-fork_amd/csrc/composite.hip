@@ -178,6 +178,8 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(CompArgs a) {
 }
 
 // gradient_error = sum_b num_b / (sum_b den_b + 1e-5); keeps the denominator for the backward.
+// (Round 5 folded this into composite_fwd_kernel — the last workgroup to arrive did the sum — and measured it: the ticket
+// atomic that every one of the 512 one-wave workgroups must wait for took the kernel from 15 to 36 us; a 5 us launch is cheaper.)
 __global__ __launch_bounds__(256) void gerr_finalize_kernel(const float* __restrict__ part, int64_t B,
                                                             float* __restrict__ gerr, float* __restrict__ den_out,
                                                             float* __restrict__ partial) {
@@ -201,6 +203,11 @@ __global__ __launch_bounds__(256) void gerr_finalize_kernel(const float* __restr
 
 __global__ __launch_bounds__(64) void composite_bwd_kernel(CompBwdArgs g) {
   __shared__ float sAlpha[kMaxS], sT[kMaxS], sWbar[kMaxS], sSuf[kMaxS];
+  // first kernel of a backward: the maxima of the adjoint tensors (PointBufs::amax) start from zero (was a memset launch)
+  if (g.amax_to_zero != nullptr && blockIdx.x == 0) {
+    static_assert(AMAX_SLOTS <= 64, "one wave zeroes the slots");
+    if ((int)threadIdx.x < AMAX_SLOTS) g.amax_to_zero[threadIdx.x] = 0u;
+  }
   const CompArgs& a = g.f;
   const int lane = threadIdx.x;
   const int64_t b = blockIdx.x;
@@ -377,20 +384,22 @@ int launch_fine_points(const float* rays_o, const float* rays_d, const float* z,
   return RNB_OK;
 }
 
-int launch_composite_fwd(const CompArgs& a, float* gerr, float* gerr_den, float* gerr_partial, hipStream_t s) {
+int launch_composite_fwd(const CompArgs& a, hipStream_t s) {
   if (a.S > kMaxS) RNB_FAIL(RNB_E_INVALID, "samples per ray %d > %d", a.S, kMaxS);
   if (a.L > kMaxL) RNB_FAIL(RNB_E_INVALID, "n_lights %d > %d", a.L, kMaxL);
+  if (a.gerr == nullptr || a.gerr_den == nullptr) RNB_FAIL(RNB_E_NULL, "composite: missing reduction buffers");
   hipLaunchKernelGGL(composite_fwd_kernel, dim3((unsigned)a.B), dim3(64), 0, s, a);
   RNB_CHECK_LAUNCH();
-  hipLaunchKernelGGL(gerr_finalize_kernel, dim3(1), dim3(256), 0, s, a.gerr_part, a.B, gerr, gerr_den, gerr_partial);
+  hipLaunchKernelGGL(gerr_finalize_kernel, dim3(1), dim3(256), 0, s, a.gerr_part, a.B, a.gerr, a.gerr_den, a.gerr_partial);
   RNB_CHECK_LAUNCH();
   return RNB_OK;
 }
 
-int launch_composite_bwd(const CompBwdArgs& g, float* dvar, hipStream_t s) {
+int launch_composite_bwd(const CompBwdArgs& g, hipStream_t s) {
+  if (g.dvar == nullptr) RNB_FAIL(RNB_E_NULL, "composite backward: missing reduction buffers");
   hipLaunchKernelGGL(composite_bwd_kernel, dim3((unsigned)g.f.B), dim3(64), 0, s, g);
   RNB_CHECK_LAUNCH();
-  hipLaunchKernelGGL(variance_grad_kernel, dim3(1), dim3(256), 0, s, g.invs_part, g.f.B, g.f.variance, dvar);
+  hipLaunchKernelGGL(variance_grad_kernel, dim3(1), dim3(256), 0, s, g.invs_part, g.f.B, g.f.variance, g.dvar);
   RNB_CHECK_LAUNCH();
   return RNB_OK;
 }

@@ -1158,7 +1158,7 @@ int sweep_backward(const Layout& L, const float* packed, PointBufs& pb, bool wit
   // x2h weight gradients: every adjoint tensor's producer (fused sweeps, albedo backward) records its maximum
   const bool h2 = is_x2h(L) && fused && !is_bf16(L) && pb.amax != nullptr;
   dw.h2 = h2;
-  if (h2) RNB_CHECK_HIP(hipMemsetAsync(pb.amax, 0, AMAX_SLOTS * sizeof(unsigned), s));
+  // (pb.amax was zeroed by the composite backward, the first kernel of rnb_render_bwd)
   const bool color_bf16 = is_bf16(L) && with_color && bf16_color_supported(L) && pb.cin8 != nullptr;
   // the albedo network's backward as ONE fused sweep (color_h2.hip), which also forms geb = J_pe(x) nbar_total
   const bool color_h2 = with_color && h2 && color_h2_supported(L) && pb.col_part != nullptr;

@@ -245,7 +245,7 @@ bool color_h2_supported(const Layout& L);
 int color_h2_forward(const Layout& L, const float* packed, PointBufs& pb, const float* pts, const float* nrm, hipStream_t s);
 int color_h2_backward(const Layout& L, const float* packed, PointBufs& pb, hipStream_t s);
 int64_t color_h2_part_floats(const Layout& L, int64_t M);
-constexpr int kSdfHeadSlabs = 32;   // row slabs of sdf_head_bwd_kernel's partial sums (summed in slab order: no atomics)
+constexpr int kSdfHeadSlabs = 64;   // row slabs of sdf_head_bwd_kernel's partial sums (summed in slab order: no atomics)
 
 // ---- RNB_VARIANT_BF16 (bf16.hip): bf16-operand sweeps of the 256-wide network, saved state in bf16 "K8" layout ----
 inline bool is_bf16(const Layout& L) { return (L.variant & RNB_VARIANT_BF16) != 0; }
@@ -292,6 +292,9 @@ struct CompArgs {
   float* weight_max;
   float* s_val;
   float* gerr_part;       // [B,2]
+  float* gerr;            // [1] gradient_error, gerr_den [1] its denominator, gerr_partial [2] or nullptr: this shard's sums
+  float* gerr_den;
+  float* gerr_partial;
   float* sdf_out;         // optional copies
   float* albedo_out;
 };
@@ -313,12 +316,14 @@ struct CompBwdArgs {
   float* nbar;               // [Mp,4]
   float* albbar;             // [Mp,4]
   float* invs_part;          // [B] partial d loss / d inv_s
+  float* dvar;               // [1] d loss / d variance
+  unsigned* amax_to_zero;    // PointBufs::amax (AMAX_SLOTS words) zeroed by the first workgroup, or nullptr
 };
 
 int launch_fine_points(const float* rays_o, const float* rays_d, const float* z, int64_t B, int S, float sample_dist,
                        float* pts, float* dists, unsigned* smax_to_zero, hipStream_t s);
-int launch_composite_fwd(const CompArgs& a, float* gerr, float* gerr_den, float* gerr_partial, hipStream_t s);
-int launch_composite_bwd(const CompBwdArgs& g, float* dvar, hipStream_t s);
+int launch_composite_fwd(const CompArgs& a, hipStream_t s);
+int launch_composite_bwd(const CompBwdArgs& g, hipStream_t s);
 
 // ---- sampling (sampling.hip) ---------------------------------------------------------------------
 int launch_z_init(const float* rays_o, const float* rays_d, const float* near, const float* far,
