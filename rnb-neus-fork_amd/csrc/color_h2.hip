@@ -71,7 +71,7 @@ __device__ inline float col_fwd_epilogue(const v16f (&acc)[2][2], float inv, con
                                          float* __restrict__ out, int64_t row0, int n0, int lane, unsigned* __restrict__ mask_out) {
   const int h = lane >> 5, cl = lane & 31;
   const BufRsrc ro = tile_rsrc(out + (size_t)row0 * FH, CT * FH * 4);
-  unsigned amb = 0u;   // (relu outputs are >= +0: their maximum on the bit patterns, h2_track2)
+  int amb = 0;   // (relu outputs are >= +0: their maximum on the bit patterns, h2_track2)
 #pragma unroll
   for (int tj = 0; tj < 2; ++tj) {
     const int col = n0 + tj * 32 + cl;

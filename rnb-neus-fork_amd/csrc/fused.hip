@@ -139,12 +139,54 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_forward_kernel
   v16f acc[TI][TJ];
   [[maybe_unused]] X3Mma<TI, TJ, WP> mm;
   if constexpr (X3) mm.request(g.w3 + WP * g.w_off[0], g.Kp[0], n0, lane);
+  // x2h, rare path: the tile at X (written by layer l_written, times SA) holds a value beyond the fixed scale — the waves
+  // exchange their maxima, every thread rescales the elements it wrote, the tile's maximum goes to PointBufs::smax
+  [[maybe_unused]] auto rescale_input = [&](float am_thread, int l_written) {
+    am_thread = wave_max(am_thread);
+    if (lane == 0) wmx[wave] = am_thread;
+    lds_barrier();
+    const float tm = tile_max<NW>(wmx);
+    if (SAVE && g.smax != nullptr && tid == 0) amax_tile_commit(g.smax + SMAX_A + l_written, tm);
+    if (tid == 0) ovf[l_written & 1] = 0;
+    x2h_dyn_scale(__builtin_bit_cast(unsigned, tm), sa, isa);
+    const float f = sa * (1.f / SA);
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+      for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) X[(ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * FP + n0 + tj * 32 + cl] *= f;
+    lds_barrier();
+  };
+  [[maybe_unused]] float am_prev = 0.f;   // x2h: this thread's maximum of what it wrote to the tile in the previous layer
   for (int l = 0; l < g.nh; ++l) {
+    // x2h: the flag of the tile this layer reads is REQUESTED here and looked at after the matrix loop (its LDS round trip
+    // hides under the loop; read right behind the previous layer's barrier it cost F(save) 7 us): the product runs
+    // speculatively on the fixed scale and is redone on the rare tile that needed another one
+    [[maybe_unused]] int pend = 0;
+    if constexpr (H2 && (RNB_H2_GUARD_AB == 0 || RNB_H2_GUARD_AB == 3)) {
+      if (l > 0) pend = *reinterpret_cast<const volatile int*>(&ovf[(l - 1) & 1]);
+    }
     // x2h: accumulator -> pre-activation: 1 / (scale of the tile x scale of this layer's matrix in the mirror)
-    [[maybe_unused]] const float inv = H2 ? isa * h2_iws_at(iwsv, l) : 1.f;
+#if RNB_H2_GUARD_AB == 3   // (timing experiment only: the round-4 literal instead of the runtime factor)
+    [[maybe_unused]] float inv = H2 ? 1.f / (kH2ActScale * kH2WScale) : 1.f;
+#else
+    [[maybe_unused]] float inv = H2 ? isa * h2_iws_at(iwsv, l) : 1.f;
+#endif
     if constexpr (X3) {   // the next product's first weight steps are requested before this layer's epilogue
       const x3raw* wn = l + 1 < g.nh ? g.w3 + WP * g.w_off[l + 1] : (g.with_feat ? g.w3 + WP * g.wf_off : nullptr);
       mm.run(X, g.w3 + WP * g.w_off[l], g.Kp[l], n0, lane, acc, wn, FH, n0);
+      if constexpr (H2 && (RNB_H2_GUARD_AB == 0 || RNB_H2_GUARD_AB == 3)) {
+        if (__builtin_expect(__builtin_amdgcn_readfirstlane(pend) != 0, 0)) {   // (workgroup-uniform)
+          lds_barrier();   // every wave has finished its (void) pass over the tile
+          rescale_input(am_prev, l - 1);
+#if RNB_H2_GUARD_AB != 3
+          inv = isa * h2_iws_at(iwsv, l);
+#endif
+          mm.request(g.w3 + WP * g.w_off[l], g.Kp[l], n0, lane);
+          mm.run(X, g.w3 + WP * g.w_off[l], g.Kp[l], n0, lane, acc, wn, FH, n0);
+        }
+      }
     } else layer_mma_nt<TI, NoHook, TJ>(X, g.packed + g.w_off[l], g.Kp[l], n0, lane, acc);
     if constexpr (NBUF == 1) lds_barrier();   // every wave has finished reading the input activations
     const float* bias = g.packed + g.b_off[l];
@@ -157,9 +199,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_forward_kernel
     const int n_real = g.n_real[l];
     const bool pe_tail = (l + 1 == g.skip);
     const bool last = (l + 1 == g.nh);
-    // x2h: max |.| of what this thread writes to the tile.  Softplus outputs are >= +0, where floats order like their bit
-    // patterns: ONE v_max3_u32 per pair of values (a NaN reads as a large integer and raises the flag, harmlessly).
-    [[maybe_unused]] unsigned amb = 0u;
+    // x2h: max |.| of what this thread writes to the tile.  Softplus outputs are >= +0: ONE v_max3_i32 per pair of values
+    // (h2_track2), no branch; the signed encoding columns of the one tile that carries the skip connection are tracked where
+    // they are written (a per-pair choice between the two forms cost a scalar branch per pair: +5 % on this kernel).
+    [[maybe_unused]] int amb = 0;
     [[maybe_unused]] float am = 0.f;
 #pragma unroll
     for (int tj = 0; tj < TJ; ++tj) {
@@ -184,13 +227,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_forward_kernel
             const bool pe_col = pe_tail && col < n_real + g.pe;
             a = vf2{pe_col ? E[row * FEP + (col - n_real)] : 0.f, pe_col ? E[(row + 1) * FEP + (col - n_real)] : 0.f};
             D = vf2{0.f, 0.f};
+            if constexpr (H2) am = fmaxf(am, fmaxf(fabsf(a.x), fabsf(a.y)));
           }
           Y[row * FP + col] = a.x * SA;
           Y[(row + 1) * FP + col] = a.y * SA;
-          if constexpr (H2 && RNB_H2_GUARD_AB != 1) {
-            if (tile_full) h2_track2(amb, a.x, a.y);
-            else h2_track2(amb, fabsf(a.x), fabsf(a.y));   // (the tile with the skip connection's signed encoding)
-          }
+          if constexpr (H2 && RNB_H2_GUARD_AB != 1) h2_track2(amb, a.x, a.y);
           if (SAVE) {
             bstore(ra, voff, rowc * FH * 4, a.x);
             bstore(ra, voff, (rowc + 1) * FH * 4, a.y);
@@ -205,32 +246,19 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_forward_kernel
       }
     }
     if constexpr (H2 && RNB_H2_GUARD_AB != 1) {
-      am = __builtin_bit_cast(float, amb);
+      am = fmaxf(am, __builtin_bit_cast(float, amb));
       h2_raise_flag(am, &ovf[l & 1], lane);
     }
     lds_barrier();   // the new activations are visible to every wave
-    if constexpr (H2 && RNB_H2_GUARD_AB == 0) {
+    if constexpr (H2) {   // (the fixed scale again, unless the next layer's look at the flag says otherwise)
       sa = SA;
       isa = 1.f / SA;
-      if (h2_flag_up(&ovf[l & 1])) {   // (workgroup-uniform; never taken by a network whose activations stay below 256)
-        am = wave_max(am);
-        if (lane == 0) wmx[wave] = am;
-        lds_barrier();
-        const float tm = tile_max<NW>(wmx);
-        if (SAVE && g.smax != nullptr && tid == 0) amax_tile_commit(g.smax + SMAX_A + l, tm);
-        if (tid == 0) ovf[l & 1] = 0;
-        x2h_dyn_scale(__builtin_bit_cast(unsigned, tm), sa, isa);
-        const float f = sa * (1.f / SA);
-#pragma unroll
-        for (int tj = 0; tj < TJ; ++tj)
-#pragma unroll
-          for (int ti = 0; ti < TI; ++ti)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) Y[(ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * FP + n0 + tj * 32 + cl] *= f;
-        lds_barrier();
-      }
+      am_prev = am;
     }
     if constexpr (NBUF == 2) { float* t = X; X = Y; Y = t; }
+  }
+  if constexpr (H2 && RNB_H2_GUARD_AB == 0) {   // the last hidden layer's tile, read by the two heads below
+    if (h2_flag_up(&ovf[(g.nh - 1) & 1])) rescale_input(am_prev, g.nh - 1);
   }
 
   // ---- sdf head: row 0 of the output layer (models/fields.py:104, :106-108) -----------------------------

@@ -69,10 +69,12 @@ __device__ inline float tile_scale(const float* wm, float& s, float& inv_s) {
   x2h_dyn_scale(__builtin_bit_cast(unsigned, m), s, inv_s);
   return m;
 }
-// m = max(m, a, b) on the BIT PATTERNS of two floats that are >= +0 (where floats order like unsigned integers): one
-// v_max3_u32 for two values.  (Written as asm: from the nested max the compiler made a float maximum plus an integer one.)
-__device__ inline void h2_track2(unsigned& m, float a, float b) {
-  asm("v_max3_u32 %0, %1, %2, %3" : "=v"(m) : "v"(m), "v"(a), "v"(b));
+// m = max(m, a, b) on the BIT PATTERNS of two floats, compared as SIGNED integers: for values >= +0 that is the float order, a
+// negative value reads as a negative integer and never wins (callers whose values can be negative keep those apart), a NaN
+// with the sign bit clear reads as a large integer and raises the flag, harmlessly.  One v_max3_i32 for two values.
+// (Written as asm: from the nested max the compiler made a float maximum plus an integer one.)
+__device__ inline void h2_track2(int& m, float a, float b) {
+  asm("v_max3_i32 %0, %1, %2, %3" : "=v"(m) : "v"(m), "v"(a), "v"(b));
 }
 // the waves of a workgroup agree on whether the tile just written needs a smaller scale: `mine` = this thread's maximum;
 // flag = one LDS word (zero unless raised; reset by the slow path)
