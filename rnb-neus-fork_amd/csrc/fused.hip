@@ -7,6 +7,8 @@
 //
 //   fused_forward_kernel   positional encoding + F sweep (+ sdf head, + feature head)
 //                          models/embedder.py:40-46, models/fields.py:82-104
+#include <type_traits>
+
 #include "fused_common.hip.h"
 
 // A/B switch (compile time): scalar instead of packed fp32 math in the x3 forward epilogue.  Measured on one box, two
@@ -195,21 +197,20 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_forward_kernel
     // pair per element, i.e. 128 extra registers and spills)
     const BufRsrc ra = tile_rsrc(SAVE ? g.a[l] + (size_t)row0 * FH : nullptr, FT * FH * 4);
     const BufRsrc rD = tile_rsrc(SAVE ? g.D[l] + (size_t)row0 * FH : nullptr, FT * FH * 4);
-    const BufRsrc rg = tile_rsrc((SAVE && g.gz_last) ? g.gz_last + (size_t)row0 * FH : nullptr, FT * FH * 4);
     const int n_real = g.n_real[l];
     const bool pe_tail = (l + 1 == g.skip);
-    const bool last = (l + 1 == g.nh);
     // x2h: max |.| of what this thread writes to the tile.  Softplus outputs are >= +0: ONE v_max3_i32 per pair of values
     // (h2_track2), no branch; the signed encoding columns of the one tile that carries the skip connection are tracked where
     // they are written (a per-pair choice between the two forms cost a scalar branch per pair: +5 % on this kernel).
     [[maybe_unused]] int amb = 0;
     [[maybe_unused]] float am = 0.f;
-#pragma unroll
-    for (int tj = 0; tj < TJ; ++tj) {
+    // One column tile of the wave.  FULL (wave-uniform, decided per tile outside): every column is a real output of the layer —
+    // no per-element column check.  The choice is made ONCE per tile between two instantiations: as a condition inside the
+    // loops the compiler kept it as a scalar branch per value pair (32 taken branches per tile and layer).
+    auto column_tile = [&](auto full_c, int tj) {
+      constexpr bool FULL = decltype(full_c)::value;
       const int col = n0 + tj * 32 + cl;
       const float bc = bias[col];
-      const float ws = (SAVE && last && g.gz_last) ? g.packed[g.wsdf_off + col] : 0.f;
-      const bool tile_full = n0 + tj * 32 + 32 <= n_real;   // wave-uniform: no per-element column checks
       const unsigned voff = (unsigned)(4 * h * FH + col) * 4u;
 #pragma unroll
       for (int ti = 0; ti < TI; ++ti) {
@@ -223,11 +224,13 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_forward_kernel
                            : vf2{acc[ti][tj][r] + bc, acc[ti][tj][r + 1] + bc};
           if constexpr (SAVE) softplus_aD_sel<X3 && RNB_X3_SCALAR_EPI>(z, a, D);
           else a = softplus_a_sel<X3 && RNB_X3_SCALAR_EPI>(z);
-          if (!tile_full && col >= n_real) {   // only the tile straddling the skip connection's PE columns
-            const bool pe_col = pe_tail && col < n_real + g.pe;
-            a = vf2{pe_col ? E[row * FEP + (col - n_real)] : 0.f, pe_col ? E[(row + 1) * FEP + (col - n_real)] : 0.f};
-            D = vf2{0.f, 0.f};
-            if constexpr (H2) am = fmaxf(am, fmaxf(fabsf(a.x), fabsf(a.y)));
+          if constexpr (!FULL) {
+            if (col >= n_real) {   // only the tile straddling the skip connection's PE columns
+              const bool pe_col = pe_tail && col < n_real + g.pe;
+              a = vf2{pe_col ? E[row * FEP + (col - n_real)] : 0.f, pe_col ? E[(row + 1) * FEP + (col - n_real)] : 0.f};
+              D = vf2{0.f, 0.f};
+              if constexpr (H2) am = fmaxf(am, fmaxf(fabsf(a.x), fabsf(a.y)));
+            }
           }
           Y[row * FP + col] = a.x * SA;
           Y[(row + 1) * FP + col] = a.y * SA;
@@ -237,13 +240,14 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_forward_kernel
             bstore(ra, voff, (rowc + 1) * FH * 4, a.y);
             bstore(rD, voff, rowc * FH * 4, D.x);
             bstore(rD, voff, (rowc + 1) * FH * 4, D.y);
-            if (last && g.gz_last) {
-              bstore(rg, voff, rowc * FH * 4, ws * D.x);
-              bstore(rg, voff, (rowc + 1) * FH * 4, ws * D.y);
-            }
           }
         }
       }
+    };
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj) {
+      if (n0 + tj * 32 + 32 <= n_real) column_tile(std::true_type{}, tj);   // (wave-uniform)
+      else column_tile(std::false_type{}, tj);
     }
     if constexpr (H2 && RNB_H2_GUARD_AB != 1) {
       am = fmaxf(am, __builtin_bit_cast(float, amb));
@@ -479,7 +483,9 @@ int fused_forward(const Layout& L, const float* packed, const float* pts, int64_
   g.sdf = pb.sdf;
   g.x4 = pb.x;
   g.e = pb.e;
-  g.gz_last = need_gz_last ? pb.gz[L.nh - 1] : nullptr;
+  // (the fused reverse sweep seeds itself from D_last: nobody asks this kernel for the seed any more)
+  if (need_gz_last) RNB_FAIL(RNB_E_INVALID, "fused forward sweep: the reverse sweep's seed is formed by fused_reverse_kernel");
+  g.gz_last = nullptr;
   g.h2tab = h2 ? h2_tab(L, packed) : nullptr;
   g.smax = (save && h2) ? pb.smax : nullptr;
   // algorithmic FLOPs of the sweep (real layer shapes), for the optional event instrumentation
