@@ -803,6 +803,10 @@ def run_train(args):
             for k, v in kw.items():
                 setattr(la, k, v)
             la.steps, la.warmup = args.also_steps, 5
+            import gc
+            import torch
+            gc.collect()
+            torch.cuda.empty_cache()    # (each leg's workspaces have their own sizes: start it from an unfragmented pool)
             l = measure_train(la, ctx, with_cpu=False)
             r = l.get("roofline") or {}
             also.append({"leg": name, "metric": l["metric"], "value": l["value"], "unit": l["unit"], "ms_per_step": l["ms_per_step"],

@@ -975,7 +975,11 @@ int64_t dw_staged_floats(const Layout& L, int64_t M, bool with_color) {
 // floats of ordered-reduction workspace of the atomic kernels (RNB_VARIANT_DETERMINISTIC), same job list as sweep_backward
 int64_t dw_partial_floats(const Layout& L, int64_t M, bool with_color) {
   int64_t total = 0;
+  // (jobs that DwBatch::add hands to the one-workgroup-per-gradient kernels leave through that kernel's own slabs, whatever
+  // the variant: no ordered-reduction slabs — and no 200 MB memset per step — for them)
+  const bool staged_path = (is_x3(L) || (L.variant & RNB_VARIANT_DW_STAGED) != 0) && !(L.variant & RNB_VARIANT_DW_LDS);
   auto job = [&](int N, int K) {
+    if (staged_path && x3_job_shape(is_x3(L), N, K) && M % kStChunk == 0) return;
     int v, splits, rows;
     dw_plan(M, N, K, &v, &splits, &rows);
     total += (int64_t)splits * N * K + (int64_t)splits * N;
@@ -1150,7 +1154,7 @@ int sweep_backward(const Layout& L, const float* packed, PointBufs& pb, bool wit
   // workspace = [ordered-reduction slabs of the atomic kernels (deterministic variant only) | slabs of the staged kernel]
   const int64_t staged_floats = dw_staged_floats(L, M, with_color);
   const int64_t det_floats = pb.dw_part_floats - staged_floats;
-  if (det) RNB_CHECK_HIP(hipMemsetAsync(pb.dw_part, 0, (size_t)det_floats * sizeof(float), s));
+  if (det && det_floats > 0) RNB_CHECK_HIP(hipMemsetAsync(pb.dw_part, 0, (size_t)det_floats * sizeof(float), s));
   DwBatch dw(M, s, (L.variant & RNB_VARIANT_DW_LDS) != 0, det ? pb.dw_part : nullptr, det ? det_floats : 0,
              pb.dw_part + det_floats, staged_floats);
   dw.x3 = is_x3(L);
