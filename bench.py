@@ -719,8 +719,8 @@ def measure_train(args, ctx, with_cpu=True):
                            ("fp32 MFMA (v_mfma_f32_32x32x2_f32)" if args.f32_mfma else
                             "x3: every fp32 operand as 3 bf16 terms (hi + mid + lo = x exactly), 6 of the 9 cross terms per product "
                             "on v_mfma_f32_32x32x16_bf16, fp32 accumulate; dropped terms < 2^-26 |ab|" if args.x2h is False else
-                            "x2h: fp32 operands as 2 fp16 terms after a power-of-two scale (fixed for weights / activations / "
-                            "Jacobian rows, taken from the data for loss adjoints), 3 of the 4 cross terms per product on "
+                            "x2h: fp32 operands as 2 fp16 terms after a power-of-two scale taken from the data (per matrix for weights, per "
+                            "64-point tile and layer for activations / Jacobian rows / adjoints: no operand range), 3 of the 4 cross terms per product on "
                             "v_mfma_f32_32x32x16_f16, fp32 accumulate; operand representation <= 2^-22 (rms 2^-23.6); the RA sweep "
                             "keeps x3 (3 bf16 terms per operand, 6 cross terms)")),
             "build_id": bid,
