@@ -11,11 +11,17 @@
 
 #include "fused_common.hip.h"
 
-// A/B switch (compile time): scalar instead of packed fp32 math in the x3 forward epilogue.  Measured on one box, two
-// runs each: packed 3.694 / 3.684 ms per step, scalar 3.71 / 3.78 — the epilogue runs beside ANOTHER wave's MFMAs, where
-// the packed forms keep their halved issue count.
+// A/B switches (compile time): scalar instead of packed fp32 math in the forward epilogue (same operations element by element:
+// the same bits).  Six bf16 terms (round 2, one box, two runs each): packed 3.694 / 3.684 ms per step, scalar 3.71 / 3.78.
+// Three fp16 terms (round 5, profiles/r05_ab_experiments.txt §11): scalar is the faster one, F(save) 0.323 / 0.324 against
+// 0.335 / 0.330 ms — a v_pk_*_f32 holds the vector port for two passes, saves no port time over the two instructions it
+// replaces, and cannot take the |x| modifier (two v_or per pair instead); with half as many MFMAs per layer the epilogue's
+// port time is what a layer's cycle is made of (§11: stamps).
 #ifndef RNB_X3_SCALAR_EPI
 #define RNB_X3_SCALAR_EPI 0
+#endif
+#ifndef RNB_H2_SCALAR_EPI
+#define RNB_H2_SCALAR_EPI 1
 #endif
 // A/B switches (compile time, tools/build_variant.sh): what the x2h range guard of the forward sweep costs.
 // 1: no maximum tracking and no flag (the tile is assumed in range: round 4's behaviour); 2: tracking, but the flag is not read
@@ -222,8 +228,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void fused_forward_kernel
           vf2 a, D;
           const vf2 z = H2 ? vf2{__builtin_fmaf(acc[ti][tj][r], inv, bc), __builtin_fmaf(acc[ti][tj][r + 1], inv, bc)}
                            : vf2{acc[ti][tj][r] + bc, acc[ti][tj][r + 1] + bc};
-          if constexpr (SAVE) softplus_aD_sel<X3 && RNB_X3_SCALAR_EPI>(z, a, D);
-          else a = softplus_a_sel<X3 && RNB_X3_SCALAR_EPI>(z);
+          constexpr bool SCALAR_EPI = H2 ? RNB_H2_SCALAR_EPI != 0 : (X3 && RNB_X3_SCALAR_EPI != 0);
+          if constexpr (SAVE) softplus_aD_sel<SCALAR_EPI>(z, a, D);
+          else a = softplus_a_sel<SCALAR_EPI>(z);
           if constexpr (!FULL) {
             if (col >= n_real) {   // only the tile straddling the skip connection's PE columns
               const bool pe_col = pe_tail && col < n_real + g.pe;

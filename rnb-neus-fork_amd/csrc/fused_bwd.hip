@@ -71,8 +71,8 @@ __device__ inline void layer_mma(const float* __restrict__ X, const FusedBwdArgs
 // R sweep
 // ---------------------------------------------------------------------------------------------------------
 // H2 (with X3): the products as three fp16 terms (gemm.hip.h, "x2h"); the LDS tile then holds gz times SG and g.w3 is the
-// fp16 mirror.  The operands are Jacobian rows of the SDF (d sdf / d a_l: bounded by the network's Lipschitz constant,
-// |.| < 1023 assumed like the activations), not loss adjoints: a fixed scale serves.
+// fp16 mirror.  The operands are Jacobian rows of the SDF (d sdf / d a_l), not loss adjoints: the fixed scale 2^6 serves unless a
+// tile holds a row beyond 256, which the writers notice (flag word in LDS) and answer with a scale from the tile's own maximum.
 template <int TI, int NW = 4, bool X3 = false, bool H2 = false>
 __global__ __launch_bounds__(64 * NW, (NW == 8 && TI == 2) ? 1 : 2) void fused_reverse_kernel(FusedBwdArgs g) {
   static_assert(!H2 || X3, "x2h is a form of the split-operand path");

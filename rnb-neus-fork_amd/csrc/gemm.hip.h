@@ -402,9 +402,10 @@ __device__ inline float acc_absmax(const v16f (&acc)[TI][TJ], int lane, int rows
 // terms.  These per-product errors are independent and far below what the fp32 accumulation of a K = 256 dot product
 // commits (2.7 ulp rms, profiles/r04_sdf_bias.txt): measured on the full network, the SDF comes out closer to fp64 than
 // with the six bf16 terms (rms 8.3e-8 against 1.07e-7, profiles/r04_x2h_check.txt).  What bf16 gave for free — range — is
-// bought with the scales: operands whose magnitudes are known a priori only (weights: S = 2^8, |w| < 255; activations and
-// the reverse sweep's Jacobian rows: S = 2^6, |a| < 1023).  Out-of-range operands give inf / NaN results, never silently
-// wrong ones.  The adjoints of the backward sweeps span too many binades for a fixed scale: they stay on the bf16 scheme.
+// bought with the scales, and every scale is taken from the data it scales (round 5; fused_common.hip.h, "per-tile scale"):
+// per matrix for the weights (2^8 while max |w| < 64), per 64-point tile and layer for activations, network inputs and the
+// reverse sweep's Jacobian rows (2^6 while the tile stays below 256), from recorded maxima for loss adjoints and for the saved
+// state the weight-gradient kernel reads.  No operand has a range to respect.  (The RA sweep alone stays on the bf16 scheme.)
 typedef _Float16 x2h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 x2h2 __attribute__((ext_vector_type(2)));
 constexpr float kH2ActScale = 64.f, kH2WScale = 256.f;
